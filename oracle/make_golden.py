@@ -1,0 +1,172 @@
+"""Generates tests/golden/* .  Runs ONLY in the build container (needs /root/reference).
+
+Nothing here ships to the GPU box as code the tests execute; the tests read the emitted data.
+The reference's own pure-numpy modules (Base/BaseRecommender.py, Base/Evaluation/*) are imported
+from where they lie to produce expected outputs; no reference source is copied.
+
+    python oracle/make_golden.py            # all fixtures
+"""
+import json
+import os
+import pickle
+import shutil
+import sys
+
+import numpy as np
+import scipy.sparse as sps
+import numpy.ma  # noqa: F401  (must be imported before the alias shim)
+
+REF = "/root/reference"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, ROOT)
+
+
+def _import_reference():
+    # numpy>=1.24 dropped the aliases the reference still uses (BaseRecommender.py:31, Evaluator.py:155)
+    np.int = int
+    np.bool = np.bool_
+    np.float = float
+    sys.path.insert(0, REF)
+    from Base.BaseRecommender import BaseRecommender
+    from Base.Evaluation.Evaluator import EvaluatorHoldout
+    return BaseRecommender, EvaluatorHoldout
+
+
+def _clean(results):
+    return {str(c): {k: float(v) for k, v in d.items()} for c, d in results.items()}
+
+
+def kat1(BaseRecommender, EvaluatorHoldout):
+    """Surviving TF V2-bundle checkpoint -> item-mode scores -> reference evaluator
+    == stored test_results.pkl  (SURVEY F4, Appendix C)."""
+    d = os.path.join(REF, "feature_matching/GANMF_item_LastFM_00/GANMF_item_LastFM")
+    raw = np.fromfile(os.path.join(d, "GANMF_item.data-00000-of-00001"), dtype="<f4")
+    assert raw.nbytes == 2090708
+    # key-sorted tensor order, offsets in bytes (Appendix C)
+    off = {"bd": (0, (1884,)), "Wd": (7536, (133, 1884)), "be": (1009824, (133,)),
+           "We": (1010356, (1884, 133)), "V": (2012644, (1884, 1)), "U": (2020180, (17632, 1))}
+    t = {k: raw[o // 4: o // 4 + int(np.prod(s))].reshape(s).copy() for k, (o, s) in off.items()}
+    # only the generator tensors are needed for scoring; the autoencoder tensors stay behind
+    np.savez_compressed(os.path.join(OUT, "kat1_checkpoint_tensors.npz"), U=t["U"], V=t["V"],
+                        be=t["be"], bd=t["bd"])
+    for split in ("train", "test"):
+        shutil.copyfile(os.path.join(REF, "experiments/datasets/LastFM_URM_%s.npz" % split),
+                        os.path.join(OUT, "LastFM_URM_%s.npz" % split))
+    expected = pickle.load(open(os.path.join(d, "test_results.pkl"), "rb"))
+
+    urm_train = sps.load_npz(os.path.join(OUT, "LastFM_URM_train.npz")).tocsr()
+    urm_test = sps.load_npz(os.path.join(OUT, "LastFM_URM_test.npz")).tocsr()
+
+    class CheckpointScorer(BaseRecommender):
+        """item mode (GANMF.py:288-290): generator 'users' are the catalogue items."""
+        RECOMMENDER_NAME = "kat1"
+
+        def _compute_item_score(self, user_id_array, items_to_compute=None):
+            return (t["U"] @ t["V"].T).T[user_id_array]
+
+    rec = CheckpointScorer(urm_train)
+    got, _ = EvaluatorHoldout(urm_test, [5, 10, 20, 50]).evaluateRecommender(rec)
+    for c in expected:
+        for k in expected[c]:
+            # float32-accumulated metrics differ in the last ulp across numpy versions
+            assert abs(got[c][k] - expected[c][k]) <= 1e-9 + 2e-7 * abs(expected[c][k]), (c, k, got[c][k], expected[c][k])
+    users = np.arange(0, 1884, 97)
+    ranking, scores = rec.recommend(users, cutoff=50, remove_seen_flag=True, return_scores=True)
+    json.dump({"expected_metrics": _clean(expected), "users": users.tolist(), "ranking_top50": ranking},
+              open(os.path.join(OUT, "kat1_expected.json"), "w"))
+    print("KAT-1 reproduced: MAP@5 =", got[5]["MAP"], "RMSE =", got[5]["RMSE"])
+
+
+def evaluator_golden(BaseRecommender, EvaluatorHoldout):
+    """Non-degenerate regime for the build's own evaluator: a seeded random rank-8 model scored
+    by the reference evaluator on the hetrec2011 validation split."""
+    for split in ("train_small", "validation"):
+        shutil.copyfile(os.path.join(REF, "experiments/datasets/Movielenshetrec2011_URM_%s.npz" % split),
+                        os.path.join(OUT, "hetrec2011_URM_%s.npz" % split))
+    urm_train = sps.load_npz(os.path.join(OUT, "hetrec2011_URM_train_small.npz")).tocsr()
+    urm_val = sps.load_npz(os.path.join(OUT, "hetrec2011_URM_validation.npz")).tocsr()
+    rng = np.random.RandomState(77)
+    # popularity-biased so that metrics are far from zero
+    pop = np.asarray(urm_train.sum(axis=0)).ravel().astype(np.float32)
+    Uf = rng.rand(urm_train.shape[0], 8).astype(np.float32)
+    Vf = (rng.rand(urm_train.shape[1], 8) * (1 + np.log1p(pop))[:, None]).astype(np.float32)
+
+    class R(BaseRecommender):
+        RECOMMENDER_NAME = "evalgold"
+
+        def _compute_item_score(self, user_id_array, items_to_compute=None):
+            return Uf[user_id_array] @ Vf.T
+
+    got, _ = EvaluatorHoldout(urm_val, [5, 10]).evaluateRecommender(R(urm_train))
+    np.savez_compressed(os.path.join(OUT, "evaluator_factors.npz"), U=Uf, V=Vf)
+    json.dump(_clean(got), open(os.path.join(OUT, "evaluator_expected.json"), "w"))
+    print("evaluator golden: MAP@5 =", got[5]["MAP"], "NDCG@5 =", got[5]["NDCG"])
+
+
+def tiny_trajectories():
+    """G2: tiny oracle trajectories (regression pins for the oracle; the GPU parity tests
+    recompute the oracle live and ALSO compare against these stored tensors)."""
+    from oracle.ganmf_oracle import DisGANMFOracle, GANMFOracle, reference_epoch_permutations
+    rng = np.random.RandomState(2024)
+    U, N = 37, 53
+    urm = sps.csr_matrix((rng.rand(U, N) < 0.15).astype(np.float32))
+    urm[np.arange(U), rng.randint(0, N, U)] = 1.0   # no empty rows
+    urm = sps.csr_matrix(urm)
+    sps.save_npz(os.path.join(OUT, "tiny_urm.npz"), urm)
+    out = {}
+    cases = {
+        "ganmf_user_hinge_on": dict(cls="GANMF", mode="user", k=5, e=7, B=8, epochs=3, d_steps=1, g_steps=1,
+                                    hp=dict(d_lr=1e-3, g_lr=2e-3, d_reg=1e-4, m=10.0, recon_coefficient=0.05)),
+        "ganmf_item_steps2": dict(cls="GANMF", mode="item", k=4, e=6, B=16, epochs=2, d_steps=2, g_steps=2,
+                                  hp=dict(d_lr=1e-3, g_lr=1e-3, d_reg=0.0, g_reg=1e-3, m=1.0, recon_coefficient=0.5)),
+        "disganmf_user_tanh2": dict(cls="DisGANMF", mode="user", k=5, e=6, B=8, epochs=2, d_steps=1, g_steps=1,
+                                    hp=dict(d_lr=1e-3, g_lr=1e-3, d_reg=1e-4, recon_coefficient=0.3,
+                                            d_layers=2, d_hidden_act="tanh")),
+    }
+    for name, c in cases.items():
+        m = urm if c["mode"] == "user" else sps.csr_matrix(urm.T)
+        nu, ni = m.shape
+        for prec in ("f32", "f64"):
+            dt = np.float32 if prec == "f32" else np.float64
+            if c["cls"] == "GANMF":
+                o = GANMFOracle(nu, ni, c["k"], c["e"], dtype=dt, seed=11, **c["hp"])
+            else:
+                o = DisGANMFOracle(nu, ni, c["k"], d_nodes=c["e"], dtype=dt, seed=11, **c["hp"])
+            if prec == "f32":
+                for n, v in o.get_params().items():
+                    out["%s/init/%s" % (name, n)] = v
+            dls, gls = [], []
+            for perm in reference_epoch_permutations(nu, c["epochs"], 1337):
+                dl, gl = o.train_epoch(m, perm, c["B"], c["d_steps"], c["g_steps"])
+                dls.append(dl)
+                gls.append(gl)
+            for n, v in o.get_params().items():
+                out["%s/%s/final/%s" % (name, prec, n)] = v
+            out["%s/%s/dloss" % (name, prec)] = np.concatenate(dls)
+            out["%s/%s/gloss" % (name, prec)] = np.concatenate(gls)
+        out["%s/config" % name] = np.array(json.dumps(c))
+    np.savez_compressed(os.path.join(OUT, "tiny_trajectories.npz"), **out)
+    print("tiny trajectories:", len(out), "arrays")
+
+
+def statistical_fixture():
+    """ML-1M train/test splits + tuned hyper-parameters + published metrics
+    (test_results/GANMF_user_1M/test_results.txt:1) for the long-horizon GPU KAT."""
+    for split in ("train", "test"):
+        shutil.copyfile(os.path.join(REF, "experiments/datasets/Movielens1M_URM_%s.npz" % split),
+                        os.path.join(OUT, "Movielens1M_URM_%s.npz" % split))
+    hp = json.load(open(os.path.join(REF, "experiments/GANMF_user_1M/best_params.txt")))
+    pub = pickle.load(open(os.path.join(REF, "test_results/GANMF_user_1M/test_results.pkl"), "rb"))
+    json.dump({"best_params": hp, "published": _clean(pub)},
+              open(os.path.join(OUT, "statistical_kat_ml1m_user.json"), "w"), indent=1)
+    print("statistical fixture: published MAP@5 =", pub[5]["MAP"])
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    BR, EH = _import_reference()
+    kat1(BR, EH)
+    evaluator_golden(BR, EH)
+    tiny_trajectories()
+    statistical_fixture()
