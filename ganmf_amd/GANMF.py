@@ -1,0 +1,263 @@
+"""GANMF recommender — host mirror of the reference class (GANRec/GANMF.py:23-342).
+
+Same constructor, fit() keyword arguments, return-value quirk, scoring and early-stopping hooks
+as the reference, so it can stand in for `GANRec.GANMF.GANMF` under RecSysExp.py /
+RunBestParameters.py.  Every number is produced by libganmf_hip.so (HIP kernels on gfx950)
+through the C ABI in include/ganmf_hip.h; this file holds only the epoch loop and bookkeeping.
+"""
+import os
+import pickle
+import time
+from datetime import datetime
+
+import numpy as np
+import scipy.sparse as sps
+
+from . import _lib as L
+from .base import BaseRecommender
+from .early_stopping import EarlyStoppingScheduler
+from .engine import Engine
+
+try:  # progress bar is cosmetic (GANMF.py:170,234)
+    import tqdm
+except Exception:  # pragma: no cover
+    tqdm = None
+
+
+def glorot_uniform(rng, shape):
+    """tf.glorot_uniform_initializer for [a, b] variables (GANMF.py:57): U(-L, L), L = sqrt(6/(a+b)).
+    TF's seeded Philox stream cannot be reproduced without TF; the build's documented default is
+    numpy RandomState(seed) drawing, in order, encoding/kernel, decoding/kernel, user_embeddings,
+    item_embeddings (biases are zero, tf.layers.dense default)."""
+    limit = np.sqrt(6.0 / (shape[0] + shape[1]))
+    return rng.uniform(-limit, limit, size=shape).astype(np.float32)
+
+
+class _TensorRef(object):
+    """Stands where the reference keeps tf.Variable objects in model.params (GANMF.py:119-122)."""
+
+    def __init__(self, tid, name):
+        self.tid, self.name = tid, name
+
+
+class _SessionShim(object):
+    """model.sess.run(var) -> ndarray, the only use callers make of the session (Utils_.py:305-308)."""
+
+    def __init__(self, model):
+        self._model = model
+
+    def run(self, fetch):
+        if isinstance(fetch, (list, tuple)):
+            return [self.run(f) for f in fetch]
+        if not isinstance(fetch, _TensorRef):
+            raise TypeError("only parameter handles can be fetched")
+        return self._model._get(fetch.tid)
+
+
+class GANMF(BaseRecommender):
+    RECOMMENDER_NAME = 'GANMF'
+
+    # (tensor id, reference variable name, attribute for shape)
+    _D_TENSORS = ((0, 'autoencoder/encoding/kernel'), (1, 'autoencoder/encoding/bias'),
+                  (2, 'autoencoder/decoding/kernel'), (3, 'autoencoder/decoding/bias'))
+    _G_TENSORS = ((L.T_USER_EMB, 'generator/user_embeddings'), (L.T_ITEM_EMB, 'generator/item_embeddings'))
+
+    def __init__(self, URM_train, mode='user', verbose=False, seed=1234, is_experiment=False, device=0):
+        if mode not in ['user', 'item']:
+            raise ValueError('Accepted training modes are `user` and `item`. Given was {}.', mode)
+        self.mode = mode
+        # the reference does not call super().__init__ (GANMF.py:26-51); keep its attributes
+        URM_train = sps.csr_matrix(URM_train, dtype=np.float32)
+        self._URM_eval = URM_train                       # user x item, what evaluators see
+        self._URM_fit = URM_train.T.tocsr() if mode == 'item' else URM_train   # training orientation
+        self.URM_train = self._URM_fit                   # GANMF.py:31-35
+        self.num_users, self.num_items = self.URM_train.shape
+        self.n_users, self.n_items = URM_train.shape
+        self.config = None
+        self.seed = seed
+        self.verbose = verbose
+        self.device = device
+        self.logsdir = os.path.join('plots', self.RECOMMENDER_NAME, datetime.now().strftime("%Y%m%d-%H%M%S"))
+        self.is_experiment = is_experiment
+        if not self.is_experiment:
+            os.makedirs(self.logsdir, exist_ok=True)
+        self.items_to_ignore_flag = False
+        self.items_to_ignore_ID = np.array([], dtype=int)
+        self.filterTopPop = False
+        self.filterTopPop_ItemsID = np.array([], dtype=int)
+        self.initial_weights = None     # optional dict {We,be,Wd,bd,U,V}: explicit init (parity tests)
+        self.engine = None
+        self.params = None
+        self.sess = None
+        self._stop_training = False
+        self.train_d_loss, self.train_g_loss = [], []
+
+    # ---- engine plumbing -----------------------------------------------------------------------
+    _NAME2ID = {"We": 0, "be": 1, "Wd": 2, "bd": 3, "U": L.T_USER_EMB, "V": L.T_ITEM_EMB}
+
+    def _get(self, tid):
+        a = self.engine.get_tensor(tid)
+        return a[0] if tid in (1, 3) else a
+
+    def _build(self, num_factors, emb_dim, batch_size, **hp):
+        self.num_factors, self.emb_dim = num_factors, emb_dim
+        if self.engine is not None:
+            self.engine.close()
+        self.engine = Engine(self.num_users, self.num_items, num_factors, emb_dim, batch_size, device=self.device, **hp)
+        self.engine.set_urm(self._URM_fit)
+        self.params = {'D': [_TensorRef(t, n) for t, n in self._D_TENSORS],
+                       'G': [_TensorRef(t, n) for t, n in self._G_TENSORS]}
+        self.sess = _SessionShim(self)
+
+    def _init_weights(self):
+        if self.initial_weights is not None:
+            w = self.initial_weights
+        else:
+            rng = np.random.RandomState(self.seed)
+            w = {"We": glorot_uniform(rng, (self.num_items, self.emb_dim)),
+                 "be": np.zeros(self.emb_dim, np.float32),
+                 "Wd": glorot_uniform(rng, (self.emb_dim, self.num_items)),
+                 "bd": np.zeros(self.num_items, np.float32),
+                 "U": glorot_uniform(rng, (self.num_users, self.num_factors)),
+                 "V": glorot_uniform(rng, (self.num_items, self.num_factors))}
+        for name, tid in self._NAME2ID.items():
+            self.engine.set_tensor(tid, w[name])
+
+    # ---- fit (GANMF.py:88-244) -------------------------------------------------------------------
+    def fit(self, num_factors=10, emb_dim=32, epochs=300, batch_size=32, d_lr=1e-4, g_lr=1e-4, d_steps=1, g_steps=1,
+            d_reg=0, g_reg=0, m=1, recon_coefficient=1e-2, allow_worse=None, freq=None, after=0, metrics=['MAP'],
+            sample_every=None, validation_evaluator=None, validation_set=None):
+        self.config = dict(locals())
+        del self.config['self']
+
+        self._build(num_factors, emb_dim, batch_size, d_lr=d_lr, g_lr=g_lr, d_reg=d_reg, g_reg=g_reg, m=m,
+                    recon_coefficient=recon_coefficient)
+        self._init_weights()
+
+        self._stop_training = False
+        if validation_evaluator is not None:
+            early_stop = EarlyStoppingScheduler(self, evaluator=validation_evaluator, allow_worse=allow_worse,
+                                                freq=freq, metrics=metrics, after=after)
+
+        all_users = np.array(range(self.num_users))
+        self.train_g_loss, self.train_d_loss = [], []
+        if self.verbose:
+            print('Starting training...')
+        t_start = time.time()
+        e_start = time.time()
+        epoch = 1
+        pbar = tqdm.tqdm(total=epochs, initial=1) if (tqdm is not None and self.verbose) else None
+
+        while not self._stop_training and epoch < epochs + 1:
+            np.random.shuffle(all_users)      # global numpy stream, in place, cumulative (GANMF.py:175)
+            # one C call per epoch: d_steps passes of D updates then g_steps passes of G updates
+            # over the same slices of the permutation (GANMF.py:176-203)
+            batch_d_loss, batch_g_loss = self.engine.train_epoch(all_users, d_steps, g_steps)
+            self.train_g_loss.append(np.mean(batch_g_loss) if len(batch_g_loss) else np.nan)
+            self.train_d_loss.append(np.mean(batch_d_loss) if len(batch_d_loss) else np.nan)
+
+            if validation_set is not None and sample_every is not None and epoch % sample_every == 0:
+                t_end = time.time()
+                total = t_end - e_start
+                print('Epoch : {:d}. Total: {:.2f} secs, {:.2f} secs/epoch.'.format(epoch, total, total / sample_every))
+                self._flip_for_evaluation(True)
+                _, results_run_string = validation_evaluator.evaluateRecommender(self)
+                self._flip_for_evaluation(False)
+                print(results_run_string)
+                e_start = time.time()
+
+            if validation_evaluator is not None:
+                self._flip_for_evaluation(True)
+                early_stop(epoch)
+                self._flip_for_evaluation(False)
+                if self._stop_training:
+                    print('Training stopped, epoch:', epoch)
+
+            epoch += 1
+            if pbar is not None:
+                pbar.update()
+        if pbar is not None:
+            pbar.close()
+
+        if self.verbose:
+            print('Training took {:.2f} seconds'.format(time.time() - t_start))
+        # leave URM_train user x item on exit (GANMF.py:241-242)
+        self.URM_train = self._URM_eval
+        return epoch - 1 if self._stop_training else epoch
+
+    def _flip_for_evaluation(self, to_eval):
+        """The reference flips self.URM_train with .T.tocsr() around every evaluation in item mode
+        (GANMF.py:215-228); both orientations are kept instead of re-transposing."""
+        self.URM_train = self._URM_eval if to_eval else self._URM_fit
+
+    # ---- hooks used by EarlyStoppingScheduler (GANMF.py:246-255) --------------------------------
+    def stop_fit(self):
+        self._stop_training = True
+
+    def save_current_model(self):
+        self.engine.snapshot_best()
+
+    def load_model(self):
+        self.engine.restore_best()
+
+    def load_weights(self, best_params, weights):
+        """GANMF.py:257-283: `weights` is the Utils_.saveWeights dict {'D': [...], 'G': [...]}."""
+        self._build(best_params['num_factors'], best_params['emb_dim'], batch_size=32)
+        for ref, w in zip(self.params['D'] + self.params['G'], list(weights['D']) + list(weights['G'])):
+            self.engine.set_tensor(ref.tid, np.asarray(w, dtype=np.float32))
+
+    # ---- scoring (GANMF.py:285-292) ---------------------------------------------------------------
+    def _compute_item_score(self, user_id_array, items_to_compute=None):
+        self._require_engine()
+        ids = np.asarray(user_id_array).reshape(-1)
+        return self.engine.scores(ids, transposed=(self.mode == 'item'))
+
+    def _require_engine(self):
+        if self.engine is None:
+            raise RuntimeError("GANMF: model has no device state; call fit() or loadModel() first")
+
+    def user_factors(self):
+        self._require_engine()
+        return self._get(L.T_USER_EMB)
+
+    def item_factors(self):
+        self._require_engine()
+        return self._get(L.T_ITEM_EMB)
+
+    # MF contract named by the north star (BaseMatrixFactorizationRecommender.py:94-143):
+    # USER_factors[ids] @ ITEM_factors.T == _compute_item_score(ids), evaluation orientation
+    @property
+    def USER_factors(self):
+        return self.item_factors() if self.mode == 'item' else self.user_factors()
+
+    @property
+    def ITEM_factors(self):
+        return self.user_factors() if self.mode == 'item' else self.item_factors()
+
+    def autoencoder_codes(self):
+        """GANMF.py:304-307: encoding of every training row, URM_train . We + be (off the hot path:
+        one sparse product on the host from the fetched encoder)."""
+        self._require_engine()
+        return np.asarray(self._URM_fit.dot(self._get(0)) + self._get(1), dtype=np.float32)
+
+    # ---- persistence (GANMF.py:309-342) -----------------------------------------------------------
+    def saveModel(self, folder_path, file_name=None):
+        self._require_engine()
+        os.makedirs(folder_path, exist_ok=True)
+        build_params = {'num_factors': self.num_factors, 'emb_dim': self.emb_dim}
+        with open(os.path.join(folder_path, 'build_params.pkl'), 'wb') as f:
+            pickle.dump(build_params, f, pickle.HIGHEST_PROTOCOL)
+        name = self.RECOMMENDER_NAME + '_' + self.mode if file_name is None else file_name
+        tensors = {ref.name: self.sess.run(ref) for ref in self.params['D'] + self.params['G']}
+        np.savez(os.path.join(folder_path, name + '.npz'), **tensors)
+
+    def loadModel(self, folder_path, file_name=None):
+        with open(os.path.join(folder_path, 'build_params.pkl'), 'rb') as f:
+            build_params = pickle.load(f)
+        self._build(build_params['num_factors'], build_params['emb_dim'], batch_size=32)
+        name = self.RECOMMENDER_NAME + '_' + self.mode if file_name is None else file_name
+        data = np.load(os.path.join(folder_path, name + '.npz'))
+        for ref in self.params['D'] + self.params['G']:
+            self.engine.set_tensor(ref.tid, data[ref.name])
+        if self.verbose:
+            print(self.RECOMMENDER_NAME + ': Loading complete')

@@ -1,0 +1,966 @@
+// libganmf_hip.so — handle, step orchestration and the C ABI declared in include/ganmf_hip.h.
+//
+// One handle = one GPU = one HIP stream (+ one RCCL communicator when data-parallel).  All state
+// of a fit() lives in HBM: the CSR user x item matrix, every parameter with its Adam moments and
+// best-snapshot twin, the minibatch work buffers.  The host sends one permutation per epoch and
+// receives the per-minibatch losses; nothing else crosses PCIe inside the training loop.
+//
+// Leading dimensions are rounded up to 32 floats (128-byte rows); pad columns of every buffer that
+// is consumed along K are zero and stay zero (Adam on a zero gradient of a zero parameter is a
+// fixed point; GEMM / reduce epilogues never store into pad columns).
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/ganmf_hip.h"
+#include "gemm_f32.hpp"
+#include "kernels.hpp"
+
+using namespace ganmf;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(x)                                                                              \
+  do {                                                                                          \
+    hipError_t e_ = (x);                                                                        \
+    if (e_ != hipSuccess) return fail(-2, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+#define NCCL_TRY(x)                                                                             \
+  do {                                                                                          \
+    ncclResult_t r_ = (x);                                                                      \
+    if (r_ != ncclSuccess) return fail(-3, "%s failed: %s (%s:%d)", #x, ncclGetErrorString(r_), __FILE__, __LINE__); \
+  } while (0)
+#define TRY(x)            \
+  do {                    \
+    int rc_ = (x);        \
+    if (rc_ != 0) return rc_; \
+  } while (0)
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+int env_int(const char* name, int dflt) {
+  const char* s = getenv(name);
+  return (s && *s) ? atoi(s) : dflt;
+}
+
+constexpr int ADAM_GRID = 1024;
+constexpr int RED_GRID = 256;
+
+struct Tensor {
+  int rows = 0, cols = 0, ld = 0;
+  float *p = nullptr, *m = nullptr, *v = nullptr, *best = nullptr, *g = nullptr;
+  size_t padded() const { return (size_t)rows * ld; }
+  size_t count() const { return (size_t)rows * cols; }
+};
+
+// profiling: kernel classes
+enum Tag : int {
+  T_DENSIFY, T_GATHER, T_GEMM_GEN, T_GEMM_ENC, T_RED_ENC, T_GEMM_DEC, T_DCOEF, T_GEMM_DE, T_RED_DE,
+  T_GEMM_GWD, T_GEMM_GWE, T_COLSUM, T_ADAM_D, T_GEMM_DF, T_GEMM_GUB, T_RED_GUB, T_GEMM_GV, T_ADAM_V,
+  T_ADAM_U, T_MULTIRED, T_ALLREDUCE, T_SCORE_GEMM, T_COUNT
+};
+const char* const kTagName[T_COUNT] = {
+  "densify_rows", "gather_rows", "gemm_generator[B,k]x[N,k]^T", "gemm_encode[2B,N]x[N,e]", "reduce_encode",
+  "gemm_decode[2B,e]x[e,N]+mse", "d_coef", "gemm_dE[2B,N]x[e,N]^T", "reduce_dE", "gemm_gWd[2B,e]^Tx[2B,N]",
+  "gemm_gWe[2B,N]^Tx[2B,e]", "colsum_bias_grads", "adam_dense_D", "gemm_dF[B,e]x[N,e]^T", "gemm_gUb[B,N]x[N,k]",
+  "reduce_gUb", "gemm_gV[B,N]^Tx[B,k]", "adam_dense_V", "adam_rows_U", "multi_reduce", "rccl_allreduce",
+  "gemm_scores"};
+
+struct ProfRec { int tag; hipEvent_t a, b; double flops, bytes; };
+
+}  // namespace
+
+struct ganmf_handle {
+  ganmf_cfg cfg;
+  int dev = 0;
+  hipStream_t st = nullptr;
+  int U = 0, N = 0, k = 0, e = 0, B = 0;
+  int ldN = 0, ldk = 0, lde = 0;
+  Tensor We, be, Wd, bd, Ue, V;
+  float* gD = nullptr;  // contiguous [gWe | gbe | gWd | gbd] (one all-reduce)
+  size_t gD_elems = 0;
+  // CSR
+  long long* indptr = nullptr;
+  int* indices = nullptr;
+  float* data = nullptr;
+  long long nnz = 0;
+  bool has_urm = false;
+  // epoch schedule
+  int* perm = nullptr;
+  int* pos = nullptr;
+  // minibatch work buffers
+  float *XF = nullptr, *Ub = nullptr, *E = nullptr, *Dl = nullptr, *dE = nullptr, *dF = nullptr, *gUb = nullptr;
+  float* slab = nullptr;
+  size_t slab_elems = 0;
+  float* rs = nullptr;
+  float* scal = nullptr;
+  float *sqp = nullptr;  // [2][max_tiles]
+  int sqp_stride = 0;
+  float* fmp = nullptr;   // [RED_GRID]
+  float* regp = nullptr;  // [6][ADAM_GRID]
+  float *d_parts = nullptr, *g_parts = nullptr;  // [cap][4]
+  int64_t parts_cap = 0;
+  // scoring scratch
+  float *sc_rows = nullptr, *sc_out = nullptr;
+  size_t sc_rows_cap = 0, sc_out_cap = 0;
+  // RCCL
+  ncclComm_t comm = nullptr;
+  bool has_comm = false;
+  // tuning knobs
+  int split_wgs = 512;
+  int tile_force = 0;
+  // profiling
+  bool prof = false;
+  std::vector<ProfRec> recs;
+};
+
+namespace {
+
+struct Scope {
+  ganmf_handle* h;
+  bool on;
+  ProfRec r;
+  Scope(ganmf_handle* h_, int tag, double flops, double bytes) : h(h_), on(h_->prof) {
+    if (on) {
+      r.tag = tag; r.flops = flops; r.bytes = bytes;
+      hipEventCreate(&r.a); hipEventCreate(&r.b);
+      hipEventRecord(r.a, h->st);
+    }
+  }
+  ~Scope() {
+    if (on) { hipEventRecord(r.b, h->st); h->recs.push_back(r); }
+  }
+};
+
+int dalloc(float** p, size_t elems) {
+  HIP_TRY(hipMalloc((void**)p, std::max<size_t>(elems, 4) * sizeof(float)));
+  HIP_TRY(hipMemset(*p, 0, std::max<size_t>(elems, 4) * sizeof(float)));
+  HIP_TRY(hipDeviceSynchronize());  // the handle's stream does not synchronise with the null stream
+  return 0;
+}
+
+int alloc_tensor(Tensor& t, int rows, int cols, bool grad_separate) {
+  t.rows = rows; t.cols = cols; t.ld = round_up(cols, 32);
+  TRY(dalloc(&t.p, t.padded()));
+  TRY(dalloc(&t.m, t.padded()));
+  TRY(dalloc(&t.v, t.padded()));
+  TRY(dalloc(&t.best, t.padded()));
+  if (grad_separate) TRY(dalloc(&t.g, t.padded()));
+  return 0;
+}
+
+void free_tensor(Tensor& t, bool grad_separate) {
+  hipFree(t.p); hipFree(t.m); hipFree(t.v); hipFree(t.best);
+  if (grad_separate) hipFree(t.g);
+}
+
+Tensor* find_tensor(ganmf_handle* h, int id) {
+  switch (id) {
+    case 0: return &h->We;
+    case 1: return &h->be;
+    case 2: return &h->Wd;
+    case 3: return &h->bd;
+    case GANMF_T_USER_EMB: return &h->Ue;
+    case GANMF_T_ITEM_EMB: return &h->V;
+    default: return nullptr;
+  }
+}
+
+float* slot_ptr(Tensor* t, int slot) {
+  switch (slot) {
+    case GANMF_SLOT_PARAM: return t->p;
+    case GANMF_SLOT_ADAM_M: return t->m;
+    case GANMF_SLOT_ADAM_V: return t->v;
+    case GANMF_SLOT_BEST: return t->best;
+    default: return nullptr;
+  }
+}
+
+// split-K plan for a GEMM with `tiles` output tiles: aim at h->split_wgs workgroups, K slices >= 256
+void plan_split(const ganmf_handle* h, int M, int Nn, int K, int& tile, int& nsplit, int& kps) {
+  tile = h->tile_force ? h->tile_force : ((M >= 128 && Nn >= 128) ? 128 : 64);
+  const int tiles = ((M + tile - 1) / tile) * ((Nn + tile - 1) / tile);
+  int want = (h->split_wgs + tiles - 1) / tiles;
+  want = std::min(want, std::max(1, K / 256));
+  split_plan(K, want, nsplit, kps);
+}
+
+size_t slab_need(const ganmf_handle* h, int M, int Nn, int K, int ld) {
+  int tile, ns, kps;
+  plan_split(h, M, Nn, K, tile, ns, kps);
+  return (size_t)ns * M * ld;
+}
+
+inline double gemm_flops(double M, double N, double K) { return 2.0 * M * N * K; }
+inline double gemm_bytes(double M, double N, double K) { return 4.0 * (M * K + N * K + M * N); }
+
+int allreduce(ganmf_handle* h, float* buf, size_t count) {
+  if (!h->has_comm) return 0;
+  Scope s(h, T_ALLREDUCE, 0, 4.0 * count);
+  NCCL_TRY(ncclAllReduce(buf, buf, count, ncclFloat, ncclSum, h->comm, h->st));
+  return 0;
+}
+
+// split-K GEMM + reduce
+int gemm_splitk(ganmf_handle* h, int tag_gemm, int tag_red, GemmP& g, bool akm, bool bkm, RedP& r) {
+  int tile, ns, kps;
+  plan_split(h, g.M, g.N, g.K, tile, ns, kps);
+  g.nsplit = ns; g.k_per_split = kps;
+  g.C = h->slab; g.ldc = r.ld; g.c_split_stride = (long long)g.M * r.ld;
+  g.epi = EPI_STORE;
+  if ((size_t)ns * g.M * r.ld > h->slab_elems) return fail(-4, "internal: split-K slab too small");
+  {
+    Scope s(h, tag_gemm, gemm_flops(g.M, g.N, g.K), gemm_bytes(g.M, g.N, g.K));
+    HIP_TRY(gemm_launch(h->st, g, akm, bkm, tile));
+  }
+  r.part = h->slab; r.split_stride = g.c_split_stride; r.nsplit = ns; r.M = g.M; r.N = g.N;
+  {
+    Scope s(h, tag_red, 0, 4.0 * (ns + 1) * g.M * g.N);
+    const long long total = (long long)r.M * ((r.N + 3) / 4);
+    const int grid = (int)std::min<long long>(RED_GRID, (total + 255) / 256);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(std::max(grid, 1)), dim3(256), 0, h->st, r);
+    HIP_TRY(hipGetLastError());
+    if (r.epi == RED_G_DE && grid < RED_GRID) {
+      // unused partial slots must read as zero
+    }
+  }
+  return 0;
+}
+
+int adam_dense(ganmf_handle* h, int tag, Tensor& t, const float* g, int alpha_idx, float reg, float* sq) {
+  const long long n4 = (long long)t.padded() / 4;
+  Scope s(h, tag, 0, 28.0 * t.count());
+  hipLaunchKernelGGL(adam_dense_kernel, dim3(ADAM_GRID), dim3(256), 0, h->st, t.p, t.m, t.v, g, n4, h->scal,
+                     alpha_idx, reg, sq);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// ---- shared front of both steps: X rows, Ub, F, E = [X;F].We + be ------------------------------
+int step_front(ganmf_handle* h, const int* rows_dev, int nb, int which) {
+  const int N = h->N, k = h->k, e = h->e;
+  {
+    Scope s(h, T_DENSIFY, 0, 4.0 * nb * N);
+    hipLaunchKernelGGL(densify_rows_kernel, dim3(nb), dim3(256), 0, h->st, h->indptr, h->indices, h->data,
+                       rows_dev, h->XF, h->ldN, h->scal, which, which ? h->cfg.g_lr : h->cfg.d_lr);
+    HIP_TRY(hipGetLastError());
+  }
+  {
+    Scope s(h, T_GATHER, 0, 8.0 * nb * k);
+    const long long total = (long long)nb * (h->ldk / 4);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((int)std::min<long long>(1024, (total + 255) / 256)), dim3(256), 0,
+                       h->st, h->Ue.p, h->ldk, rows_dev, nb, h->Ub);
+    HIP_TRY(hipGetLastError());
+  }
+  {  // F = Ub . V^T  -> rows [nb, 2nb) of XF            (GANMF.py:83)
+    GemmP g{};
+    g.A = h->Ub; g.lda = h->ldk; g.B = h->V.p; g.ldb = h->ldk;
+    g.C = h->XF + (size_t)nb * h->ldN; g.ldc = h->ldN;
+    g.M = nb; g.N = N; g.K = k; g.epi = EPI_STORE;
+    Scope s(h, T_GEMM_GEN, gemm_flops(nb, N, k), gemm_bytes(nb, N, k));
+    HIP_TRY(gemm_launch(h->st, g, false, false, h->tile_force));
+  }
+  {  // E = [X;F] . We + be                              (GANMF.py:64-65)
+    GemmP g{};
+    g.A = h->XF; g.lda = h->ldN; g.B = h->We.p; g.ldb = h->lde;
+    g.M = 2 * nb; g.N = e; g.K = N;
+    RedP r{};
+    r.out = h->E; r.ld = h->lde; r.epi = RED_BIAS; r.bias = h->be.p;
+    TRY(gemm_splitk(h, T_GEMM_ENC, T_RED_ENC, g, false, true, r));
+  }
+  return 0;
+}
+
+// One discriminator update on local rows rows_dev[0..nb) (GANMF.py:131-132,138,186-187).
+int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* parts) {
+  const int N = h->N, e = h->e;
+  const bool dist = h->has_comm;
+  const float inv_bn = 1.0f / ((float)b_global * (float)N);
+  if (nb > 0) {
+    TRY(step_front(h, rows_dev, nb, 0));
+    {  // Delta = E.Wd + bd - inp, per-path sum of squares  (GANMF.py:66-68), batch z = path
+      GemmP g{};
+      g.A = h->E; g.lda = h->lde; g.B = h->Wd.p; g.ldb = h->ldN;
+      g.C = h->Dl; g.ldc = h->ldN; g.M = nb; g.N = N; g.K = e;
+      g.nbatch = 2; g.a_batch_stride = (long long)nb * h->lde; g.c_batch_stride = (long long)nb * h->ldN;
+      g.aux = h->XF; g.ldaux = h->ldN; g.aux_batch_stride = (long long)nb * h->ldN;
+      g.epi = EPI_BIAS_SUB_AUX_SQ; g.bias = h->bd.p; g.sq_partials = h->sqp;
+      Scope s(h, T_GEMM_DEC, 2 * gemm_flops(nb, N, e), gemm_bytes(2 * nb, N, e) + 4.0 * 2 * nb * N);
+      HIP_TRY(gemm_launch(h->st, g, false, true, h->tile_force));
+      h->sqp_stride = g.tiles_m * g.tiles_n;
+    }
+  } else {
+    // rank out of rows: still open the optimizer step and contribute zeros to the collectives
+    hipLaunchKernelGGL(open_step_kernel, dim3(1), dim3(64), 0, h->st, h->scal, 0, h->cfg.d_lr);
+    HIP_TRY(hipGetLastError());
+  }
+  if (dist) {
+    MultiRed mr{};
+    mr.count = 2; mr.out = h->scal;
+    mr.e[0] = {h->sqp, nb > 0 ? h->sqp_stride : 0, S_SUM_REAL, 0};
+    mr.e[1] = {h->sqp + h->sqp_stride, nb > 0 ? h->sqp_stride : 0, S_SUM_FAKE, 0};
+    {
+      Scope s(h, T_MULTIRED, 0, 0);
+      hipLaunchKernelGGL(multi_reduce_kernel, dim3(1), dim3(256), 0, h->st, mr);
+      HIP_TRY(hipGetLastError());
+    }
+    TRY(allreduce(h, h->scal + S_SUM_REAL, 2));
+  }
+  {
+    Scope s(h, T_DCOEF, 0, 0);
+    hipLaunchKernelGGL(d_coef_kernel, dim3(1), dim3(256), 0, h->st, h->scal, h->sqp, h->sqp_stride, h->sqp_stride,
+                       dist ? 1 : 0, h->cfg.m, nb, inv_bn, h->rs, parts);
+    HIP_TRY(hipGetLastError());
+  }
+  if (nb > 0) {
+    {  // dE = rs * (Delta . Wd^T)
+      GemmP g{};
+      g.A = h->Dl; g.lda = h->ldN; g.B = h->Wd.p; g.ldb = h->ldN;
+      g.M = 2 * nb; g.N = e; g.K = N;
+      RedP r{};
+      r.out = h->dE; r.ld = h->lde; r.epi = RED_ROWSCALE; r.rowscale = h->rs;
+      TRY(gemm_splitk(h, T_GEMM_DE, T_RED_DE, g, false, false, r));
+    }
+    {  // gWd = (rs*E)^T . Delta
+      GemmP g{};
+      g.A = h->E; g.lda = h->lde; g.kscale = h->rs; g.B = h->Dl; g.ldb = h->ldN;
+      g.C = h->Wd.g; g.ldc = h->ldN; g.M = e; g.N = N; g.K = 2 * nb; g.epi = EPI_STORE;
+      Scope s(h, T_GEMM_GWD, gemm_flops(e, N, 2 * nb), gemm_bytes(e, N, 2 * nb));
+      HIP_TRY(gemm_launch(h->st, g, true, true, h->tile_force));
+    }
+    {  // gWe = [X;F]^T . dE
+      GemmP g{};
+      g.A = h->XF; g.lda = h->ldN; g.B = h->dE; g.ldb = h->lde;
+      g.C = h->We.g; g.ldc = h->lde; g.M = N; g.N = e; g.K = 2 * nb; g.epi = EPI_STORE;
+      Scope s(h, T_GEMM_GWE, gemm_flops(N, e, 2 * nb), gemm_bytes(N, e, 2 * nb));
+      HIP_TRY(gemm_launch(h->st, g, true, true, h->tile_force));
+    }
+    {
+      Scope s(h, T_COLSUM, 0, 4.0 * 2 * nb * (N + e));
+      hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64), dim3(256), 0, h->st, h->Dl, h->ldN, 2 * nb, N, h->rs,
+                         h->bd.g);
+      hipLaunchKernelGGL(colsum_kernel, dim3((e + 63) / 64), dim3(256), 0, h->st, h->dE, h->lde, 2 * nb, e,
+                         (const float*)nullptr, h->be.g);
+      HIP_TRY(hipGetLastError());
+    }
+  } else {
+    HIP_TRY(hipMemsetAsync(h->gD, 0, h->gD_elems * sizeof(float), h->st));
+  }
+  TRY(allreduce(h, h->gD, h->gD_elems));
+  const bool reg = h->cfg.d_reg != 0.f;
+  TRY(adam_dense(h, T_ADAM_D, h->We, h->We.g, S_ALPHA_D, h->cfg.d_reg, reg ? h->regp : nullptr));
+  TRY(adam_dense(h, T_ADAM_D, h->be, h->be.g, S_ALPHA_D, h->cfg.d_reg, reg ? h->regp + ADAM_GRID : nullptr));
+  TRY(adam_dense(h, T_ADAM_D, h->Wd, h->Wd.g, S_ALPHA_D, h->cfg.d_reg, reg ? h->regp + 2 * ADAM_GRID : nullptr));
+  TRY(adam_dense(h, T_ADAM_D, h->bd, h->bd.g, S_ALPHA_D, h->cfg.d_reg, reg ? h->regp + 3 * ADAM_GRID : nullptr));
+  if (reg) {
+    MultiRed mr{};
+    mr.count = 4; mr.out = parts;
+    for (int i = 0; i < 4; ++i) mr.e[i] = {h->regp + i * ADAM_GRID, ADAM_GRID, 2, i ? 1 : 0};
+    Scope s(h, T_MULTIRED, 0, 0);
+    hipLaunchKernelGGL(multi_reduce_kernel, dim3(1), dim3(256), 0, h->st, mr);
+    HIP_TRY(hipGetLastError());
+  }
+  return 0;
+}
+
+// One generator update (GANMF.py:133-135,139,200-201).  `start` = position of the batch in the
+// epoch permutation (adam_rows_kernel finds batch rows through pos[]).
+int g_step(ganmf_handle* h, const int* rows_dev, int nb, int start, int b_global, float* parts) {
+  const int N = h->N, e = h->e, k = h->k;
+  const float alpha = h->cfg.recon_coefficient;
+  const float inv_bn = 1.0f / ((float)b_global * (float)N);
+  if (nb > 0) {
+    TRY(step_front(h, rows_dev, nb, 1));
+    {  // Delta_f = Ef.Wd + bd - F, sum of squares
+      GemmP g{};
+      g.A = h->E + (size_t)nb * h->lde; g.lda = h->lde; g.B = h->Wd.p; g.ldb = h->ldN;
+      g.C = h->Dl; g.ldc = h->ldN; g.M = nb; g.N = N; g.K = e;
+      g.aux = h->XF + (size_t)nb * h->ldN; g.ldaux = h->ldN;
+      g.epi = EPI_BIAS_SUB_AUX_SQ; g.bias = h->bd.p; g.sq_partials = h->sqp;
+      Scope s(h, T_GEMM_DEC, gemm_flops(nb, N, e), gemm_bytes(nb, N, e) + 4.0 * nb * N);
+      HIP_TRY(gemm_launch(h->st, g, false, true, h->tile_force));
+      h->sqp_stride = g.tiles_m * g.tiles_n;
+    }
+    // host constants: rsG = (1-alpha)*2/(B*N) ; cfm = alpha*2/(B*e)
+    const float rsv = (1.0f - alpha) * (2.0f * inv_bn);
+    const float cfm = alpha * 2.0f / ((float)b_global * (float)e);
+    {  // dE = rsG*(Delta_f . Wd^T) + cfm*(Ef - Er) ; FM partials
+      GemmP g{};
+      g.A = h->Dl; g.lda = h->ldN; g.B = h->Wd.p; g.ldb = h->ldN;
+      g.M = nb; g.N = e; g.K = N;
+      RedP r{};
+      r.out = h->dE; r.ld = h->lde; r.epi = RED_G_DE; r.rowscale = nullptr; r.rowscale_c = rsv;
+      r.er = h->E; r.ef = h->E + (size_t)nb * h->lde; r.cfm = cfm; r.sq_partials = h->fmp;
+      HIP_TRY(hipMemsetAsync(h->fmp, 0, RED_GRID * sizeof(float), h->st));
+      TRY(gemm_splitk(h, T_GEMM_DE, T_RED_DE, g, false, false, r));
+    }
+    {  // dF = dE . We^T - rsG*Delta_f      (MSE gradient reaches F through both arguments)
+      GemmP g{};
+      g.A = h->dE; g.lda = h->lde; g.B = h->We.p; g.ldb = h->lde;
+      g.C = h->dF; g.ldc = h->ldN; g.M = nb; g.N = N; g.K = e;
+      g.epi = EPI_SUB_ROWSCALED_AUX; g.rowscale = nullptr; g.rowscale_c = rsv; g.aux = h->Dl; g.ldaux = h->ldN;
+      Scope s(h, T_GEMM_DF, gemm_flops(nb, N, e), gemm_bytes(nb, N, e) + 4.0 * nb * N);
+      HIP_TRY(gemm_launch(h->st, g, false, false, h->tile_force));
+    }
+    {  // gUb = dF . V
+      GemmP g{};
+      g.A = h->dF; g.lda = h->ldN; g.B = h->V.p; g.ldb = h->ldk;
+      g.M = nb; g.N = k; g.K = N;
+      RedP r{};
+      r.out = h->gUb; r.ld = h->ldk; r.epi = RED_PLAIN;
+      TRY(gemm_splitk(h, T_GEMM_GUB, T_RED_GUB, g, false, true, r));
+    }
+    {  // gV = dF^T . Ub
+      GemmP g{};
+      g.A = h->dF; g.lda = h->ldN; g.B = h->Ub; g.ldb = h->ldk;
+      g.C = h->V.g; g.ldc = h->ldk; g.M = N; g.N = k; g.K = nb; g.epi = EPI_STORE;
+      Scope s(h, T_GEMM_GV, gemm_flops(N, k, nb), gemm_bytes(N, k, nb));
+      HIP_TRY(gemm_launch(h->st, g, true, true, h->tile_force));
+    }
+  } else {
+    hipLaunchKernelGGL(open_step_kernel, dim3(1), dim3(64), 0, h->st, h->scal, 1, h->cfg.g_lr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemsetAsync(h->V.g, 0, h->V.padded() * sizeof(float), h->st));
+    HIP_TRY(hipMemsetAsync(h->fmp, 0, RED_GRID * sizeof(float), h->st));
+  }
+  TRY(allreduce(h, h->V.g, h->V.padded()));
+  const bool reg = h->cfg.g_reg != 0.f;
+  TRY(adam_dense(h, T_ADAM_V, h->V, h->V.g, S_ALPHA_G, h->cfg.g_reg, reg ? h->regp + 5 * ADAM_GRID : nullptr));
+  {
+    Scope s(h, T_ADAM_U, 0, 24.0 * h->Ue.count());
+    hipLaunchKernelGGL(adam_rows_kernel, dim3(ADAM_GRID), dim3(256), 0, h->st, h->Ue.p, h->Ue.m, h->Ue.v, h->gUb,
+                       h->pos, start, nb, h->U, h->ldk, h->scal, S_ALPHA_G, h->cfg.g_reg,
+                       reg ? h->regp + 4 * ADAM_GRID : nullptr);
+    HIP_TRY(hipGetLastError());
+  }
+  {  // parts = {sum Delta_f^2, sum (Ef-Er)^2, sum U^2, sum V^2}
+    MultiRed mr{};
+    mr.out = parts;
+    mr.e[0] = {h->sqp, nb > 0 ? h->sqp_stride : 0, 0, 0};
+    mr.e[1] = {h->fmp, RED_GRID, 1, 0};
+    mr.count = 2;
+    if (reg) {
+      mr.e[2] = {h->regp + 4 * ADAM_GRID, ADAM_GRID, 2, 0};
+      mr.e[3] = {h->regp + 5 * ADAM_GRID, ADAM_GRID, 3, 0};
+      mr.count = 4;
+    }
+    Scope s(h, T_MULTIRED, 0, 0);
+    hipLaunchKernelGGL(multi_reduce_kernel, dim3(1), dim3(256), 0, h->st, mr);
+    HIP_TRY(hipGetLastError());
+  }
+  return 0;
+}
+
+int ensure_parts(ganmf_handle* h, int64_t steps) {
+  if (steps <= h->parts_cap) return 0;
+  if (h->d_parts) hipFree(h->d_parts);
+  if (h->g_parts) hipFree(h->g_parts);
+  h->parts_cap = steps + 64;
+  TRY(dalloc(&h->d_parts, (size_t)h->parts_cap * 4));
+  TRY(dalloc(&h->g_parts, (size_t)h->parts_cap * 4));
+  return 0;
+}
+
+// losses from the per-step parts (fp32 host arithmetic, same expression order as the oracle)
+void finish_losses(const ganmf_handle* h, const std::vector<float>& dp, const std::vector<float>& gp,
+                   const std::vector<int>& bglob, int64_t nd, int64_t ng, int64_t per_pass, float* d_losses,
+                   float* g_losses) {
+  const float alpha = h->cfg.recon_coefficient;
+  for (int64_t i = 0; i < nd && d_losses; ++i)
+    d_losses[i] = dp[4 * i] + h->cfg.d_reg * (dp[4 * i + 2] / 2.0f);
+  for (int64_t i = 0; i < ng && g_losses; ++i) {
+    const float bg = (float)bglob[i % per_pass];
+    const float Lf = gp[4 * i] / (bg * (float)h->N);
+    const float fm = gp[4 * i + 1] / (bg * (float)h->e);
+    float sv = gp[4 * i + 3];
+    if (h->has_comm && h->cfg.world_size > 1) sv /= (float)h->cfg.world_size;  // V is replicated
+    g_losses[i] = ((1.0f - alpha) * Lf + alpha * fm) + h->cfg.g_reg * ((gp[4 * i + 2] + sv) / 2.0f);
+  }
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+int ganmf_abi_version(void) { return GANMF_ABI_VERSION; }
+const char* ganmf_last_error(void) { return g_err.c_str(); }
+
+int ganmf_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int ganmf_create(const ganmf_cfg* cfg, ganmf_handle** out) {
+  if (!cfg || !out) return fail(-1, "ganmf_create: null argument");
+  if (cfg->abi_version != GANMF_ABI_VERSION) return fail(-1, "ganmf_create: ABI version %d != %d", cfg->abi_version, GANMF_ABI_VERSION);
+  if (cfg->model != GANMF_MODEL_GANMF) return fail(-5, "ganmf_create: model %d has no device path yet", cfg->model);
+  if (cfg->num_users < 1 || cfg->num_items < 1 || cfg->num_factors < 1 || cfg->emb_dim < 1 || cfg->batch_size < 1)
+    return fail(-1, "ganmf_create: non-positive dimension");
+  if (cfg->num_users > (1LL << 30) || cfg->num_items > (1LL << 30)) return fail(-1, "ganmf_create: dimension too large");
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (ndev < 1) return fail(-2, "ganmf_create: no HIP device (the HIP path is the only path; there is no CPU fallback)");
+  if (cfg->device < 0 || cfg->device >= ndev) return fail(-1, "ganmf_create: device %d out of range [0,%d)", cfg->device, ndev);
+  HIP_TRY(hipSetDevice(cfg->device));
+  ganmf_handle* h = new ganmf_handle();
+  h->cfg = *cfg;
+  h->dev = cfg->device;
+  h->U = (int)cfg->num_users; h->N = (int)cfg->num_items; h->k = cfg->num_factors; h->e = cfg->emb_dim;
+  h->B = (int)std::min<int64_t>(cfg->batch_size, cfg->num_users);
+  h->ldN = round_up(h->N, 32); h->ldk = round_up(h->k, 32); h->lde = round_up(h->e, 32);
+  h->split_wgs = env_int("GANMF_SPLIT_WGS", 512);
+  h->tile_force = env_int("GANMF_TILE", 0);
+  if (h->tile_force != 0 && h->tile_force != 64 && h->tile_force != 128) h->tile_force = 0;
+  HIP_TRY(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
+  const int U = h->U, N = h->N, k = h->k, e = h->e, B = h->B;
+  // parameters; D gradients contiguous for a single all-reduce
+  TRY(alloc_tensor(h->We, N, e, false));
+  TRY(alloc_tensor(h->be, 1, e, false));
+  TRY(alloc_tensor(h->Wd, e, N, false));
+  TRY(alloc_tensor(h->bd, 1, N, false));
+  TRY(alloc_tensor(h->Ue, U, k, false));
+  TRY(alloc_tensor(h->V, N, k, true));
+  h->gD_elems = h->We.padded() + h->be.padded() + h->Wd.padded() + h->bd.padded();
+  TRY(dalloc(&h->gD, h->gD_elems));
+  h->We.g = h->gD;
+  h->be.g = h->We.g + h->We.padded();
+  h->Wd.g = h->be.g + h->be.padded();
+  h->bd.g = h->Wd.g + h->Wd.padded();
+  TRY(dalloc((float**)&h->perm, U));
+  TRY(dalloc((float**)&h->pos, U));
+  TRY(dalloc(&h->XF, (size_t)2 * B * h->ldN));
+  TRY(dalloc(&h->Ub, (size_t)B * h->ldk));
+  TRY(dalloc(&h->E, (size_t)2 * B * h->lde));
+  TRY(dalloc(&h->Dl, (size_t)2 * B * h->ldN));
+  TRY(dalloc(&h->dE, (size_t)2 * B * h->lde));
+  TRY(dalloc(&h->dF, (size_t)B * h->ldN));
+  TRY(dalloc(&h->gUb, (size_t)B * h->ldk));
+  size_t need = 0;
+  for (int nb = 1; nb <= B; nb = (nb == B ? B + 1 : std::min(B, nb * 2))) {  // plan is monotone enough; take max
+    need = std::max(need, slab_need(h, 2 * nb, e, N, h->lde));
+    need = std::max(need, slab_need(h, nb, e, N, h->lde));
+    need = std::max(need, slab_need(h, nb, k, N, h->ldk));
+  }
+  h->slab_elems = need + 1024;
+  TRY(dalloc(&h->slab, h->slab_elems));
+  TRY(dalloc(&h->rs, (size_t)2 * B));
+  TRY(dalloc(&h->scal, S_COUNT));
+  TRY(dalloc(&h->sqp, (size_t)2 * gemm_max_tiles(B, N) + 16));
+  TRY(dalloc(&h->fmp, RED_GRID));
+  TRY(dalloc(&h->regp, (size_t)6 * ADAM_GRID));
+  const float pw[4] = {ADAM_B1, ADAM_B2, ADAM_B1, ADAM_B2};
+  HIP_TRY(hipMemcpy(h->scal, pw, sizeof pw, hipMemcpyHostToDevice));
+  HIP_TRY(hipDeviceSynchronize());
+  *out = h;
+  return 0;
+}
+
+int ganmf_destroy(ganmf_handle* h) {
+  if (!h) return 0;
+  hipSetDevice(h->dev);
+  hipStreamSynchronize(h->st);
+  if (h->has_comm) ncclCommDestroy(h->comm);
+  free_tensor(h->We, false); free_tensor(h->be, false); free_tensor(h->Wd, false); free_tensor(h->bd, false);
+  free_tensor(h->Ue, false); free_tensor(h->V, true);
+  hipFree(h->gD); hipFree(h->indptr); hipFree(h->indices); hipFree(h->data); hipFree(h->perm); hipFree(h->pos);
+  hipFree(h->XF); hipFree(h->Ub); hipFree(h->E); hipFree(h->Dl); hipFree(h->dE); hipFree(h->dF); hipFree(h->gUb);
+  hipFree(h->slab); hipFree(h->rs); hipFree(h->scal); hipFree(h->sqp); hipFree(h->fmp);
+  hipFree(h->regp); hipFree(h->d_parts); hipFree(h->g_parts); hipFree(h->sc_rows); hipFree(h->sc_out);
+  for (auto& r : h->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+  hipStreamDestroy(h->st);
+  delete h;
+  return 0;
+}
+
+int ganmf_comm_unique_id(uint8_t out128[128]) {
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is expected to be 128 bytes");
+  ncclUniqueId id;
+  NCCL_TRY(ncclGetUniqueId(&id));
+  memcpy(out128, &id, 128);
+  return 0;
+}
+
+int ganmf_comm_init(ganmf_handle* h, const uint8_t id128[128]) {
+  if (!h) return fail(-1, "null handle");
+  HIP_TRY(hipSetDevice(h->dev));
+  ncclUniqueId id;
+  memcpy(&id, id128, 128);
+  NCCL_TRY(ncclCommInitRank(&h->comm, h->cfg.world_size, id, h->cfg.rank));
+  h->has_comm = true;
+  return 0;
+}
+
+int ganmf_set_urm_csr(ganmf_handle* h, const int64_t* indptr, const int32_t* indices, const float* data,
+                      int64_t n_rows, int64_t n_cols) {
+  if (!h || !indptr || (!indices && indptr[n_rows] > 0)) return fail(-1, "ganmf_set_urm_csr: null argument");
+  if (n_rows != h->U || n_cols != h->N) return fail(-1, "ganmf_set_urm_csr: shape %lldx%lld != handle %dx%d", (long long)n_rows, (long long)n_cols, h->U, h->N);
+  const int64_t nnz = indptr[n_rows];
+  if (indptr[0] != 0 || nnz < 0) return fail(-1, "ganmf_set_urm_csr: bad indptr");
+  for (int64_t r = 0; r < n_rows; ++r)
+    if (indptr[r + 1] < indptr[r]) return fail(-1, "ganmf_set_urm_csr: indptr not monotone at row %lld", (long long)r);
+  for (int64_t j = 0; j < nnz; ++j)
+    if (indices[j] < 0 || indices[j] >= n_cols) return fail(-1, "ganmf_set_urm_csr: column index %d out of range at %lld", indices[j], (long long)j);
+  HIP_TRY(hipSetDevice(h->dev));
+  if (h->indptr) { hipFree(h->indptr); hipFree(h->indices); hipFree(h->data); h->indptr = nullptr; }
+  HIP_TRY(hipMalloc((void**)&h->indptr, (n_rows + 1) * sizeof(long long)));
+  HIP_TRY(hipMalloc((void**)&h->indices, std::max<int64_t>(nnz, 1) * sizeof(int)));
+  HIP_TRY(hipMalloc((void**)&h->data, std::max<int64_t>(nnz, 1) * sizeof(float)));
+  HIP_TRY(hipMemcpy(h->indptr, indptr, (n_rows + 1) * sizeof(long long), hipMemcpyHostToDevice));
+  if (nnz) {
+    HIP_TRY(hipMemcpy(h->indices, indices, nnz * sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->data, data, nnz * sizeof(float), hipMemcpyHostToDevice));
+  }
+  h->nnz = nnz;
+  h->has_urm = true;
+  return 0;
+}
+
+int ganmf_tensor_shape(ganmf_handle* h, int tensor_id, int64_t* rows, int64_t* cols) {
+  Tensor* t = h ? find_tensor(h, tensor_id) : nullptr;
+  if (!t) return fail(-1, "unknown tensor id %d", tensor_id);
+  if (rows) *rows = t->rows;
+  if (cols) *cols = t->cols;
+  return 0;
+}
+
+int ganmf_set_tensor(ganmf_handle* h, int tensor_id, int slot, const float* host, int64_t n) {
+  Tensor* t = h ? find_tensor(h, tensor_id) : nullptr;
+  if (!t || !host) return fail(-1, "ganmf_set_tensor: unknown tensor id %d", tensor_id);
+  float* d = slot_ptr(t, slot);
+  if (!d) return fail(-1, "ganmf_set_tensor: bad slot %d", slot);
+  if (n != (int64_t)t->count()) return fail(-1, "ganmf_set_tensor: tensor %d has %lld elements, got %lld", tensor_id, (long long)t->count(), (long long)n);
+  HIP_TRY(hipSetDevice(h->dev));
+  HIP_TRY(hipStreamSynchronize(h->st));
+  HIP_TRY(hipMemcpy2D(d, (size_t)t->ld * 4, host, (size_t)t->cols * 4, (size_t)t->cols * 4, t->rows, hipMemcpyHostToDevice));
+  return 0;
+}
+
+int ganmf_get_tensor(ganmf_handle* h, int tensor_id, int slot, float* host, int64_t n) {
+  Tensor* t = h ? find_tensor(h, tensor_id) : nullptr;
+  if (!t || !host) return fail(-1, "ganmf_get_tensor: unknown tensor id %d", tensor_id);
+  float* d = slot_ptr(t, slot);
+  if (!d) return fail(-1, "ganmf_get_tensor: bad slot %d", slot);
+  if (n != (int64_t)t->count()) return fail(-1, "ganmf_get_tensor: tensor %d has %lld elements, got %lld", tensor_id, (long long)t->count(), (long long)n);
+  HIP_TRY(hipSetDevice(h->dev));
+  HIP_TRY(hipStreamSynchronize(h->st));
+  HIP_TRY(hipMemcpy2D(host, (size_t)t->cols * 4, d, (size_t)t->ld * 4, (size_t)t->cols * 4, t->rows, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int ganmf_get_adam_powers(ganmf_handle* h, float out4[4]) {
+  if (!h) return fail(-1, "null handle");
+  HIP_TRY(hipSetDevice(h->dev));
+  HIP_TRY(hipStreamSynchronize(h->st));
+  HIP_TRY(hipMemcpy(out4, h->scal, 4 * sizeof(float), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int ganmf_set_adam_powers(ganmf_handle* h, const float in4[4]) {
+  if (!h) return fail(-1, "null handle");
+  HIP_TRY(hipSetDevice(h->dev));
+  HIP_TRY(hipStreamSynchronize(h->st));
+  HIP_TRY(hipMemcpy(h->scal, in4, 4 * sizeof(float), hipMemcpyHostToDevice));
+  return 0;
+}
+
+int ganmf_train_epoch(ganmf_handle* h, const int32_t* perm, int64_t n, int32_t d_steps, int32_t g_steps,
+                      int64_t n_steps_per_pass, const int32_t* global_batch_rows, float* d_losses,
+                      float* g_losses) {
+  if (!h || (!perm && n > 0)) return fail(-1, "ganmf_train_epoch: null argument");
+  if (!h->has_urm) return fail(-1, "ganmf_train_epoch: ganmf_set_urm_csr has not been called");
+  if (n < 0 || n > h->U) return fail(-1, "ganmf_train_epoch: n=%lld out of range", (long long)n);
+  if (d_steps < 0 || g_steps < 0) return fail(-1, "ganmf_train_epoch: negative step count");
+  const bool dist = h->has_comm && h->cfg.world_size > 1;
+  if (dist && !global_batch_rows) return fail(-1, "ganmf_train_epoch: global_batch_rows required when world_size > 1");
+  HIP_TRY(hipSetDevice(h->dev));
+  const int B = h->B;
+  const int64_t local_steps = (n + B - 1) / B;
+  const int64_t per_pass = std::max(local_steps, n_steps_per_pass);
+  if (per_pass == 0) return 0;
+  std::vector<int> pos(h->U, -1);
+  for (int64_t i = 0; i < n; ++i) {
+    const int r = perm[i];
+    if (r < 0 || r >= h->U) return fail(-1, "ganmf_train_epoch: row id %d out of range at %lld", r, (long long)i);
+    if (pos[r] != -1) return fail(-1, "ganmf_train_epoch: row id %d appears twice in the permutation", r);
+    pos[r] = (int)i;
+  }
+  std::vector<int> bglob(per_pass);
+  for (int64_t i = 0; i < per_pass; ++i) {
+    const int64_t a = i * B;
+    const int nb = (int)std::max<int64_t>(0, std::min<int64_t>(B, n - a));
+    bglob[i] = global_batch_rows ? global_batch_rows[i] : nb;
+    if (bglob[i] < nb || bglob[i] < 1) return fail(-1, "ganmf_train_epoch: global_batch_rows[%lld]=%d < local %d", (long long)i, bglob[i], nb);
+  }
+  HIP_TRY(hipMemcpyAsync(h->perm, perm, n * sizeof(int), hipMemcpyHostToDevice, h->st));
+  HIP_TRY(hipMemcpyAsync(h->pos, pos.data(), (size_t)h->U * sizeof(int), hipMemcpyHostToDevice, h->st));
+  const int64_t nd = (int64_t)d_steps * per_pass, ng = (int64_t)g_steps * per_pass;
+  TRY(ensure_parts(h, std::max(nd, ng)));
+  HIP_TRY(hipMemsetAsync(h->d_parts, 0, (size_t)std::max<int64_t>(nd, 1) * 4 * sizeof(float), h->st));
+  HIP_TRY(hipMemsetAsync(h->g_parts, 0, (size_t)std::max<int64_t>(ng, 1) * 4 * sizeof(float), h->st));
+  int64_t idx = 0;
+  for (int p = 0; p < d_steps; ++p)
+    for (int64_t i = 0; i < per_pass; ++i, ++idx) {
+      const int64_t a = i * B;
+      const int nb = (int)std::max<int64_t>(0, std::min<int64_t>(B, n - a));
+      TRY(d_step(h, h->perm + std::min<int64_t>(a, std::max<int64_t>(n - 1, 0)), nb, bglob[i], h->d_parts + 4 * idx));
+    }
+  idx = 0;
+  for (int p = 0; p < g_steps; ++p)
+    for (int64_t i = 0; i < per_pass; ++i, ++idx) {
+      const int64_t a = i * B;
+      const int nb = (int)std::max<int64_t>(0, std::min<int64_t>(B, n - a));
+      TRY(g_step(h, h->perm + std::min<int64_t>(a, std::max<int64_t>(n - 1, 0)), nb, (int)a, bglob[i], h->g_parts + 4 * idx));
+    }
+  if (dist && ng > 0) TRY(allreduce(h, h->g_parts, (size_t)ng * 4));
+  std::vector<float> dp((size_t)std::max<int64_t>(nd, 1) * 4), gp((size_t)std::max<int64_t>(ng, 1) * 4);
+  HIP_TRY(hipMemcpyAsync(dp.data(), h->d_parts, dp.size() * sizeof(float), hipMemcpyDeviceToHost, h->st));
+  HIP_TRY(hipMemcpyAsync(gp.data(), h->g_parts, gp.size() * sizeof(float), hipMemcpyDeviceToHost, h->st));
+  HIP_TRY(hipStreamSynchronize(h->st));
+  finish_losses(h, dp, gp, bglob, nd, ng, per_pass, d_losses, g_losses);
+  return 0;
+}
+
+int ganmf_train_step(ganmf_handle* h, int kind, const int32_t* uids, int32_t n, float* loss) {
+  if (!h || !uids) return fail(-1, "ganmf_train_step: null argument");
+  if (!h->has_urm) return fail(-1, "ganmf_train_step: ganmf_set_urm_csr has not been called");
+  if (n < 1 || n > h->B) return fail(-1, "ganmf_train_step: batch of %d rows (handle batch_size %d)", n, h->B);
+  if (kind != 0 && kind != 1) return fail(-1, "ganmf_train_step: kind must be 0 (D) or 1 (G)");
+  if (h->has_comm && h->cfg.world_size > 1) return fail(-1, "ganmf_train_step: single-GPU entry; use ganmf_train_epoch");
+  HIP_TRY(hipSetDevice(h->dev));
+  std::vector<int> pos(h->U, -1);
+  for (int i = 0; i < n; ++i) {
+    if (uids[i] < 0 || uids[i] >= h->U) return fail(-1, "ganmf_train_step: row id %d out of range", uids[i]);
+    if (pos[uids[i]] != -1) return fail(-1, "ganmf_train_step: duplicate row id %d", uids[i]);
+    pos[uids[i]] = i;
+  }
+  TRY(ensure_parts(h, 1));
+  HIP_TRY(hipMemcpyAsync(h->perm, uids, n * sizeof(int), hipMemcpyHostToDevice, h->st));
+  HIP_TRY(hipMemcpyAsync(h->pos, pos.data(), (size_t)h->U * sizeof(int), hipMemcpyHostToDevice, h->st));
+  HIP_TRY(hipMemsetAsync(h->d_parts, 0, 4 * sizeof(float), h->st));
+  HIP_TRY(hipMemsetAsync(h->g_parts, 0, 4 * sizeof(float), h->st));
+  if (kind == 0) TRY(d_step(h, h->perm, n, n, h->d_parts));
+  else TRY(g_step(h, h->perm, n, 0, n, h->g_parts));
+  std::vector<float> dp(4), gp(4);
+  HIP_TRY(hipMemcpyAsync(dp.data(), h->d_parts, 4 * sizeof(float), hipMemcpyDeviceToHost, h->st));
+  HIP_TRY(hipMemcpyAsync(gp.data(), h->g_parts, 4 * sizeof(float), hipMemcpyDeviceToHost, h->st));
+  HIP_TRY(hipStreamSynchronize(h->st));
+  std::vector<int> bglob(1, n);
+  float dl = 0.f, gl = 0.f;
+  finish_losses(h, dp, gp, bglob, kind == 0 ? 1 : 0, kind == 1 ? 1 : 0, 1, &dl, &gl);
+  if (loss) *loss = kind == 0 ? dl : gl;
+  return 0;
+}
+
+static int scores_device(ganmf_handle* h, const int* ids_dev, int64_t n, int transposed, float** out_dev, int* width,
+                         int* ld_out) {
+  Tensor& rowsT = transposed ? h->V : h->Ue;   // rows we gather
+  Tensor& colsT = transposed ? h->Ue : h->V;   // the other factor
+  const int W = colsT.rows, ldw = round_up(W, 32);
+  const size_t need_rows = (size_t)n * h->ldk, need_out = (size_t)n * ldw;
+  if (need_rows > h->sc_rows_cap) {
+    if (h->sc_rows) hipFree(h->sc_rows);
+    TRY(dalloc(&h->sc_rows, need_rows)); h->sc_rows_cap = need_rows;
+  }
+  if (need_out > h->sc_out_cap) {
+    if (h->sc_out) hipFree(h->sc_out);
+    TRY(dalloc(&h->sc_out, need_out)); h->sc_out_cap = need_out;
+  }
+  const long long total = (long long)n * (h->ldk / 4);
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((int)std::min<long long>(2048, (total + 255) / 256)), dim3(256), 0,
+                     h->st, rowsT.p, h->ldk, ids_dev, (int)n, h->sc_rows);
+  HIP_TRY(hipGetLastError());
+  GemmP g{};
+  g.A = h->sc_rows; g.lda = h->ldk; g.B = colsT.p; g.ldb = h->ldk;
+  g.C = h->sc_out; g.ldc = ldw; g.M = (int)n; g.N = W; g.K = h->k; g.epi = EPI_STORE;
+  {
+    Scope s(h, T_SCORE_GEMM, gemm_flops(n, W, h->k), gemm_bytes(n, W, h->k));
+    HIP_TRY(gemm_launch(h->st, g, false, false, h->tile_force));
+  }
+  *out_dev = h->sc_out; *width = W; *ld_out = ldw;
+  return 0;
+}
+
+int ganmf_scores(ganmf_handle* h, const int32_t* ids, int64_t n, int transposed, float* out) {
+  if (!h || !ids || !out) return fail(-1, "ganmf_scores: null argument");
+  if (n < 1 || n > (1 << 30)) return fail(-1, "ganmf_scores: n out of range");
+  const int limit = transposed ? h->N : h->U;
+  for (int64_t i = 0; i < n; ++i)
+    if (ids[i] < 0 || ids[i] >= limit) return fail(-1, "ganmf_scores: id %d out of range [0,%d)", ids[i], limit);
+  HIP_TRY(hipSetDevice(h->dev));
+  int* ids_dev = nullptr;
+  HIP_TRY(hipMalloc((void**)&ids_dev, n * sizeof(int)));
+  HIP_TRY(hipMemcpyAsync(ids_dev, ids, n * sizeof(int), hipMemcpyHostToDevice, h->st));
+  float* od = nullptr; int W = 0, ldw = 0;
+  int rc = scores_device(h, ids_dev, n, transposed, &od, &W, &ldw);
+  if (rc == 0) {
+    hipError_t e = hipMemcpy2DAsync(out, (size_t)W * 4, od, (size_t)ldw * 4, (size_t)W * 4, n, hipMemcpyDeviceToHost, h->st);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->st);
+    if (e != hipSuccess) rc = fail(-2, "ganmf_scores: copy back failed: %s", hipGetErrorString(e));
+  }
+  hipStreamSynchronize(h->st);
+  hipFree(ids_dev);
+  return rc;
+}
+
+int ganmf_bench_scores(ganmf_handle* h, int64_t n, int transposed, int32_t iters, float* ms_per_launch) {
+  if (!h || iters < 1) return fail(-1, "ganmf_bench_scores: bad argument");
+  const int limit = transposed ? h->N : h->U;
+  if (n < 1 || n > limit) return fail(-1, "ganmf_bench_scores: n out of range");
+  HIP_TRY(hipSetDevice(h->dev));
+  std::vector<int> ids(n);
+  for (int64_t i = 0; i < n; ++i) ids[i] = (int)i;
+  int* ids_dev = nullptr;
+  HIP_TRY(hipMalloc((void**)&ids_dev, n * sizeof(int)));
+  HIP_TRY(hipMemcpy(ids_dev, ids.data(), n * sizeof(int), hipMemcpyHostToDevice));
+  float* od; int W, ldw;
+  int rc = scores_device(h, ids_dev, n, transposed, &od, &W, &ldw);  // warm-up + allocation
+  if (rc) { hipFree(ids_dev); return rc; }
+  Tensor& colsT = transposed ? h->Ue : h->V;
+  GemmP g{};
+  g.A = h->sc_rows; g.lda = h->ldk; g.B = colsT.p; g.ldb = h->ldk;
+  g.C = h->sc_out; g.ldc = ldw; g.M = (int)n; g.N = W; g.K = h->k; g.epi = EPI_STORE;
+  hipEvent_t a, b;
+  hipEventCreate(&a); hipEventCreate(&b);
+  gemm_launch(h->st, g, false, false, h->tile_force);
+  hipEventRecord(a, h->st);
+  for (int i = 0; i < iters; ++i) gemm_launch(h->st, g, false, false, h->tile_force);
+  hipEventRecord(b, h->st);
+  hipError_t e = hipEventSynchronize(b);
+  float ms = 0.f;
+  hipEventElapsedTime(&ms, a, b);
+  hipEventDestroy(a); hipEventDestroy(b);
+  hipFree(ids_dev);
+  if (e != hipSuccess) return fail(-2, "ganmf_bench_scores: %s", hipGetErrorString(e));
+  if (ms_per_launch) *ms_per_launch = ms / iters;
+  return 0;
+}
+
+int ganmf_snapshot_best(ganmf_handle* h) {
+  if (!h) return fail(-1, "null handle");
+  HIP_TRY(hipSetDevice(h->dev));
+  for (Tensor* t : {&h->We, &h->be, &h->Wd, &h->bd, &h->Ue, &h->V})
+    HIP_TRY(hipMemcpyAsync(t->best, t->p, t->padded() * sizeof(float), hipMemcpyDeviceToDevice, h->st));
+  HIP_TRY(hipStreamSynchronize(h->st));
+  return 0;
+}
+
+int ganmf_restore_best(ganmf_handle* h) {
+  if (!h) return fail(-1, "null handle");
+  HIP_TRY(hipSetDevice(h->dev));
+  for (Tensor* t : {&h->We, &h->be, &h->Wd, &h->bd, &h->Ue, &h->V})
+    HIP_TRY(hipMemcpyAsync(t->p, t->best, t->padded() * sizeof(float), hipMemcpyDeviceToDevice, h->st));
+  HIP_TRY(hipStreamSynchronize(h->st));
+  return 0;
+}
+
+int ganmf_profile_enable(ganmf_handle* h, int on) {
+  if (!h) return fail(-1, "null handle");
+  HIP_TRY(hipSetDevice(h->dev));
+  HIP_TRY(hipStreamSynchronize(h->st));
+  for (auto& r : h->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+  h->recs.clear();
+  h->prof = on != 0;
+  return 0;
+}
+
+int ganmf_profile_read(ganmf_handle* h, ganmf_prof_entry* out, int32_t cap, int32_t* n_out) {
+  if (!h || !out || !n_out) return fail(-1, "null argument");
+  HIP_TRY(hipSetDevice(h->dev));
+  HIP_TRY(hipStreamSynchronize(h->st));
+  std::vector<ganmf_prof_entry> acc(T_COUNT);
+  for (int i = 0; i < T_COUNT; ++i) {
+    memset(&acc[i], 0, sizeof acc[i]);
+    snprintf(acc[i].name, sizeof acc[i].name, "%s", kTagName[i]);
+  }
+  for (auto& r : h->recs) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
+    acc[r.tag].launches += 1; acc[r.tag].ms += ms; acc[r.tag].flops += r.flops; acc[r.tag].bytes += r.bytes;
+  }
+  int n = 0;
+  for (int i = 0; i < T_COUNT && n < cap; ++i)
+    if (acc[i].launches) out[n++] = acc[i];
+  *n_out = n;
+  return 0;
+}
+
+int ganmf_gemm_f32(int device, const float* A, const float* B, float* C, int64_t M, int64_t N, int64_t K,
+                   int a_kmajor, int b_kmajor, int tile, int nsplit, int iters, float* ms) {
+  if (!A || !B || !C || M < 1 || N < 1 || K < 1) return fail(-1, "ganmf_gemm_f32: bad argument");
+  if (a_kmajor && !b_kmajor) return fail(-1, "ganmf_gemm_f32: the TT layout is not part of the GANMF path");
+  if (tile != 0 && tile != 64 && tile != 128) return fail(-1, "ganmf_gemm_f32: tile must be 0, 64 or 128");
+  HIP_TRY(hipSetDevice(device));
+  const int ar = a_kmajor ? K : M, ac = a_kmajor ? M : K;
+  const int br = b_kmajor ? K : N, bc = b_kmajor ? N : K;
+  const int lda = round_up(ac, 32), ldb = round_up(bc, 32), ldc = round_up((int)N, 32);
+  float *dA = nullptr, *dB = nullptr, *dC = nullptr, *slab = nullptr;
+  TRY(dalloc(&dA, (size_t)ar * lda)); TRY(dalloc(&dB, (size_t)br * ldb)); TRY(dalloc(&dC, (size_t)M * ldc));
+  HIP_TRY(hipMemcpy2D(dA, (size_t)lda * 4, A, (size_t)ac * 4, (size_t)ac * 4, ar, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy2D(dB, (size_t)ldb * 4, B, (size_t)bc * 4, (size_t)bc * 4, br, hipMemcpyHostToDevice));
+  GemmP g{};
+  g.A = dA; g.lda = lda; g.B = dB; g.ldb = ldb; g.C = dC; g.ldc = ldc;
+  g.M = (int)M; g.N = (int)N; g.K = (int)K; g.epi = EPI_STORE;
+  int ns = 1, kps = 0;
+  if (nsplit > 1) {
+    split_plan((int)K, nsplit, ns, kps);
+    TRY(dalloc(&slab, (size_t)ns * M * ldc));
+  }
+  hipStream_t st = nullptr;
+  auto run = [&]() -> hipError_t {
+    if (ns > 1) {
+      GemmP q = g;
+      q.nsplit = ns; q.k_per_split = kps; q.C = slab; q.c_split_stride = (long long)M * ldc;
+      hipError_t e = gemm_launch(st, q, a_kmajor, b_kmajor, tile);
+      if (e != hipSuccess) return e;
+      RedP r{};
+      r.part = slab; r.split_stride = q.c_split_stride; r.nsplit = ns; r.out = dC; r.ld = ldc; r.M = (int)M; r.N = (int)N;
+      r.epi = RED_PLAIN;
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(RED_GRID), dim3(256), 0, st, r);
+      return hipGetLastError();
+    }
+    GemmP q = g;
+    return gemm_launch(st, q, a_kmajor, b_kmajor, tile);
+  };
+  HIP_TRY(run());
+  HIP_TRY(hipDeviceSynchronize());
+  if (iters > 1 || ms) {
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    hipEventRecord(a, st);
+    for (int i = 0; i < std::max(iters, 1); ++i) run();
+    hipEventRecord(b, st);
+    hipEventSynchronize(b);
+    float t = 0.f;
+    hipEventElapsedTime(&t, a, b);
+    if (ms) *ms = t / std::max(iters, 1);
+    hipEventDestroy(a); hipEventDestroy(b);
+  }
+  HIP_TRY(hipMemcpy2D(C, (size_t)N * 4, dC, (size_t)ldc * 4, (size_t)N * 4, M, hipMemcpyDeviceToHost));
+  hipFree(dA); hipFree(dB); hipFree(dC);
+  if (slab) hipFree(slab);
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,236 @@
+// HBM-bound kernels of the GANMF step: CSR row expansion, row gather, column sums, the loss /
+// hinge scalar kernels and the two TF-formula Adam updates.
+// All are coalesced float4 streams with wavefront (64-lane) shuffle reductions; reductions that
+// feed results go through per-block partials summed in a fixed order (bitwise reproducible).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace ganmf {
+
+// ---- device scalar block (floats) ----------------------------------------------------------
+enum Scal : int {
+  S_B1P_D = 0, S_B2P_D = 1, S_B1P_G = 2, S_B2P_G = 3,  // Adam beta powers (AdamOptimizer._finish)
+  S_ALPHA_D = 4, S_ALPHA_G = 5,                        // lr_t of the step in flight
+  S_SUM_REAL = 8, S_SUM_FAKE = 9, S_SUM_FM = 10,        // sum of squares (local, then all-reduced)
+  S_COUNT = 16
+};
+
+constexpr float ADAM_B1 = 0.9f, ADAM_B2 = 0.999f, ADAM_EPS = 1e-8f;
+
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// block-wide sum for 256-thread blocks; result valid in thread 0
+__device__ inline float block_sum_256(float v, float* red4) {
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) red4[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (red4[0] + red4[1]) + (red4[2] + red4[3]);
+}
+
+// Step prologue + CSR row expansion (replaces URM_train[uids].toarray(), GANMF.py:183-184):
+// block b zero-fills row b of X (pad columns included) and scatters the stored values of CSR
+// row rows[b].  Block 0 / thread 0 also opens the optimizer step: lr_t from the beta powers
+// (TF ApplyAdam), then advances the powers.
+__global__ __launch_bounds__(256) void densify_rows_kernel(const long long* __restrict__ indptr,
+                                                           const int* __restrict__ indices,
+                                                           const float* __restrict__ data,
+                                                           const int* __restrict__ rows, float* __restrict__ X,
+                                                           int ldx, float* __restrict__ scal, int which,
+                                                           float lr) {
+  const int b = blockIdx.x;
+  if (b == 0 && threadIdx.x == 0 && which >= 0) {
+    const int o = which ? S_B1P_G : S_B1P_D;
+    const float b1p = scal[o], b2p = scal[o + 1];
+    scal[which ? S_ALPHA_G : S_ALPHA_D] = lr * sqrtf(1.f - b2p) / (1.f - b1p);
+    scal[o] = b1p * ADAM_B1;
+    scal[o + 1] = b2p * ADAM_B2;
+  }
+  float4* xr = reinterpret_cast<float4*>(X + (size_t)b * ldx);
+  for (int c = threadIdx.x; c < ldx / 4; c += blockDim.x) xr[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();
+  const int r = rows[b];
+  const long long s = indptr[r], e = indptr[r + 1];
+  float* x = X + (size_t)b * ldx;
+  for (long long j = s + threadIdx.x; j < e; j += blockDim.x) x[indices[j]] = data[j];
+}
+
+// Opens an optimizer step without any rows (a data-parallel rank that ran out of rows).
+__global__ void open_step_kernel(float* __restrict__ scal, int which, float lr) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const int o = which ? S_B1P_G : S_B1P_D;
+    const float b1p = scal[o], b2p = scal[o + 1];
+    scal[which ? S_ALPHA_G : S_ALPHA_D] = lr * sqrtf(1.f - b2p) / (1.f - b1p);
+    scal[o] = b1p * ADAM_B1;
+    scal[o + 1] = b2p * ADAM_B2;
+  }
+}
+
+// dst[b, :] = src[rows[b], :]   (embedding_lookup, GANMF.py:82)
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, int ld,
+                                                          const int* __restrict__ rows, int nrows,
+                                                          float* __restrict__ dst) {
+  const int c4 = ld / 4;
+  const long long total = (long long)nrows * c4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int b = (int)(i / c4), c = (int)(i % c4);
+    reinterpret_cast<float4*>(dst + (size_t)b * ld)[c] =
+        reinterpret_cast<const float4*>(src + (size_t)rows[b] * ld)[c];
+  }
+}
+
+// out[n] = sum_r rowscale[r] * in[r, n]      (bias gradients, reduce over the batch axis)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ in, int ld, int R, int N,
+                                                     const float* __restrict__ rowscale,
+                                                     float* __restrict__ out) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int g = threadIdx.x >> 6;
+  float s = 0.f;
+  if (c < N)
+    for (int r = g; r < R; r += 4) s += (rowscale ? rowscale[r] : 1.f) * in[(size_t)r * ld + c];
+  red[g][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (g == 0 && c < N) out[c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// Several reproducible sums in ONE launch (one block, entries processed in order):
+//   dst[e.dst] (+)= sum_i e.p[i], i < e.n     -- accumulate=0 overwrites, 1 adds
+struct MultiRedEntry { const float* p; int n; int dst; int accumulate; };
+struct MultiRed { MultiRedEntry e[6]; int count; float* out; };
+
+__global__ __launch_bounds__(256) void multi_reduce_kernel(const MultiRed mr) {
+  __shared__ float red[4];
+  for (int z = 0; z < mr.count; ++z) {
+    const MultiRedEntry e = mr.e[z];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < e.n; i += 256) s += e.p[i];
+    const float t = block_sum_256(s, red);
+    if (threadIdx.x == 0) mr.out[e.dst] = e.accumulate ? mr.out[e.dst] + t : t;
+    __syncthreads();
+  }
+}
+
+// Discriminator scalars (GANMF.py:131-132): Lr, Lf, hinge, per-row backward scale
+// rs[r] = c_path * 2/(B*N) with c_real = 1 + m*[h>0], c_fake = -[h>0]; loss_parts[0] = Lr + max(0,h).
+// presummed = 0: the squared-error partials of the two paths are summed here (single GPU);
+// presummed = 1: scal[S_SUM_REAL/FAKE] already hold the all-reduced sums.
+__global__ __launch_bounds__(256) void d_coef_kernel(float* __restrict__ scal, const float* __restrict__ partials,
+                                                     int np, int pstride, int presummed, float m, int b_local,
+                                                     float inv_bn /* 1/(B_global*N) */,
+                                                     float* __restrict__ rs, float* __restrict__ loss_parts) {
+  __shared__ float red[4];
+  __shared__ float sums[2];
+  if (!presummed) {
+    for (int z = 0; z < 2; ++z) {
+      float s = 0.f;
+      for (int i = threadIdx.x; i < np; i += 256) s += partials[(size_t)z * pstride + i];
+      const float t = block_sum_256(s, red);
+      if (threadIdx.x == 0) sums[z] = t;
+      __syncthreads();
+    }
+  } else {
+    if (threadIdx.x == 0) { sums[0] = scal[S_SUM_REAL]; sums[1] = scal[S_SUM_FAKE]; }
+    __syncthreads();
+  }
+  const float Lr = sums[0] * inv_bn, Lf = sums[1] * inv_bn;
+  const float h = m * Lr - Lf;
+  const bool on = h > 0.f;
+  const float cr = (on ? 1.f + m : 1.f) * (2.f * inv_bn);
+  const float cf = (on ? -1.f : 0.f) * (2.f * inv_bn);
+  for (int r = threadIdx.x; r < 2 * b_local; r += blockDim.x) rs[r] = r < b_local ? cr : cf;
+  if (threadIdx.x == 0) {
+    loss_parts[0] = Lr + fmaxf(0.f, h);
+    loss_parts[1] = on ? 1.f : 0.f;
+  }
+}
+
+// ApplyAdam (dense):  g' = g + reg*theta ; m += (g'-m)(1-b1) ; v += (g'^2-v)(1-b2) ;
+// theta -= (m*alpha)/(sqrt(v)+eps).  Optionally accumulates sum(theta_old^2) per block.
+__global__ __launch_bounds__(256) void adam_dense_kernel(float* __restrict__ th, float* __restrict__ mo,
+                                                         float* __restrict__ vo, const float* __restrict__ g,
+                                                         long long n4, const float* __restrict__ scal,
+                                                         int alpha_idx, float reg, float* __restrict__ sq_partials) {
+  __shared__ float red[4];
+  const float alpha = scal[alpha_idx];
+  float sq = 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+       i += (long long)gridDim.x * blockDim.x) {
+    float4 t = reinterpret_cast<float4*>(th)[i];
+    float4 m = reinterpret_cast<float4*>(mo)[i];
+    float4 v = reinterpret_cast<float4*>(vo)[i];
+    const float4 gg = reinterpret_cast<const float4*>(g)[i];
+    float* tp = &t.x; float* mp = &m.x; float* vp = &v.x; const float* gp = &gg.x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float x = tp[j];
+      sq += x * x;
+      const float gr = gp[j] + reg * x;
+      mp[j] += (gr - mp[j]) * (1.f - ADAM_B1);
+      vp[j] += (gr * gr - vp[j]) * (1.f - ADAM_B2);
+      tp[j] = x - (mp[j] * alpha) / (sqrtf(vp[j]) + ADAM_EPS);
+    }
+    reinterpret_cast<float4*>(th)[i] = t;
+    reinterpret_cast<float4*>(mo)[i] = m;
+    reinterpret_cast<float4*>(vo)[i] = v;
+  }
+  if (sq_partials) {
+    const float s = block_sum_256(sq, red);
+    if (threadIdx.x == 0) sq_partials[blockIdx.x] = s;
+  }
+}
+
+// AdamOptimizer._apply_sparse_shared over ALL rows of user_embeddings (TF-1 Adam is not lazy,
+// SURVEY Appendix B.5): rows of the current batch take their gradient from gUb, others g = 0.
+//   m = m*b1 + g'(1-b1) ; v = v*b2 + g'^2(1-b2) ; theta -= alpha*m/(sqrt(v)+eps)
+// pos[r] = position of row r in this epoch's permutation (-1 if absent); batch = [start, start+nb).
+__global__ __launch_bounds__(256) void adam_rows_kernel(float* __restrict__ th, float* __restrict__ mo,
+                                                        float* __restrict__ vo, const float* __restrict__ gb,
+                                                        const int* __restrict__ pos, int start, int nb,
+                                                        int nrows, int ld, const float* __restrict__ scal,
+                                                        int alpha_idx, float reg, float* __restrict__ sq_partials) {
+  __shared__ float red[4];
+  const float alpha = scal[alpha_idx];
+  const int c4 = ld / 4;
+  const long long total = (long long)nrows * c4;
+  float sq = 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / c4), c = (int)(i % c4);
+    const int slot = pos[r] - start;
+    float4 gg = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (slot >= 0 && slot < nb) gg = reinterpret_cast<const float4*>(gb + (size_t)slot * ld)[c];
+    float4 t = reinterpret_cast<float4*>(th)[i];
+    float4 m = reinterpret_cast<float4*>(mo)[i];
+    float4 v = reinterpret_cast<float4*>(vo)[i];
+    float* tp = &t.x; float* mp = &m.x; float* vp = &v.x; const float* gp = &gg.x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float x = tp[j];
+      sq += x * x;
+      const float gr = gp[j] + reg * x;
+      mp[j] = mp[j] * ADAM_B1 + gr * (1.f - ADAM_B1);
+      vp[j] = vp[j] * ADAM_B2 + (gr * gr) * (1.f - ADAM_B2);
+      tp[j] = x - alpha * mp[j] / (sqrtf(vp[j]) + ADAM_EPS);
+    }
+    reinterpret_cast<float4*>(th)[i] = t;
+    reinterpret_cast<float4*>(mo)[i] = m;
+    reinterpret_cast<float4*>(vo)[i] = v;
+  }
+  if (sq_partials) {
+    const float s = block_sum_256(sq, red);
+    if (threadIdx.x == 0) sq_partials[blockIdx.x] = s;
+  }
+}
+
+__global__ void fill_kernel(float* __restrict__ p, float v, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x)
+    p[i] = v;
+}
+
+}  // namespace ganmf

@@ -1,0 +1,157 @@
+"""Thin object wrapper of one libganmf_hip handle (one GPU).  No arithmetic happens here."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+def _f32p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _i32p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+class Engine:
+    def __init__(self, num_users, num_items, num_factors, emb_dim, batch_size, d_lr=1e-4, g_lr=1e-4, d_reg=0.0,
+                 g_reg=0.0, m=1.0, recon_coefficient=1e-2, model=L.MODEL_GANMF, d_layers=1, d_act="linear",
+                 device=0, world_size=1, rank=0, row_offset=0):
+        self.lib = L.load_library()
+        if self.lib.ganmf_device_count() < 1:
+            raise L.GanmfError("no HIP device visible: libganmf_hip has no CPU fallback")
+        cfg = L.Cfg(abi_version=L.ABI_VERSION, model=model, num_users=num_users, num_items=num_items,
+                    num_factors=num_factors, emb_dim=emb_dim, d_layers=d_layers, d_act=L.ACT[d_act],
+                    batch_size=batch_size, d_lr=d_lr, g_lr=g_lr, d_reg=d_reg, g_reg=g_reg, m=m,
+                    recon_coefficient=recon_coefficient, device=device, world_size=world_size, rank=rank,
+                    row_offset=row_offset, flags=0)
+        self.cfg = cfg
+        self.h = C.c_void_p()
+        L.check(self.lib.ganmf_create(C.byref(cfg), C.byref(self.h)), "ganmf_create")
+        self.num_users, self.num_items = num_users, num_items
+        self.batch_size = min(batch_size, num_users)
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h.value:
+            self.lib.ganmf_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- data -------------------------------------------------------------------------------
+    def set_urm(self, urm_csr):
+        urm = urm_csr.tocsr()
+        urm.sum_duplicates()
+        urm.sort_indices()
+        indptr = np.ascontiguousarray(urm.indptr, dtype=np.int64)
+        indices = np.ascontiguousarray(urm.indices, dtype=np.int32)
+        data = np.ascontiguousarray(urm.data, dtype=np.float32)
+        L.check(self.lib.ganmf_set_urm_csr(self.h, indptr.ctypes.data_as(C.POINTER(C.c_int64)), _i32p(indices),
+                                           _f32p(data), urm.shape[0], urm.shape[1]), "ganmf_set_urm_csr")
+
+    def shape(self, tid):
+        r, c = C.c_int64(), C.c_int64()
+        L.check(self.lib.ganmf_tensor_shape(self.h, tid, C.byref(r), C.byref(c)), "ganmf_tensor_shape")
+        return r.value, c.value
+
+    def set_tensor(self, tid, arr, slot=L.SLOT_PARAM):
+        a = np.ascontiguousarray(arr, dtype=np.float32)
+        L.check(self.lib.ganmf_set_tensor(self.h, tid, slot, _f32p(a), a.size), "ganmf_set_tensor")
+
+    def get_tensor(self, tid, slot=L.SLOT_PARAM):
+        r, c = self.shape(tid)
+        out = np.empty((r, c), dtype=np.float32)
+        L.check(self.lib.ganmf_get_tensor(self.h, tid, slot, _f32p(out), out.size), "ganmf_get_tensor")
+        return out
+
+    def adam_powers(self):
+        out = np.empty(4, dtype=np.float32)
+        L.check(self.lib.ganmf_get_adam_powers(self.h, _f32p(out)), "ganmf_get_adam_powers")
+        return out
+
+    def set_adam_powers(self, p):
+        a = np.ascontiguousarray(p, dtype=np.float32)
+        L.check(self.lib.ganmf_set_adam_powers(self.h, _f32p(a)), "ganmf_set_adam_powers")
+
+    # -- training ---------------------------------------------------------------------------
+    def train_epoch(self, perm, d_steps=1, g_steps=1, steps_per_pass=0, global_batch_rows=None):
+        perm = np.ascontiguousarray(perm, dtype=np.int32)
+        n = perm.size
+        per_pass = max(-(-n // self.batch_size), steps_per_pass)
+        dl = np.zeros(max(d_steps * per_pass, 1), dtype=np.float32)
+        gl = np.zeros(max(g_steps * per_pass, 1), dtype=np.float32)
+        gb = None
+        if global_batch_rows is not None:
+            gb = np.ascontiguousarray(global_batch_rows, dtype=np.int32)
+            assert gb.size == per_pass
+        L.check(self.lib.ganmf_train_epoch(self.h, _i32p(perm), n, d_steps, g_steps, steps_per_pass,
+                                           _i32p(gb) if gb is not None else None, _f32p(dl), _f32p(gl)),
+                "ganmf_train_epoch")
+        return dl[:d_steps * per_pass], gl[:g_steps * per_pass]
+
+    def train_step(self, kind, uids):
+        u = np.ascontiguousarray(uids, dtype=np.int32)
+        loss = C.c_float()
+        L.check(self.lib.ganmf_train_step(self.h, kind, _i32p(u), u.size, C.byref(loss)), "ganmf_train_step")
+        return np.float32(loss.value)
+
+    def scores(self, ids, transposed=False):
+        ids = np.ascontiguousarray(ids, dtype=np.int32).ravel()
+        width = self.num_users if transposed else self.num_items
+        out = np.empty((ids.size, width), dtype=np.float32)
+        if ids.size:
+            L.check(self.lib.ganmf_scores(self.h, _i32p(ids), ids.size, int(transposed), _f32p(out)), "ganmf_scores")
+        return out
+
+    def snapshot_best(self):
+        L.check(self.lib.ganmf_snapshot_best(self.h), "ganmf_snapshot_best")
+
+    def restore_best(self):
+        L.check(self.lib.ganmf_restore_best(self.h), "ganmf_restore_best")
+
+    # -- measurement ------------------------------------------------------------------------
+    def profile(self, on):
+        L.check(self.lib.ganmf_profile_enable(self.h, int(on)), "ganmf_profile_enable")
+
+    def profile_read(self):
+        buf = (L.ProfEntry * L.PROF_MAX)()
+        n = C.c_int32()
+        L.check(self.lib.ganmf_profile_read(self.h, buf, L.PROF_MAX, C.byref(n)), "ganmf_profile_read")
+        return [dict(name=buf[i].name.decode(), launches=buf[i].launches, ms=buf[i].ms, flops=buf[i].flops,
+                     bytes=buf[i].bytes) for i in range(n.value)]
+
+    def bench_scores(self, n, transposed=False, iters=10):
+        ms = C.c_float()
+        L.check(self.lib.ganmf_bench_scores(self.h, n, int(transposed), iters, C.byref(ms)), "ganmf_bench_scores")
+        return ms.value
+
+    def comm_init(self, id_bytes):
+        arr = (C.c_uint8 * 128).from_buffer_copy(bytes(id_bytes))
+        L.check(self.lib.ganmf_comm_init(self.h, arr), "ganmf_comm_init")
+
+
+def comm_unique_id():
+    lib = L.load_library()
+    arr = (C.c_uint8 * 128)()
+    L.check(lib.ganmf_comm_unique_id(arr), "ganmf_comm_unique_id")
+    return bytes(arr)
+
+
+def gemm_f32(A, B, a_kmajor=False, b_kmajor=False, tile=0, nsplit=0, iters=1, device=0):
+    """C = op(A).op(B) through the stand-alone entry (tests / bench)."""
+    lib = L.load_library()
+    A = np.ascontiguousarray(A, dtype=np.float32)
+    B = np.ascontiguousarray(B, dtype=np.float32)
+    K, M = (A.shape if a_kmajor else A.shape[::-1])
+    Kb, N = (B.shape if b_kmajor else B.shape[::-1])
+    assert K == Kb, (A.shape, B.shape)
+    out = np.empty((M, N), dtype=np.float32)
+    ms = C.c_float()
+    L.check(lib.ganmf_gemm_f32(device, _f32p(A), _f32p(B), _f32p(out), M, N, K, int(a_kmajor), int(b_kmajor),
+                               tile, nsplit, iters, C.byref(ms)), "ganmf_gemm_f32")
+    return out, ms.value

@@ -1,0 +1,160 @@
+/*
+ * ganmf_hip.h — C ABI of libganmf_hip.so: the MI355X (gfx950) GANMF / DisGANMF training hot path.
+ *
+ * This is the drop-in boundary.  Every entry point replaces one interaction the reference has
+ * with its numeric runtime (a TensorFlow-1.12 tf.Session); the reference site is cited per
+ * function (paths relative to the reference repository root).  The Python host classes in
+ * ganmf_amd/ bind exactly these symbols through ctypes; nothing else crosses the boundary.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; caller owns every host buffer; the library copies in/out
+ *     before returning; the handle owns all device memory, its HIP stream and (optionally) its
+ *     RCCL communicator.
+ *   - return value 0 = OK, negative = error; ganmf_last_error() returns a thread-local message.
+ *     No exceptions cross the ABI and the library never calls exit().
+ *   - a handle is driven by one host thread at a time; distinct handles are independent.
+ *   - all floating point data are IEEE float32 (the reference's dtype, GANMF.py:108), ids int32
+ *     (GANMF.py:109), CSR row pointers int64.
+ *   - "training orientation": rows = the generator's users, columns = profile width.  In item
+ *     mode the host passes URM^T (GANMF.py:32-36).
+ */
+#ifndef GANMF_HIP_H
+#define GANMF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GANMF_ABI_VERSION 1
+
+typedef struct ganmf_handle ganmf_handle;
+
+enum { GANMF_MODEL_GANMF = 0, GANMF_MODEL_DISGANMF = 1 };
+enum { GANMF_ACT_LINEAR = 0, GANMF_ACT_TANH = 1, GANMF_ACT_RELU = 2, GANMF_ACT_SIGMOID = 3 };
+
+/* Tensor ids.  Discriminator tensors are numbered in the order of the reference's
+ * tf.get_collection(TRAINABLE_VARIABLES, scope) (GANMF.py:121, DisGANMF.py:121):
+ *   GANMF:    0 encoding/kernel [N,e]  1 encoding/bias [e]  2 decoding/kernel [e,N]  3 decoding/bias [N]
+ *   DisGANMF: 2l layer_l/kernel  2l+1 layer_l/bias (l < d_layers)  2L D_output/kernel [e,1]  2L+1 D_output/bias [1]
+ * Generator tensors (GANMF.py:122): */
+#define GANMF_T_USER_EMB 100 /* generator/user_embeddings [U,k] */
+#define GANMF_T_ITEM_EMB 101 /* generator/item_embeddings [N,k] */
+
+/* which copy of a tensor */
+enum { GANMF_SLOT_PARAM = 0, GANMF_SLOT_ADAM_M = 1, GANMF_SLOT_ADAM_V = 2, GANMF_SLOT_BEST = 3 };
+
+/* Hyper-parameters = the kwargs of fit() (GANMF.py:88-90, DisGANMF.py:83-85) that enter the graph. */
+typedef struct ganmf_cfg {
+  int32_t abi_version;      /* GANMF_ABI_VERSION */
+  int32_t model;            /* GANMF_MODEL_* */
+  int64_t num_users;        /* rows held by THIS handle (a shard when world_size > 1) */
+  int64_t num_items;        /* profile width N */
+  int32_t num_factors;      /* k */
+  int32_t emb_dim;          /* GANMF emb_dim / DisGANMF d_nodes */
+  int32_t d_layers;         /* DisGANMF only */
+  int32_t d_act;            /* DisGANMF only, GANMF_ACT_* */
+  int32_t batch_size;       /* rows per minibatch on this handle */
+  float d_lr, g_lr, d_reg, g_reg;
+  float m;                  /* GANMF hinge margin multiplier */
+  float recon_coefficient;  /* alpha */
+  int32_t device;           /* HIP device ordinal */
+  int32_t world_size;       /* data-parallel replicas (1 = single GPU) */
+  int32_t rank;
+  int64_t row_offset;       /* global id of local row 0 (DisGANMF feeds float(uid), DisGANMF.py:110) */
+  uint32_t flags;           /* GANMF_FLAG_* */
+} ganmf_cfg;
+
+#define GANMF_FLAG_NONE 0u
+
+/* Replaces: tf.reset_default_graph + build() + optimizers + Session + initialize_all_variables
+ * (GANMF.py:97-105,146-149).  Parameters start at zero; the host uploads initial values with
+ * ganmf_set_tensor (the reference's Glorot init happens inside TF and is not reproducible). */
+int ganmf_create(const ganmf_cfg* cfg, ganmf_handle** out);
+int ganmf_destroy(ganmf_handle* h);
+
+/* Data-parallel setup (no reference counterpart: the reference is single-device).  Rank 0 calls
+ * ganmf_comm_unique_id, the host broadcasts the 128 bytes, every rank calls ganmf_comm_init. */
+int ganmf_comm_unique_id(uint8_t out128[128]);
+int ganmf_comm_init(ganmf_handle* h, const uint8_t id128[128]);
+
+/* Replaces the per-minibatch host work `URM_train[uids].toarray()` + feed_dict upload
+ * (GANMF.py:183-187,198-201): the CSR matrix (training orientation, this handle's rows) is
+ * uploaded ONCE and minibatch rows are expanded on the device. */
+int ganmf_set_urm_csr(ganmf_handle* h, const int64_t* indptr, const int32_t* indices,
+                      const float* data, int64_t n_rows, int64_t n_cols);
+
+/* Replaces sess.run(var) / sess.run(var.assign(x)) on one variable (GANMF.py:294-302,
+ * Utils_.py:292-294,305-310).  `n` must equal the tensor's element count (row-major, unpadded). */
+int ganmf_set_tensor(ganmf_handle* h, int tensor_id, int slot, const float* host, int64_t n);
+int ganmf_get_tensor(ganmf_handle* h, int tensor_id, int slot, float* host, int64_t n);
+int ganmf_tensor_shape(ganmf_handle* h, int tensor_id, int64_t* rows, int64_t* cols);
+
+/* Adam beta-power accumulators of the two optimizers (AdamOptimizer._finish): 4 floats
+ * {b1p_D, b2p_D, b1p_G, b2p_G}; exposed for save/restore and tests. */
+int ganmf_get_adam_powers(ganmf_handle* h, float out4[4]);
+int ganmf_set_adam_powers(ganmf_handle* h, const float in4[4]);
+
+/* Replaces one pass of the `while epoch` body (GANMF.py:175-203): given this epoch's already
+ * shuffled row order `perm` (GANMF.py:175; local row ids), runs d_steps passes of discriminator
+ * updates over consecutive slices of batch_size rows (ragged tail kept) and then g_steps passes
+ * of generator updates over the same slices.  Losses are the pre-update values the reference's
+ * sess.run([train, loss]) returns (GANMF.py:186-187,200-201); arrays hold
+ * d_steps*ceil(n/batch) resp. g_steps*ceil(n/batch) floats (may be NULL).
+ * With world_size > 1 `n_steps_per_pass` (>= ceil(n/batch)) forces every rank to issue the same
+ * number of collectives; pass 0 for the default.  `global_batch_rows[i]` = rows in the i-th slice
+ * summed over all ranks (NULL when world_size == 1).  Blocking. */
+int ganmf_train_epoch(ganmf_handle* h, const int32_t* perm, int64_t n, int32_t d_steps,
+                      int32_t g_steps, int64_t n_steps_per_pass, const int32_t* global_batch_rows,
+                      float* d_losses, float* g_losses);
+
+/* Single updates on an explicit id list (same arithmetic as inside ganmf_train_epoch); used by
+ * tests and by callers that schedule batches themselves.  kind: 0 = D-step, 1 = G-step. */
+int ganmf_train_step(ganmf_handle* h, int kind, const int32_t* uids, int32_t n, float* loss);
+
+/* Replaces _compute_item_score (GANMF.py:285-292, DisGANMF.py:257-262).
+ *   transposed = 0 (user mode): out[i, :] = U[ids[i]] . V^T          -> [n, num_items]
+ *   transposed = 1 (item mode): out[i, :] = (U V^T)^T[ids[i]] = V[ids[i]] . U^T -> [n, num_users]
+ * (the item-mode product is formed directly; the full matrix is never materialised). */
+int ganmf_scores(ganmf_handle* h, const int32_t* ids, int64_t n, int transposed, float* out);
+
+/* Replaces save_current_model / load_model (GANMF.py:249-255, Utils_.py:292-294): device-side
+ * copies of all trainable tensors to / from their `best` twins. */
+int ganmf_snapshot_best(ganmf_handle* h);
+int ganmf_restore_best(ganmf_handle* h);
+
+/* Measurement hooks (bench.py).  ganmf_profile_enable(1) makes every kernel launch of the
+ * training step be bracketed by hipEvents on the handle's stream; ganmf_profile_read returns per
+ * kernel class the number of launches, total milliseconds and total algorithmic FLOPs / bytes. */
+#define GANMF_PROF_MAX 48
+typedef struct ganmf_prof_entry {
+  char name[48];
+  int64_t launches;
+  double ms;
+  double flops;   /* algorithmic */
+  double bytes;   /* algorithmic HBM bytes */
+} ganmf_prof_entry;
+int ganmf_profile_enable(ganmf_handle* h, int on);
+int ganmf_profile_read(ganmf_handle* h, ganmf_prof_entry* out, int32_t cap, int32_t* n_out);
+
+/* Device-resident scoring GEMM timing (no D2H): scores for the first n rows, `iters` launches;
+ * returns average milliseconds per launch measured with hipEvents on the handle's stream. */
+int ganmf_bench_scores(ganmf_handle* h, int64_t n, int transposed, int32_t iters, float* ms_per_launch);
+
+/* Stand-alone fp32 MFMA GEMM on host buffers, C[M,N] = op(A) . op(B):
+ *   a_kmajor = 0: A is [M, K] row-major;  1: A is [K, M] row-major
+ *   b_kmajor = 0: B is [N, K] row-major;  1: B is [K, N] row-major
+ * tile = 0 auto, 64 or 128; nsplit = 0 auto.  `iters` >= 1 repeats the launch on resident data and
+ * returns the average kernel milliseconds in *ms (may be NULL).  Test and bench entry. */
+int ganmf_gemm_f32(int device, const float* A, const float* B, float* C, int64_t M, int64_t N,
+                   int64_t K, int a_kmajor, int b_kmajor, int tile, int nsplit, int iters, float* ms);
+
+int ganmf_device_count(void);
+int ganmf_abi_version(void);
+const char* ganmf_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GANMF_HIP_H */
