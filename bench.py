@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""bench.py — GANMF training steps/sec on MI355X (BASELINE.json metric), one process per GPU.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A *step* is one minibatch parameter update — one `sess.run([dtrain|gtrain, loss])` of the
+reference (GANRec/GANMF.py:186-187,200-201) — on a batch of 128 user rows.  K timed steps are
+K/2 discriminator updates followed by K/2 generator updates over the same slices, issued exactly
+as fit() issues them (ganmf_train_epoch, one C call per pass of at most floor(U/128) slices).
+
+Workload at every N: BASELINE.json configs[1] — "GANMF --user on MovieLens-1M shape
+(6040 x 3706, k=250, batch=128)" with the reference's tuned hyper-parameters
+(experiments/GANMF_user_1M/best_params.txt: emb_dim=992, m=10, d_lr=1e-4, g_lr=1.653e-4,
+d_reg=1e-4, alpha=0.01) on a synthetic binary user x item matrix of that shape and density
+(ganmf_amd/synthetic.py), resident in HBM as CSR before the timed region.  With N > 1 GPUs each
+rank holds its own 6040-user shard (global users = 6040*N, weak scaling) and the gradients of the
+replicated tensors are all-reduced over RCCL every step; `value` counts the 128-row minibatch
+updates all ranks processed per second (= N x synchronous global steps/s).
+
+Extra objects on the JSON line: `roofline` (dominant kernel of the step, HIP-event timed on the
+library's stream in a profiled repeat of the same K steps right after the timed region — events
+stay out of the timed region so that `value` is not perturbed), `cpu_baseline` (the numpy fp32
+oracle = a port of the reference's per-step procedure, timed on this box's host cores on a
+bounded sample), `kernels` (per-kernel-class table) and `scoring_gemm` (the 6040x3706x250
+generator/scoring GEMM the north star quotes its MFMA target on).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 FLOP/clk/CU x 256 CU x 2.4 GHz
+PEAK_HBM_GBS = 8000.0          # HBM3E spec; ~6.3 TB/s achievable
+
+C2 = dict(U=6040, N=3706, k=250, e=992, B=128, density=0.035,
+          hp=dict(d_lr=1e-4, g_lr=0.0001653241474168571, d_reg=1e-4, g_reg=0.0, m=10.0, recon_coefficient=0.01))
+
+
+def run_steps(eng, perm, B, n_steps):
+    """n_steps = D updates then G updates, in chunks of full batches (same call fit() makes)."""
+    per_call = (len(perm) // B)
+    half = n_steps // 2
+    done = 0
+    while done < half:
+        c = min(per_call, half - done)
+        eng.train_epoch(perm[:c * B], 1, 1)
+        done += c
+    return 2 * half
+
+
+def cpu_baseline(urm, params, w, seconds):
+    """Port of the reference's per-step procedure (densify + dense GEMMs + dense TF-Adam) in numpy
+    fp32 on the host cores; bounded sample of the same workload."""
+    from oracle.ganmf_oracle import GANMFOracle   # checker / baseline only, never the product path
+    o = GANMFOracle(w["U"], w["N"], w["k"], w["e"], dtype=np.float32, **w["hp"])
+    o.set_params(**params)
+    rng = np.random.RandomState(7)
+    perm = rng.permutation(w["U"])
+    B = w["B"]
+
+    def pair(i):
+        uids = perm[(i * B) % (w["U"] - B):][:B]
+        X = np.asarray(urm[uids].toarray(), dtype=np.float32)   # the reference's per-step densify
+        o.d_step(uids, X)
+        X = np.asarray(urm[uids].toarray(), dtype=np.float32)
+        o.g_step(uids, X)
+    pair(0)  # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        pair(n + 1)
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or n >= 200:
+            break
+    threads = os.cpu_count()
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        pass
+    return {"value": round(2 * n / el, 3), "unit": "steps/s", "cores": int(threads), "kind": "port",
+            "sample": "%d D + %d G updates (B=%d) of the same synthetic workload, numpy fp32 oracle incl. "
+                      "URM[uids].toarray() densify and dense Adam, %.1f s" % (n, n, B, el)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=192)
+    ap.add_argument("--warmup", type=int, default=96)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch N>1 with python -m torch.distributed.run (see module docstring)")
+    steps = max(2, args.steps - args.steps % 2)
+    warmup = max(0, args.warmup - args.warmup % 2)
+
+    torch = dist = None
+    try:
+        import torch
+        import torch.distributed as dist
+    except Exception:
+        if world > 1:
+            raise
+    if world > 1:
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+        dist.init_process_group("gloo", rank=rank, world_size=world)   # control plane only
+
+    from ganmf_amd.engine import Engine, comm_unique_id
+    from ganmf_amd.synthetic import glorot_params, synthetic_urm
+
+    w = C2
+    urm = synthetic_urm(w["U"], w["N"], w["density"], seed=1337 + rank)
+    params = glorot_params(w["U"], w["N"], w["k"], w["e"], seed=1337)
+    if rank:
+        params["U"] = glorot_params(w["U"], 8, w["k"], 8, seed=1337 + rank)["U"]   # own user rows
+    eng = Engine(w["U"], w["N"], w["k"], w["e"], w["B"], device=local_rank, world_size=world, rank=rank,
+                 row_offset=rank * w["U"], **w["hp"])
+    eng.set_urm(urm)
+    for name, tid in (("We", 0), ("be", 1), ("Wd", 2), ("bd", 3), ("U", 100), ("V", 101)):
+        eng.set_tensor(tid, params[name])
+    if world > 1:
+        ids = [comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        eng.comm_init(ids[0])
+        _train = eng.train_epoch
+
+        def train_dp(perm, d, g):   # every slice is full on every rank: global rows = world*B
+            n = len(perm) // w["B"]
+            return _train(perm, d, g, steps_per_pass=n, global_batch_rows=np.full(n, world * w["B"], np.int32))
+        eng.train_epoch = train_dp
+
+    def sync():
+        if torch is not None and torch.cuda.is_available():
+            torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    perm = np.random.RandomState(1337 + rank).permutation(w["U"]).astype(np.int32)
+    if warmup:
+        run_steps(eng, perm, w["B"], warmup)
+    sync()
+    t0 = time.perf_counter()
+    done = run_steps(eng, perm, w["B"], steps)      # blocking: returns after the stream drained
+    sync()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+
+    # ---- profiled repeat (HIP events around every launch, on the library's stream) --------------
+    eng.profile(True)
+    run_steps(eng, perm, w["B"], steps)
+    prof = eng.profile_read()
+    eng.profile(False)
+
+    out = None
+    if rank == 0:
+        kernels = []
+        for p in prof:
+            avg_ms = p["ms"] / max(p["launches"], 1)
+            row = {"name": p["name"], "launches": p["launches"], "avg_us": round(avg_ms * 1e3, 2),
+                   "total_ms": round(p["ms"], 3)}
+            if p["flops"] > 0:
+                row["tflops"] = round(p["flops"] / max(p["ms"], 1e-9) / 1e9, 2)
+            if p["bytes"] > 0:
+                row["gbs"] = round(p["bytes"] / max(p["ms"], 1e-9) / 1e6, 1)
+            kernels.append(row)
+        gemms = [p for p in prof if p["flops"] > 0]
+        dom = max(gemms, key=lambda p: p["ms"])
+        dom_tf = dom["flops"] / dom["ms"] / 1e9
+        roofline = {"kernel": dom["name"], "bound": "mfma", "achieved": round(dom_tf, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(dom_tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "flops_per_launch": dom["flops"] / dom["launches"],
+                    "avg_launch_us": round(dom["ms"] / dom["launches"] * 1e3, 2)}
+        step_flops = sum(p["flops"] for p in prof)
+        step_ms = sum(p["ms"] for p in prof)
+        roofline["whole_step_tflops_kernel_time"] = round(step_flops / step_ms / 1e9, 2)
+        # generator / scoring GEMM at the shape the north star quotes (6040 x 3706, k = 250)
+        ms_sc = eng.bench_scores(w["U"], transposed=False, iters=20)
+        sc_tf = 2.0 * w["U"] * w["N"] * w["k"] / ms_sc / 1e9
+        scoring = {"shape": [w["U"], w["N"], w["k"]], "ms": round(ms_sc, 4), "achieved": round(sc_tf, 2),
+                   "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(sc_tf / PEAK_F32_MFMA_TFLOPS, 4)}
+        out = {
+            "metric": "GANMF training steps/sec", "value": round(world * done / el, 2), "unit": "steps/s",
+            "n_gpus": world, "steps": done, "warmup": warmup, "ms_per_step": round(el / done * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "GANMF --user, MovieLens-1M shape %dx%d per GPU, k=%d, emb_dim=%d, batch=%d/GPU, "
+                                   "tuned hyper-parameters (BASELINE.json configs[1])" % (w["U"], w["N"], w["k"], w["e"], w["B"]),
+                       "step": "one 128-row minibatch update (D or G), K/2 D then K/2 G",
+                       "global_steps_per_s": round(done / el, 2), "rows_per_s": round(world * done * w["B"] / el, 1),
+                       "parallelism": "dp%d (users sharded row-wise, RCCL all-reduce of D and V gradients)" % world},
+            "roofline": roofline, "scoring_gemm": scoring, "kernels": kernels,
+            "reference_derived_steps_per_s": 84.0,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(urm, params, w, args.cpu_seconds)
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

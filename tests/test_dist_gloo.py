@@ -1,0 +1,94 @@
+"""The data-parallel decomposition (ganmf_amd/dist.py + the per-rank arithmetic of the C++
+d_step/g_step) checked on CPU with torch.distributed gloo, world_size 2: each rank computes the
+oracle's gradients on its own rows with the GLOBAL batch size in the loss scales, gradients of
+replicated tensors are all-reduced, and the result must equal the single-process oracle on the
+union batch."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_bounds_and_plan():
+    from ganmf_amd.dist import epoch_plan, shard_bounds
+    b = shard_bounds(10, 4)
+    assert b == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    steps, rows = epoch_plan([7, 3], 4)
+    assert steps == 2 and rows.tolist() == [7, 3]      # step 0: 4+3, step 1: 3+0 (rank 1 out of rows)
+    steps, rows = epoch_plan([6040] * 8, 128)
+    assert steps == 48 and rows[0] == 1024 and rows[-1] == 8 * (6040 - 47 * 128)
+
+
+def _worker(rank, world, port, out):
+    import torch.distributed as dist
+    import torch
+    sys.path.insert(0, ROOT)
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    from oracle.ganmf_oracle import GANMFOracle
+    from ganmf_amd.dist import epoch_plan, shard_bounds
+    rng = np.random.RandomState(0)
+    U, N, k, e, B = 23, 31, 4, 6, 8
+    X = (rng.rand(U, N) < 0.2).astype(np.float64)
+    hp = dict(d_lr=1e-3, g_lr=1e-3, d_reg=1e-3, g_reg=0.0, m=10.0, recon_coefficient=0.1)
+    full = GANMFOracle(U, N, k, e, dtype=np.float64, seed=4, **hp)
+    bounds = shard_bounds(U, world)
+    lo, hi = bounds[rank]
+    steps, grows = epoch_plan([b - a for a, b in bounds], B)
+    # local model: own rows of U, replicated everything else
+    loc = GANMFOracle(hi - lo, N, k, e, dtype=np.float64, seed=4, **hp)
+    p = full.get_params()
+    loc.set_params(We=p["We"], be=p["be"], Wd=p["Wd"], bd=p["bd"], V=p["V"], U=p["U"][lo:hi])
+    for i in range(steps):
+        rows = np.arange(i * B, min((i + 1) * B, hi - lo))
+        Bg = int(grows[i])
+        # ---- D step with global scales: sums all-reduced before the hinge
+        nb = len(rows)
+        if nb:
+            F = loc.generator(rows)
+            Er, dr, _ = loc.autoencoder(X[lo:hi][rows]); Ef, df, _ = loc.autoencoder(F)
+            sums = torch.tensor([np.sum(dr * dr), np.sum(df * df)])
+        else:
+            sums = torch.zeros(2, dtype=torch.float64)
+        dist.all_reduce(sums)
+        Lr, Lf = sums[0].item() / (Bg * N), sums[1].item() / (Bg * N)
+        on = (hp["m"] * Lr - Lf) > 0
+        g = {n: np.zeros_like(loc.p[n]) for n in loc.D_NAMES}
+        if nb:
+            s = 2.0 / (Bg * N)
+            for inp, E, dl, c in ((X[lo:hi][rows], Er, dr, 1 + (hp["m"] if on else 0)), (F, Ef, df, -1.0 if on else 0.0)):
+                dR = c * s * dl
+                g["Wd"] += E.T @ dR; g["bd"] += dR.sum(0)
+                dE = dR @ loc.p["Wd"].T
+                g["We"] += inp.T @ dE; g["be"] += dE.sum(0)
+        for n in loc.D_NAMES:
+            t = torch.from_numpy(g[n]); dist.all_reduce(t)
+            g[n] = t.numpy() + hp["d_reg"] * loc.p[n]
+            loc.opt_d.apply_dense(n, loc.p[n], g[n])
+        loc.opt_d.finish()
+        # reference: one oracle D-step on the union batch
+        union = np.concatenate([np.arange(a + i * B, min(a + (i + 1) * B, b)) for a, b in bounds])
+        full.d_step(union, X[union])
+    for n in loc.D_NAMES:
+        np.testing.assert_allclose(loc.p[n], full.p[n], rtol=1e-9, atol=1e-12)
+    dist.barrier()
+    dist.destroy_process_group()
+    out.put((rank, "ok"))
+
+
+def test_sharded_d_steps_equal_union_batch_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    got = sorted(q.get(timeout=5) for _ in range(2))
+    assert got == [(0, "ok"), (1, "ok")]
