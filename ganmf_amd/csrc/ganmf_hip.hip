@@ -5,9 +5,15 @@
 // best-snapshot twin, the minibatch work buffers.  The host sends one permutation per epoch and
 // receives the per-minibatch losses; nothing else crosses PCIe inside the training loop.
 //
-// Leading dimensions are rounded up to 32 floats (128-byte rows); pad columns of every buffer that
-// is consumed along K are zero and stay zero (Adam on a zero gradient of a zero parameter is a
-// fixed point; GEMM / reduce epilogues never store into pad columns).
+// Layout in HBM.  Every matrix is row-major with a leading dimension rounded up to 64 floats
+// (256-byte rows, whole K-tiles); pad columns of every buffer that is consumed along K are zero
+// and stay zero (Adam on a zero gradient of a zero parameter is a fixed point; GEMM / reduce
+// epilogues never store into pad columns).
+// Bias folding: the encoder bias is stored as row N of We_ext [N+1, e] and the decoder bias as
+// row e of Wd_ext [e+1, N]; minibatch matrices carry a ones column (XF[:, N] = 1, E[:, e] = 1).
+// The bias add then rides inside the forward GEMMs and both bias gradients fall out of the weight
+// gradient GEMMs as their last row, so biases need no kernels of their own (and Adam / L2 see
+// them as part of the same tensor, exactly as the reference regularises biases, GANMF.py:131-132).
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -75,14 +81,14 @@ struct Tensor {
 
 // profiling: kernel classes
 enum Tag : int {
-  T_DENSIFY, T_GATHER, T_GEMM_GEN, T_GEMM_ENC, T_RED_ENC, T_GEMM_DEC, T_DCOEF, T_GEMM_DE, T_RED_DE,
-  T_GEMM_GWD, T_GEMM_GWE, T_COLSUM, T_ADAM_D, T_GEMM_DF, T_GEMM_GUB, T_RED_GUB, T_GEMM_GV, T_ADAM_V,
+  T_DENSIFY, T_GEMM_GEN, T_GEMM_ENC, T_RED_ENC, T_GEMM_DEC, T_DCOEF, T_GEMM_DE, T_RED_DE,
+  T_GEMM_GWD, T_GEMM_GWE, T_ADAM_D, T_GEMM_DF, T_GEMM_GUB, T_RED_GUB, T_GEMM_GV, T_ADAM_V,
   T_ADAM_U, T_MULTIRED, T_ALLREDUCE, T_SCORE_GEMM, T_COUNT
 };
 const char* const kTagName[T_COUNT] = {
-  "densify_rows", "gather_rows", "gemm_generator[B,k]x[N,k]^T", "gemm_encode[2B,N]x[N,e]", "reduce_encode",
-  "gemm_decode[2B,e]x[e,N]+mse", "d_coef", "gemm_dE[2B,N]x[e,N]^T", "reduce_dE", "gemm_gWd[2B,e]^Tx[2B,N]",
-  "gemm_gWe[2B,N]^Tx[2B,e]", "colsum_bias_grads", "adam_dense_D", "gemm_dF[B,e]x[N,e]^T", "gemm_gUb[B,N]x[N,k]",
+  "densify_rows+gather", "gemm_generator[B,k]x[N,k]^T", "gemm_encode[2B,N]x[N,e]", "reduce_encode",
+  "gemm_decode[2B,e]x[e,N]+mse", "d_coef+scale", "gemm_dE[2B,N]x[e,N]^T", "reduce_dE", "gemm_gWd[2B,e]^Tx[2B,N]",
+  "gemm_gWe[2B,N]^Tx[2B,e]", "adam_dense_D", "gemm_dF[B,e]x[N,e]^T", "gemm_gUb[B,N]x[N,k]",
   "reduce_gUb", "gemm_gV[B,N]^Tx[B,k]", "adam_dense_V", "adam_rows_U", "multi_reduce", "rccl_allreduce",
   "gemm_scores"};
 
@@ -96,8 +102,8 @@ struct ganmf_handle {
   hipStream_t st = nullptr;
   int U = 0, N = 0, k = 0, e = 0, B = 0;
   int ldN = 0, ldk = 0, lde = 0;
-  Tensor We, be, Wd, bd, Ue, V;
-  float* gD = nullptr;  // contiguous [gWe | gbe | gWd | gbd] (one all-reduce)
+  Tensor We, Wd, Ue, V;   // We = We_ext [N+1, e] (row N = encoder bias), Wd = Wd_ext [e+1, N] (row e = decoder bias)
+  float* gD = nullptr;  // contiguous [gWe_ext | gWd_ext] (one all-reduce)
   size_t gD_elems = 0;
   // CSR
   long long* indptr = nullptr;
@@ -109,7 +115,8 @@ struct ganmf_handle {
   int* perm = nullptr;
   int* pos = nullptr;
   // minibatch work buffers
-  float *XF = nullptr, *Ub = nullptr, *E = nullptr, *Dl = nullptr, *dE = nullptr, *dF = nullptr, *gUb = nullptr;
+  float *XF = nullptr, *Ub = nullptr, *E = nullptr, *Es = nullptr, *Dl = nullptr, *dE = nullptr, *dF = nullptr, *gUb = nullptr;
+  float* zero_page = nullptr;
   float* slab = nullptr;
   size_t slab_elems = 0;
   float* rs = nullptr;
@@ -117,7 +124,7 @@ struct ganmf_handle {
   float *sqp = nullptr;  // [2][max_tiles]
   int sqp_stride = 0;
   float* fmp = nullptr;   // [RED_GRID]
-  float* regp = nullptr;  // [6][ADAM_GRID]
+  float* regp = nullptr;  // [4][ADAM_GRID]: We_ext, Wd_ext, U, V
   float *d_parts = nullptr, *g_parts = nullptr;  // [cap][4]
   int64_t parts_cap = 0;
   // scoring scratch
@@ -160,7 +167,7 @@ int dalloc(float** p, size_t elems) {
 }
 
 int alloc_tensor(Tensor& t, int rows, int cols, bool grad_separate) {
-  t.rows = rows; t.cols = cols; t.ld = round_up(cols, 32);
+  t.rows = rows; t.cols = cols; t.ld = round_up(cols + 1, LD_ALIGN);
   TRY(dalloc(&t.p, t.padded()));
   TRY(dalloc(&t.m, t.padded()));
   TRY(dalloc(&t.v, t.padded()));
@@ -174,15 +181,18 @@ void free_tensor(Tensor& t, bool grad_separate) {
   if (grad_separate) hipFree(t.g);
 }
 
-Tensor* find_tensor(ganmf_handle* h, int id) {
+// A view of one reference variable inside the folded tensors: rows x cols at p + row0 * ld.
+struct View { Tensor* t; int row0, rows, cols; };
+
+bool find_view(ganmf_handle* h, int id, View* v) {
   switch (id) {
-    case 0: return &h->We;
-    case 1: return &h->be;
-    case 2: return &h->Wd;
-    case 3: return &h->bd;
-    case GANMF_T_USER_EMB: return &h->Ue;
-    case GANMF_T_ITEM_EMB: return &h->V;
-    default: return nullptr;
+    case 0: *v = {&h->We, 0, h->N, h->e}; return true;      // autoencoder/encoding/kernel
+    case 1: *v = {&h->We, h->N, 1, h->e}; return true;      // autoencoder/encoding/bias  (row N of We_ext)
+    case 2: *v = {&h->Wd, 0, h->e, h->N}; return true;      // autoencoder/decoding/kernel
+    case 3: *v = {&h->Wd, h->e, 1, h->N}; return true;      // autoencoder/decoding/bias  (row e of Wd_ext)
+    case GANMF_T_USER_EMB: *v = {&h->Ue, 0, h->U, h->k}; return true;
+    case GANMF_T_ITEM_EMB: *v = {&h->V, 0, h->N, h->k}; return true;
+    default: return false;
   }
 }
 
@@ -227,7 +237,7 @@ int gemm_splitk(ganmf_handle* h, int tag_gemm, int tag_red, GemmP& g, bool akm, 
   plan_split(h, g.M, g.N, g.K, tile, ns, kps);
   g.nsplit = ns; g.k_per_split = kps;
   g.C = h->slab; g.ldc = r.ld; g.c_split_stride = (long long)g.M * r.ld;
-  g.epi = EPI_STORE;
+  g.epi = EPI_STORE; g.zero_page = h->zero_page;
   if ((size_t)ns * g.M * r.ld > h->slab_elems) return fail(-4, "internal: split-K slab too small");
   {
     Scope s(h, tag_gemm, gemm_flops(g.M, g.N, g.K), gemm_bytes(g.M, g.N, g.K));
@@ -236,13 +246,10 @@ int gemm_splitk(ganmf_handle* h, int tag_gemm, int tag_red, GemmP& g, bool akm, 
   r.part = h->slab; r.split_stride = g.c_split_stride; r.nsplit = ns; r.M = g.M; r.N = g.N;
   {
     Scope s(h, tag_red, 0, 4.0 * (ns + 1) * g.M * g.N);
-    const long long total = (long long)r.M * ((r.N + 3) / 4);
+    const long long total = (long long)r.M * (r.N / 4 + 1);
     const int grid = (int)std::min<long long>(RED_GRID, (total + 255) / 256);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(std::max(grid, 1)), dim3(256), 0, h->st, r);
     HIP_TRY(hipGetLastError());
-    if (r.epi == RED_G_DE && grid < RED_GRID) {
-      // unused partial slots must read as zero
-    }
   }
   return 0;
 }
@@ -256,36 +263,30 @@ int adam_dense(ganmf_handle* h, int tag, Tensor& t, const float* g, int alpha_id
   return 0;
 }
 
-// ---- shared front of both steps: X rows, Ub, F, E = [X;F].We + be ------------------------------
+// ---- shared front of both steps: X rows (+ones column), Ub, F, E = [X;F|1].We_ext ----------------
 int step_front(ganmf_handle* h, const int* rows_dev, int nb, int which) {
   const int N = h->N, k = h->k, e = h->e;
   {
-    Scope s(h, T_DENSIFY, 0, 4.0 * nb * N);
+    Scope s(h, T_DENSIFY, 0, 4.0 * nb * (N + 2 * k));
     hipLaunchKernelGGL(densify_rows_kernel, dim3(nb), dim3(256), 0, h->st, h->indptr, h->indices, h->data,
-                       rows_dev, h->XF, h->ldN, h->scal, which, which ? h->cfg.g_lr : h->cfg.d_lr);
-    HIP_TRY(hipGetLastError());
-  }
-  {
-    Scope s(h, T_GATHER, 0, 8.0 * nb * k);
-    const long long total = (long long)nb * (h->ldk / 4);
-    hipLaunchKernelGGL(gather_rows_kernel, dim3((int)std::min<long long>(1024, (total + 255) / 256)), dim3(256), 0,
-                       h->st, h->Ue.p, h->ldk, rows_dev, nb, h->Ub);
+                       rows_dev, nb, N, h->XF, h->ldN, h->Ue.p, h->ldk, h->Ub, h->scal, which,
+                       which ? h->cfg.g_lr : h->cfg.d_lr);
     HIP_TRY(hipGetLastError());
   }
   {  // F = Ub . V^T  -> rows [nb, 2nb) of XF            (GANMF.py:83)
     GemmP g{};
     g.A = h->Ub; g.lda = h->ldk; g.B = h->V.p; g.ldb = h->ldk;
     g.C = h->XF + (size_t)nb * h->ldN; g.ldc = h->ldN;
-    g.M = nb; g.N = N; g.K = k; g.epi = EPI_STORE;
+    g.M = nb; g.N = N; g.K = k; g.epi = EPI_STORE; g.zero_page = h->zero_page;
     Scope s(h, T_GEMM_GEN, gemm_flops(nb, N, k), gemm_bytes(nb, N, k));
     HIP_TRY(gemm_launch(h->st, g, false, false, h->tile_force));
   }
-  {  // E = [X;F] . We + be                              (GANMF.py:64-65)
+  {  // E = [X;F | 1] . We_ext  (bias = row N), E[:, e] = 1      (GANMF.py:64-65)
     GemmP g{};
     g.A = h->XF; g.lda = h->ldN; g.B = h->We.p; g.ldb = h->lde;
-    g.M = 2 * nb; g.N = e; g.K = N;
+    g.M = 2 * nb; g.N = e; g.K = N + 1;
     RedP r{};
-    r.out = h->E; r.ld = h->lde; r.epi = RED_BIAS; r.bias = h->be.p;
+    r.out = h->E; r.ld = h->lde; r.epi = RED_ONES_COL;
     TRY(gemm_splitk(h, T_GEMM_ENC, T_RED_ENC, g, false, true, r));
   }
   return 0;
@@ -298,14 +299,14 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
   const float inv_bn = 1.0f / ((float)b_global * (float)N);
   if (nb > 0) {
     TRY(step_front(h, rows_dev, nb, 0));
-    {  // Delta = E.Wd + bd - inp, per-path sum of squares  (GANMF.py:66-68), batch z = path
+    {  // Delta = [E|1].Wd_ext - inp, per-path sum of squares  (GANMF.py:66-68), batch z = path
       GemmP g{};
       g.A = h->E; g.lda = h->lde; g.B = h->Wd.p; g.ldb = h->ldN;
-      g.C = h->Dl; g.ldc = h->ldN; g.M = nb; g.N = N; g.K = e;
+      g.C = h->Dl; g.ldc = h->ldN; g.M = nb; g.N = N; g.K = e + 1;
       g.nbatch = 2; g.a_batch_stride = (long long)nb * h->lde; g.c_batch_stride = (long long)nb * h->ldN;
       g.aux = h->XF; g.ldaux = h->ldN; g.aux_batch_stride = (long long)nb * h->ldN;
-      g.epi = EPI_BIAS_SUB_AUX_SQ; g.bias = h->bd.p; g.sq_partials = h->sqp;
-      Scope s(h, T_GEMM_DEC, 2 * gemm_flops(nb, N, e), gemm_bytes(2 * nb, N, e) + 4.0 * 2 * nb * N);
+      g.epi = EPI_SUB_AUX_SQ; g.sq_partials = h->sqp; g.zero_page = h->zero_page;
+      Scope s(h, T_GEMM_DEC, 2 * gemm_flops(nb, N, e + 1), gemm_bytes(2 * nb, N, e + 1) + 4.0 * 2 * nb * N);
       HIP_TRY(gemm_launch(h->st, g, false, true, h->tile_force));
       h->sqp_stride = g.tiles_m * g.tiles_n;
     }
@@ -327,13 +328,15 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
     TRY(allreduce(h, h->scal + S_SUM_REAL, 2));
   }
   {
-    Scope s(h, T_DCOEF, 0, 0);
-    hipLaunchKernelGGL(d_coef_kernel, dim3(1), dim3(256), 0, h->st, h->scal, h->sqp, h->sqp_stride, h->sqp_stride,
-                       dist ? 1 : 0, h->cfg.m, nb, inv_bn, h->rs, parts);
+    Scope s(h, T_DCOEF, 0, 8.0 * 2 * nb * e);
+    const long long total = (long long)2 * nb * (h->lde / 4);
+    const int grid = (int)std::max<long long>(1, std::min<long long>(128, (total + 1023) / 1024));
+    hipLaunchKernelGGL(d_coef_kernel, dim3(grid), dim3(256), 0, h->st, h->scal, h->sqp, h->sqp_stride,
+                       h->sqp_stride, dist ? 1 : 0, h->cfg.m, nb, inv_bn, h->E, h->Es, h->lde, h->rs, parts);
     HIP_TRY(hipGetLastError());
   }
   if (nb > 0) {
-    {  // dE = rs * (Delta . Wd^T)
+    {  // dE = rs * (Delta . Wd^T)          (bias row e of Wd_ext is not part of this product)
       GemmP g{};
       g.A = h->Dl; g.lda = h->ldN; g.B = h->Wd.p; g.ldb = h->ldN;
       g.M = 2 * nb; g.N = e; g.K = N;
@@ -341,27 +344,21 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
       r.out = h->dE; r.ld = h->lde; r.epi = RED_ROWSCALE; r.rowscale = h->rs;
       TRY(gemm_splitk(h, T_GEMM_DE, T_RED_DE, g, false, false, r));
     }
-    {  // gWd = (rs*E)^T . Delta
+    {  // gWd_ext = (rs*[E|1])^T . Delta   -> rows 0..e-1 = gWd, row e = gbd
       GemmP g{};
-      g.A = h->E; g.lda = h->lde; g.kscale = h->rs; g.B = h->Dl; g.ldb = h->ldN;
-      g.C = h->Wd.g; g.ldc = h->ldN; g.M = e; g.N = N; g.K = 2 * nb; g.epi = EPI_STORE;
-      Scope s(h, T_GEMM_GWD, gemm_flops(e, N, 2 * nb), gemm_bytes(e, N, 2 * nb));
+      g.A = h->Es; g.lda = h->lde; g.B = h->Dl; g.ldb = h->ldN;
+      g.C = h->Wd.g; g.ldc = h->ldN; g.M = e + 1; g.N = N; g.K = 2 * nb; g.epi = EPI_STORE;
+      g.zero_page = h->zero_page;
+      Scope s(h, T_GEMM_GWD, gemm_flops(e + 1, N, 2 * nb), gemm_bytes(e + 1, N, 2 * nb));
       HIP_TRY(gemm_launch(h->st, g, true, true, h->tile_force));
     }
-    {  // gWe = [X;F]^T . dE
+    {  // gWe_ext = [X;F | 1]^T . dE       -> rows 0..N-1 = gWe, row N = gbe
       GemmP g{};
       g.A = h->XF; g.lda = h->ldN; g.B = h->dE; g.ldb = h->lde;
-      g.C = h->We.g; g.ldc = h->lde; g.M = N; g.N = e; g.K = 2 * nb; g.epi = EPI_STORE;
-      Scope s(h, T_GEMM_GWE, gemm_flops(N, e, 2 * nb), gemm_bytes(N, e, 2 * nb));
+      g.C = h->We.g; g.ldc = h->lde; g.M = N + 1; g.N = e; g.K = 2 * nb; g.epi = EPI_STORE;
+      g.zero_page = h->zero_page;
+      Scope s(h, T_GEMM_GWE, gemm_flops(N + 1, e, 2 * nb), gemm_bytes(N + 1, e, 2 * nb));
       HIP_TRY(gemm_launch(h->st, g, true, true, h->tile_force));
-    }
-    {
-      Scope s(h, T_COLSUM, 0, 4.0 * 2 * nb * (N + e));
-      hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64), dim3(256), 0, h->st, h->Dl, h->ldN, 2 * nb, N, h->rs,
-                         h->bd.g);
-      hipLaunchKernelGGL(colsum_kernel, dim3((e + 63) / 64), dim3(256), 0, h->st, h->dE, h->lde, 2 * nb, e,
-                         (const float*)nullptr, h->be.g);
-      HIP_TRY(hipGetLastError());
     }
   } else {
     HIP_TRY(hipMemsetAsync(h->gD, 0, h->gD_elems * sizeof(float), h->st));
@@ -369,13 +366,11 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
   TRY(allreduce(h, h->gD, h->gD_elems));
   const bool reg = h->cfg.d_reg != 0.f;
   TRY(adam_dense(h, T_ADAM_D, h->We, h->We.g, S_ALPHA_D, h->cfg.d_reg, reg ? h->regp : nullptr));
-  TRY(adam_dense(h, T_ADAM_D, h->be, h->be.g, S_ALPHA_D, h->cfg.d_reg, reg ? h->regp + ADAM_GRID : nullptr));
-  TRY(adam_dense(h, T_ADAM_D, h->Wd, h->Wd.g, S_ALPHA_D, h->cfg.d_reg, reg ? h->regp + 2 * ADAM_GRID : nullptr));
-  TRY(adam_dense(h, T_ADAM_D, h->bd, h->bd.g, S_ALPHA_D, h->cfg.d_reg, reg ? h->regp + 3 * ADAM_GRID : nullptr));
+  TRY(adam_dense(h, T_ADAM_D, h->Wd, h->Wd.g, S_ALPHA_D, h->cfg.d_reg, reg ? h->regp + ADAM_GRID : nullptr));
   if (reg) {
     MultiRed mr{};
-    mr.count = 4; mr.out = parts;
-    for (int i = 0; i < 4; ++i) mr.e[i] = {h->regp + i * ADAM_GRID, ADAM_GRID, 2, i ? 1 : 0};
+    mr.count = 2; mr.out = parts;
+    for (int i = 0; i < 2; ++i) mr.e[i] = {h->regp + i * ADAM_GRID, ADAM_GRID, 2, i ? 1 : 0};
     Scope s(h, T_MULTIRED, 0, 0);
     hipLaunchKernelGGL(multi_reduce_kernel, dim3(1), dim3(256), 0, h->st, mr);
     HIP_TRY(hipGetLastError());
@@ -391,13 +386,13 @@ int g_step(ganmf_handle* h, const int* rows_dev, int nb, int start, int b_global
   const float inv_bn = 1.0f / ((float)b_global * (float)N);
   if (nb > 0) {
     TRY(step_front(h, rows_dev, nb, 1));
-    {  // Delta_f = Ef.Wd + bd - F, sum of squares
+    {  // Delta_f = [Ef|1].Wd_ext - F, sum of squares
       GemmP g{};
       g.A = h->E + (size_t)nb * h->lde; g.lda = h->lde; g.B = h->Wd.p; g.ldb = h->ldN;
-      g.C = h->Dl; g.ldc = h->ldN; g.M = nb; g.N = N; g.K = e;
+      g.C = h->Dl; g.ldc = h->ldN; g.M = nb; g.N = N; g.K = e + 1;
       g.aux = h->XF + (size_t)nb * h->ldN; g.ldaux = h->ldN;
-      g.epi = EPI_BIAS_SUB_AUX_SQ; g.bias = h->bd.p; g.sq_partials = h->sqp;
-      Scope s(h, T_GEMM_DEC, gemm_flops(nb, N, e), gemm_bytes(nb, N, e) + 4.0 * nb * N);
+      g.epi = EPI_SUB_AUX_SQ; g.sq_partials = h->sqp; g.zero_page = h->zero_page;
+      Scope s(h, T_GEMM_DEC, gemm_flops(nb, N, e + 1), gemm_bytes(nb, N, e + 1) + 4.0 * nb * N);
       HIP_TRY(gemm_launch(h->st, g, false, true, h->tile_force));
       h->sqp_stride = g.tiles_m * g.tiles_n;
     }
@@ -418,7 +413,8 @@ int g_step(ganmf_handle* h, const int* rows_dev, int nb, int start, int b_global
       GemmP g{};
       g.A = h->dE; g.lda = h->lde; g.B = h->We.p; g.ldb = h->lde;
       g.C = h->dF; g.ldc = h->ldN; g.M = nb; g.N = N; g.K = e;
-      g.epi = EPI_SUB_ROWSCALED_AUX; g.rowscale = nullptr; g.rowscale_c = rsv; g.aux = h->Dl; g.ldaux = h->ldN;
+      g.epi = EPI_SUB_ROWSCALED_AUX; g.rowscale_c = rsv; g.aux = h->Dl; g.ldaux = h->ldN;
+      g.zero_page = h->zero_page;
       Scope s(h, T_GEMM_DF, gemm_flops(nb, N, e), gemm_bytes(nb, N, e) + 4.0 * nb * N);
       HIP_TRY(gemm_launch(h->st, g, false, false, h->tile_force));
     }
@@ -434,6 +430,7 @@ int g_step(ganmf_handle* h, const int* rows_dev, int nb, int start, int b_global
       GemmP g{};
       g.A = h->dF; g.lda = h->ldN; g.B = h->Ub; g.ldb = h->ldk;
       g.C = h->V.g; g.ldc = h->ldk; g.M = N; g.N = k; g.K = nb; g.epi = EPI_STORE;
+      g.zero_page = h->zero_page;
       Scope s(h, T_GEMM_GV, gemm_flops(N, k, nb), gemm_bytes(N, k, nb));
       HIP_TRY(gemm_launch(h->st, g, true, true, h->tile_force));
     }
@@ -445,12 +442,12 @@ int g_step(ganmf_handle* h, const int* rows_dev, int nb, int start, int b_global
   }
   TRY(allreduce(h, h->V.g, h->V.padded()));
   const bool reg = h->cfg.g_reg != 0.f;
-  TRY(adam_dense(h, T_ADAM_V, h->V, h->V.g, S_ALPHA_G, h->cfg.g_reg, reg ? h->regp + 5 * ADAM_GRID : nullptr));
+  TRY(adam_dense(h, T_ADAM_V, h->V, h->V.g, S_ALPHA_G, h->cfg.g_reg, reg ? h->regp + 3 * ADAM_GRID : nullptr));
   {
     Scope s(h, T_ADAM_U, 0, 24.0 * h->Ue.count());
     hipLaunchKernelGGL(adam_rows_kernel, dim3(ADAM_GRID), dim3(256), 0, h->st, h->Ue.p, h->Ue.m, h->Ue.v, h->gUb,
                        h->pos, start, nb, h->U, h->ldk, h->scal, S_ALPHA_G, h->cfg.g_reg,
-                       reg ? h->regp + 4 * ADAM_GRID : nullptr);
+                       reg ? h->regp + 2 * ADAM_GRID : nullptr);
     HIP_TRY(hipGetLastError());
   }
   {  // parts = {sum Delta_f^2, sum (Ef-Er)^2, sum U^2, sum V^2}
@@ -460,8 +457,8 @@ int g_step(ganmf_handle* h, const int* rows_dev, int nb, int start, int b_global
     mr.e[1] = {h->fmp, RED_GRID, 1, 0};
     mr.count = 2;
     if (reg) {
-      mr.e[2] = {h->regp + 4 * ADAM_GRID, ADAM_GRID, 2, 0};
-      mr.e[3] = {h->regp + 5 * ADAM_GRID, ADAM_GRID, 3, 0};
+      mr.e[2] = {h->regp + 2 * ADAM_GRID, ADAM_GRID, 2, 0};
+      mr.e[3] = {h->regp + 3 * ADAM_GRID, ADAM_GRID, 3, 0};
       mr.count = 4;
     }
     Scope s(h, T_MULTIRED, 0, 0);
@@ -529,37 +526,35 @@ int ganmf_create(const ganmf_cfg* cfg, ganmf_handle** out) {
   h->dev = cfg->device;
   h->U = (int)cfg->num_users; h->N = (int)cfg->num_items; h->k = cfg->num_factors; h->e = cfg->emb_dim;
   h->B = (int)std::min<int64_t>(cfg->batch_size, cfg->num_users);
-  h->ldN = round_up(h->N, 32); h->ldk = round_up(h->k, 32); h->lde = round_up(h->e, 32);
+  h->ldN = round_up(h->N + 1, LD_ALIGN); h->ldk = round_up(h->k + 1, LD_ALIGN); h->lde = round_up(h->e + 1, LD_ALIGN);
   h->split_wgs = env_int("GANMF_SPLIT_WGS", 512);
   h->tile_force = env_int("GANMF_TILE", 0);
   if (h->tile_force != 0 && h->tile_force != 64 && h->tile_force != 128) h->tile_force = 0;
   HIP_TRY(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
   const int U = h->U, N = h->N, k = h->k, e = h->e, B = h->B;
   // parameters; D gradients contiguous for a single all-reduce
-  TRY(alloc_tensor(h->We, N, e, false));
-  TRY(alloc_tensor(h->be, 1, e, false));
-  TRY(alloc_tensor(h->Wd, e, N, false));
-  TRY(alloc_tensor(h->bd, 1, N, false));
+  TRY(alloc_tensor(h->We, N + 1, e, false));   // We_ext: row N = encoder bias
+  TRY(alloc_tensor(h->Wd, e + 1, N, false));   // Wd_ext: row e = decoder bias
   TRY(alloc_tensor(h->Ue, U, k, false));
   TRY(alloc_tensor(h->V, N, k, true));
-  h->gD_elems = h->We.padded() + h->be.padded() + h->Wd.padded() + h->bd.padded();
+  h->gD_elems = h->We.padded() + h->Wd.padded();
   TRY(dalloc(&h->gD, h->gD_elems));
   h->We.g = h->gD;
-  h->be.g = h->We.g + h->We.padded();
-  h->Wd.g = h->be.g + h->be.padded();
-  h->bd.g = h->Wd.g + h->Wd.padded();
+  h->Wd.g = h->We.g + h->We.padded();
+  TRY(dalloc(&h->zero_page, 64));
   TRY(dalloc((float**)&h->perm, U));
   TRY(dalloc((float**)&h->pos, U));
   TRY(dalloc(&h->XF, (size_t)2 * B * h->ldN));
   TRY(dalloc(&h->Ub, (size_t)B * h->ldk));
   TRY(dalloc(&h->E, (size_t)2 * B * h->lde));
+  TRY(dalloc(&h->Es, (size_t)2 * B * h->lde));
   TRY(dalloc(&h->Dl, (size_t)2 * B * h->ldN));
   TRY(dalloc(&h->dE, (size_t)2 * B * h->lde));
   TRY(dalloc(&h->dF, (size_t)B * h->ldN));
   TRY(dalloc(&h->gUb, (size_t)B * h->ldk));
   size_t need = 0;
   for (int nb = 1; nb <= B; nb = (nb == B ? B + 1 : std::min(B, nb * 2))) {  // plan is monotone enough; take max
-    need = std::max(need, slab_need(h, 2 * nb, e, N, h->lde));
+    need = std::max(need, slab_need(h, 2 * nb, e, N + 1, h->lde));
     need = std::max(need, slab_need(h, nb, e, N, h->lde));
     need = std::max(need, slab_need(h, nb, k, N, h->ldk));
   }
@@ -569,7 +564,7 @@ int ganmf_create(const ganmf_cfg* cfg, ganmf_handle** out) {
   TRY(dalloc(&h->scal, S_COUNT));
   TRY(dalloc(&h->sqp, (size_t)2 * gemm_max_tiles(B, N) + 16));
   TRY(dalloc(&h->fmp, RED_GRID));
-  TRY(dalloc(&h->regp, (size_t)6 * ADAM_GRID));
+  TRY(dalloc(&h->regp, (size_t)4 * ADAM_GRID));
   const float pw[4] = {ADAM_B1, ADAM_B2, ADAM_B1, ADAM_B2};
   HIP_TRY(hipMemcpy(h->scal, pw, sizeof pw, hipMemcpyHostToDevice));
   HIP_TRY(hipDeviceSynchronize());
@@ -582,7 +577,7 @@ int ganmf_destroy(ganmf_handle* h) {
   hipSetDevice(h->dev);
   hipStreamSynchronize(h->st);
   if (h->has_comm) ncclCommDestroy(h->comm);
-  free_tensor(h->We, false); free_tensor(h->be, false); free_tensor(h->Wd, false); free_tensor(h->bd, false);
+  free_tensor(h->We, false); free_tensor(h->Wd, false); hipFree(h->zero_page); hipFree(h->Es);
   free_tensor(h->Ue, false); free_tensor(h->V, true);
   hipFree(h->gD); hipFree(h->indptr); hipFree(h->indices); hipFree(h->data); hipFree(h->perm); hipFree(h->pos);
   hipFree(h->XF); hipFree(h->Ub); hipFree(h->E); hipFree(h->Dl); hipFree(h->dE); hipFree(h->dF); hipFree(h->gUb);
@@ -638,34 +633,34 @@ int ganmf_set_urm_csr(ganmf_handle* h, const int64_t* indptr, const int32_t* ind
 }
 
 int ganmf_tensor_shape(ganmf_handle* h, int tensor_id, int64_t* rows, int64_t* cols) {
-  Tensor* t = h ? find_tensor(h, tensor_id) : nullptr;
-  if (!t) return fail(-1, "unknown tensor id %d", tensor_id);
-  if (rows) *rows = t->rows;
-  if (cols) *cols = t->cols;
+  View v;
+  if (!h || !find_view(h, tensor_id, &v)) return fail(-1, "unknown tensor id %d", tensor_id);
+  if (rows) *rows = v.rows;
+  if (cols) *cols = v.cols;
   return 0;
 }
 
 int ganmf_set_tensor(ganmf_handle* h, int tensor_id, int slot, const float* host, int64_t n) {
-  Tensor* t = h ? find_tensor(h, tensor_id) : nullptr;
-  if (!t || !host) return fail(-1, "ganmf_set_tensor: unknown tensor id %d", tensor_id);
-  float* d = slot_ptr(t, slot);
+  View v;
+  if (!h || !host || !find_view(h, tensor_id, &v)) return fail(-1, "ganmf_set_tensor: unknown tensor id %d", tensor_id);
+  float* d = slot_ptr(v.t, slot);
   if (!d) return fail(-1, "ganmf_set_tensor: bad slot %d", slot);
-  if (n != (int64_t)t->count()) return fail(-1, "ganmf_set_tensor: tensor %d has %lld elements, got %lld", tensor_id, (long long)t->count(), (long long)n);
+  if (n != (int64_t)v.rows * v.cols) return fail(-1, "ganmf_set_tensor: tensor %d has %lld elements, got %lld", tensor_id, (long long)v.rows * v.cols, (long long)n);
   HIP_TRY(hipSetDevice(h->dev));
   HIP_TRY(hipStreamSynchronize(h->st));
-  HIP_TRY(hipMemcpy2D(d, (size_t)t->ld * 4, host, (size_t)t->cols * 4, (size_t)t->cols * 4, t->rows, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy2D(d + (size_t)v.row0 * v.t->ld, (size_t)v.t->ld * 4, host, (size_t)v.cols * 4, (size_t)v.cols * 4, v.rows, hipMemcpyHostToDevice));
   return 0;
 }
 
 int ganmf_get_tensor(ganmf_handle* h, int tensor_id, int slot, float* host, int64_t n) {
-  Tensor* t = h ? find_tensor(h, tensor_id) : nullptr;
-  if (!t || !host) return fail(-1, "ganmf_get_tensor: unknown tensor id %d", tensor_id);
-  float* d = slot_ptr(t, slot);
+  View v;
+  if (!h || !host || !find_view(h, tensor_id, &v)) return fail(-1, "ganmf_get_tensor: unknown tensor id %d", tensor_id);
+  float* d = slot_ptr(v.t, slot);
   if (!d) return fail(-1, "ganmf_get_tensor: bad slot %d", slot);
-  if (n != (int64_t)t->count()) return fail(-1, "ganmf_get_tensor: tensor %d has %lld elements, got %lld", tensor_id, (long long)t->count(), (long long)n);
+  if (n != (int64_t)v.rows * v.cols) return fail(-1, "ganmf_get_tensor: tensor %d has %lld elements, got %lld", tensor_id, (long long)v.rows * v.cols, (long long)n);
   HIP_TRY(hipSetDevice(h->dev));
   HIP_TRY(hipStreamSynchronize(h->st));
-  HIP_TRY(hipMemcpy2D(host, (size_t)t->cols * 4, d, (size_t)t->ld * 4, (size_t)t->cols * 4, t->rows, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy2D(host, (size_t)v.cols * 4, d + (size_t)v.row0 * v.t->ld, (size_t)v.t->ld * 4, (size_t)v.cols * 4, v.rows, hipMemcpyDeviceToHost));
   return 0;
 }
 
@@ -777,7 +772,7 @@ static int scores_device(ganmf_handle* h, const int* ids_dev, int64_t n, int tra
                          int* ld_out) {
   Tensor& rowsT = transposed ? h->V : h->Ue;   // rows we gather
   Tensor& colsT = transposed ? h->Ue : h->V;   // the other factor
-  const int W = colsT.rows, ldw = round_up(W, 32);
+  const int W = colsT.rows, ldw = round_up(W, LD_ALIGN);
   const size_t need_rows = (size_t)n * h->ldk, need_out = (size_t)n * ldw;
   if (need_rows > h->sc_rows_cap) {
     if (h->sc_rows) hipFree(h->sc_rows);
@@ -793,7 +788,7 @@ static int scores_device(ganmf_handle* h, const int* ids_dev, int64_t n, int tra
   HIP_TRY(hipGetLastError());
   GemmP g{};
   g.A = h->sc_rows; g.lda = h->ldk; g.B = colsT.p; g.ldb = h->ldk;
-  g.C = h->sc_out; g.ldc = ldw; g.M = (int)n; g.N = W; g.K = h->k; g.epi = EPI_STORE;
+  g.C = h->sc_out; g.ldc = ldw; g.M = (int)n; g.N = W; g.K = h->k; g.epi = EPI_STORE; g.zero_page = h->zero_page;
   {
     Scope s(h, T_SCORE_GEMM, gemm_flops(n, W, h->k), gemm_bytes(n, W, h->k));
     HIP_TRY(gemm_launch(h->st, g, false, false, h->tile_force));
@@ -840,7 +835,7 @@ int ganmf_bench_scores(ganmf_handle* h, int64_t n, int transposed, int32_t iters
   Tensor& colsT = transposed ? h->Ue : h->V;
   GemmP g{};
   g.A = h->sc_rows; g.lda = h->ldk; g.B = colsT.p; g.ldb = h->ldk;
-  g.C = h->sc_out; g.ldc = ldw; g.M = (int)n; g.N = W; g.K = h->k; g.epi = EPI_STORE;
+  g.C = h->sc_out; g.ldc = ldw; g.M = (int)n; g.N = W; g.K = h->k; g.epi = EPI_STORE; g.zero_page = h->zero_page;
   hipEvent_t a, b;
   hipEventCreate(&a); hipEventCreate(&b);
   gemm_launch(h->st, g, false, false, h->tile_force);
@@ -860,7 +855,7 @@ int ganmf_bench_scores(ganmf_handle* h, int64_t n, int transposed, int32_t iters
 int ganmf_snapshot_best(ganmf_handle* h) {
   if (!h) return fail(-1, "null handle");
   HIP_TRY(hipSetDevice(h->dev));
-  for (Tensor* t : {&h->We, &h->be, &h->Wd, &h->bd, &h->Ue, &h->V})
+  for (Tensor* t : {&h->We, &h->Wd, &h->Ue, &h->V})
     HIP_TRY(hipMemcpyAsync(t->best, t->p, t->padded() * sizeof(float), hipMemcpyDeviceToDevice, h->st));
   HIP_TRY(hipStreamSynchronize(h->st));
   return 0;
@@ -869,7 +864,7 @@ int ganmf_snapshot_best(ganmf_handle* h) {
 int ganmf_restore_best(ganmf_handle* h) {
   if (!h) return fail(-1, "null handle");
   HIP_TRY(hipSetDevice(h->dev));
-  for (Tensor* t : {&h->We, &h->be, &h->Wd, &h->bd, &h->Ue, &h->V})
+  for (Tensor* t : {&h->We, &h->Wd, &h->Ue, &h->V})
     HIP_TRY(hipMemcpyAsync(t->p, t->best, t->padded() * sizeof(float), hipMemcpyDeviceToDevice, h->st));
   HIP_TRY(hipStreamSynchronize(h->st));
   return 0;
@@ -914,14 +909,15 @@ int ganmf_gemm_f32(int device, const float* A, const float* B, float* C, int64_t
   HIP_TRY(hipSetDevice(device));
   const int ar = a_kmajor ? K : M, ac = a_kmajor ? M : K;
   const int br = b_kmajor ? K : N, bc = b_kmajor ? N : K;
-  const int lda = round_up(ac, 32), ldb = round_up(bc, 32), ldc = round_up((int)N, 32);
-  float *dA = nullptr, *dB = nullptr, *dC = nullptr, *slab = nullptr;
+  const int lda = round_up(ac, LD_ALIGN), ldb = round_up(bc, LD_ALIGN), ldc = round_up((int)N, LD_ALIGN);
+  float *dA = nullptr, *dB = nullptr, *dC = nullptr, *slab = nullptr, *zp = nullptr;
+  TRY(dalloc(&zp, 64));
   TRY(dalloc(&dA, (size_t)ar * lda)); TRY(dalloc(&dB, (size_t)br * ldb)); TRY(dalloc(&dC, (size_t)M * ldc));
   HIP_TRY(hipMemcpy2D(dA, (size_t)lda * 4, A, (size_t)ac * 4, (size_t)ac * 4, ar, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy2D(dB, (size_t)ldb * 4, B, (size_t)bc * 4, (size_t)bc * 4, br, hipMemcpyHostToDevice));
   GemmP g{};
   g.A = dA; g.lda = lda; g.B = dB; g.ldb = ldb; g.C = dC; g.ldc = ldc;
-  g.M = (int)M; g.N = (int)N; g.K = (int)K; g.epi = EPI_STORE;
+  g.M = (int)M; g.N = (int)N; g.K = (int)K; g.epi = EPI_STORE; g.zero_page = zp;
   int ns = 1, kps = 0;
   if (nsplit > 1) {
     split_plan((int)K, nsplit, ns, kps);
@@ -958,7 +954,7 @@ int ganmf_gemm_f32(int device, const float* A, const float* B, float* C, int64_t
     hipEventDestroy(a); hipEventDestroy(b);
   }
   HIP_TRY(hipMemcpy2D(C, (size_t)N * 4, dC, (size_t)ldc * 4, (size_t)N * 4, M, hipMemcpyDeviceToHost));
-  hipFree(dA); hipFree(dB); hipFree(dC);
+  hipFree(dA); hipFree(dB); hipFree(dC); hipFree(zp);
   if (slab) hipFree(slab);
   return 0;
 }

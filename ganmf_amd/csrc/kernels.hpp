@@ -31,31 +31,43 @@ __device__ inline float block_sum_256(float v, float* red4) {
   return (red4[0] + red4[1]) + (red4[2] + red4[3]);
 }
 
-// Step prologue + CSR row expansion (replaces URM_train[uids].toarray(), GANMF.py:183-184):
-// block b zero-fills row b of X (pad columns included) and scatters the stored values of CSR
-// row rows[b].  Block 0 / thread 0 also opens the optimizer step: lr_t from the beta powers
-// (TF ApplyAdam), then advances the powers.
+// Step prologue + CSR row expansion (replaces URM_train[uids].toarray(), GANMF.py:183-184) +
+// embedding lookup (GANMF.py:82).  Block b:
+//   * zero-fills row b of X (pad columns included), scatters the stored values of CSR row rows[b]
+//     and sets the bias-folding ones column X[b, N] = 1 and F[b, N] = 1 (F = rows nb.. of XF);
+//   * copies row rows[b] of user_embeddings into Ub[b, :].
+// Block 0 / thread 0 also opens the optimizer step: lr_t from the beta powers (TF ApplyAdam),
+// then advances the powers.
 __global__ __launch_bounds__(256) void densify_rows_kernel(const long long* __restrict__ indptr,
                                                            const int* __restrict__ indices,
                                                            const float* __restrict__ data,
-                                                           const int* __restrict__ rows, float* __restrict__ X,
-                                                           int ldx, float* __restrict__ scal, int which,
-                                                           float lr) {
+                                                           const int* __restrict__ rows, int nb, int ncols,
+                                                           float* __restrict__ X, int ldx,
+                                                           const float* __restrict__ Uemb, int ldk,
+                                                           float* __restrict__ Ub, float* __restrict__ scal,
+                                                           int which, float lr) {
   const int b = blockIdx.x;
-  if (b == 0 && threadIdx.x == 0 && which >= 0) {
+  if (b == 0 && threadIdx.x == 0) {
     const int o = which ? S_B1P_G : S_B1P_D;
     const float b1p = scal[o], b2p = scal[o + 1];
     scal[which ? S_ALPHA_G : S_ALPHA_D] = lr * sqrtf(1.f - b2p) / (1.f - b1p);
     scal[o] = b1p * ADAM_B1;
     scal[o + 1] = b2p * ADAM_B2;
   }
+  const int r = rows[b];
   float4* xr = reinterpret_cast<float4*>(X + (size_t)b * ldx);
   for (int c = threadIdx.x; c < ldx / 4; c += blockDim.x) xr[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4* us = reinterpret_cast<const float4*>(Uemb + (size_t)r * ldk);
+  float4* ud = reinterpret_cast<float4*>(Ub + (size_t)b * ldk);
+  for (int c = threadIdx.x; c < ldk / 4; c += blockDim.x) ud[c] = us[c];
   __syncthreads();
-  const int r = rows[b];
   const long long s = indptr[r], e = indptr[r + 1];
   float* x = X + (size_t)b * ldx;
   for (long long j = s + threadIdx.x; j < e; j += blockDim.x) x[indices[j]] = data[j];
+  if (threadIdx.x == 0) {
+    x[ncols] = 1.0f;
+    X[(size_t)(nb + b) * ldx + ncols] = 1.0f;
+  }
 }
 
 // Opens an optimizer step without any rows (a data-parallel rank that ran out of rows).
@@ -83,21 +95,6 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
   }
 }
 
-// out[n] = sum_r rowscale[r] * in[r, n]      (bias gradients, reduce over the batch axis)
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ in, int ld, int R, int N,
-                                                     const float* __restrict__ rowscale,
-                                                     float* __restrict__ out) {
-  __shared__ float red[4][64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int g = threadIdx.x >> 6;
-  float s = 0.f;
-  if (c < N)
-    for (int r = g; r < R; r += 4) s += (rowscale ? rowscale[r] : 1.f) * in[(size_t)r * ld + c];
-  red[g][threadIdx.x & 63] = s;
-  __syncthreads();
-  if (g == 0 && c < N) out[c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-}
-
 // Several reproducible sums in ONE launch (one block, entries processed in order):
 //   dst[e.dst] (+)= sum_i e.p[i], i < e.n     -- accumulate=0 overwrites, 1 adds
 struct MultiRedEntry { const float* p; int n; int dst; int accumulate; };
@@ -115,14 +112,17 @@ __global__ __launch_bounds__(256) void multi_reduce_kernel(const MultiRed mr) {
   }
 }
 
-// Discriminator scalars (GANMF.py:131-132): Lr, Lf, hinge, per-row backward scale
+// Discriminator scalars (GANMF.py:131-132): Lr, Lf, hinge and the backward row scales
 // rs[r] = c_path * 2/(B*N) with c_real = 1 + m*[h>0], c_fake = -[h>0]; loss_parts[0] = Lr + max(0,h).
-// presummed = 0: the squared-error partials of the two paths are summed here (single GPU);
-// presummed = 1: scal[S_SUM_REAL/FAKE] already hold the all-reduced sums.
+// Every block recomputes the two sums from the partials in the same fixed order (identical result
+// in every block) and then scales its slice of the encodings: Es = rs (.) E, the A operand of the
+// decoder-gradient GEMM (its ones column becomes rs, which yields the decoder-bias gradient).
+// presummed = 1: scal[S_SUM_REAL/FAKE] already hold the all-reduced sums (data-parallel).
 __global__ __launch_bounds__(256) void d_coef_kernel(float* __restrict__ scal, const float* __restrict__ partials,
                                                      int np, int pstride, int presummed, float m, int b_local,
-                                                     float inv_bn /* 1/(B_global*N) */,
-                                                     float* __restrict__ rs, float* __restrict__ loss_parts) {
+                                                     float inv_bn /* 1/(B_global*N) */, const float* __restrict__ E,
+                                                     float* __restrict__ Es, int lde, float* __restrict__ rs,
+                                                     float* __restrict__ loss_parts) {
   __shared__ float red[4];
   __shared__ float sums[2];
   if (!presummed) {
@@ -142,10 +142,22 @@ __global__ __launch_bounds__(256) void d_coef_kernel(float* __restrict__ scal, c
   const bool on = h > 0.f;
   const float cr = (on ? 1.f + m : 1.f) * (2.f * inv_bn);
   const float cf = (on ? -1.f : 0.f) * (2.f * inv_bn);
-  for (int r = threadIdx.x; r < 2 * b_local; r += blockDim.x) rs[r] = r < b_local ? cr : cf;
-  if (threadIdx.x == 0) {
-    loss_parts[0] = Lr + fmaxf(0.f, h);
-    loss_parts[1] = on ? 1.f : 0.f;
+  const int c4 = lde / 4;
+  const long long total = (long long)2 * b_local * c4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / c4);
+    const float sc = r < b_local ? cr : cf;
+    float4 v = reinterpret_cast<const float4*>(E)[i];
+    v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+    reinterpret_cast<float4*>(Es)[i] = v;
+  }
+  if (blockIdx.x == 0) {
+    for (int r = threadIdx.x; r < 2 * b_local; r += blockDim.x) rs[r] = r < b_local ? cr : cf;
+    if (threadIdx.x == 0) {
+      loss_parts[0] = Lr + fmaxf(0.f, h);
+      loss_parts[1] = on ? 1.f : 0.f;
+    }
   }
 }
 
