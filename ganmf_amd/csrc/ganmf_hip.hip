@@ -70,7 +70,7 @@ int env_int(const char* name, int dflt) {
 }
 
 constexpr int ADAM_GRID = 1024;
-constexpr int RED_GRID = 256;
+constexpr int RED_GRID = GEMM_RED_GRID;
 
 struct Tensor {
   int rows = 0, cols = 0, ld = 0;
@@ -81,16 +81,16 @@ struct Tensor {
 
 // profiling: kernel classes
 enum Tag : int {
-  T_DENSIFY, T_GEMM_GEN, T_GEMM_ENC, T_RED_ENC, T_GEMM_DEC, T_DCOEF, T_GEMM_DE, T_RED_DE,
-  T_GEMM_GWD, T_GEMM_GWE, T_ADAM_D, T_GEMM_DF, T_GEMM_GUB, T_RED_GUB, T_GEMM_GV, T_ADAM_V,
-  T_ADAM_U, T_MULTIRED, T_ALLREDUCE, T_SCORE_GEMM, T_COUNT
+  T_DENSIFY, T_GEMM_GEN, T_RED_GEN, T_GEMM_ENC, T_RED_ENC, T_GEMM_DEC, T_RED_DEC, T_DCOEF, T_GEMM_DE, T_RED_DE,
+  T_GEMM_GWD, T_RED_GWD, T_GEMM_GWE, T_RED_GWE, T_ADAM_D, T_GEMM_DF, T_RED_DF, T_GEMM_GUB, T_RED_GUB, T_GEMM_GV,
+  T_RED_GV, T_ADAM_V, T_ADAM_U, T_MULTIRED, T_ALLREDUCE, T_SCORE_GEMM, T_RED_SCORE, T_COUNT
 };
 const char* const kTagName[T_COUNT] = {
-  "densify_rows+gather", "gemm_generator[B,k]x[N,k]^T", "gemm_encode[2B,N]x[N,e]", "reduce_encode",
-  "gemm_decode[2B,e]x[e,N]+mse", "d_coef+scale", "gemm_dE[2B,N]x[e,N]^T", "reduce_dE", "gemm_gWd[2B,e]^Tx[2B,N]",
-  "gemm_gWe[2B,N]^Tx[2B,e]", "adam_dense_D", "gemm_dF[B,e]x[N,e]^T", "gemm_gUb[B,N]x[N,k]",
-  "reduce_gUb", "gemm_gV[B,N]^Tx[B,k]", "adam_dense_V", "adam_rows_U", "multi_reduce", "rccl_allreduce",
-  "gemm_scores"};
+  "densify_rows+gather", "gemm_generator[B,k]x[N,k]^T", "reduce_generator", "gemm_encode[2B,N]x[N,e]",
+  "reduce_encode", "gemm_decode[2B,e]x[e,N]", "reduce_decode+mse", "d_coef+scale", "gemm_dE[2B,N]x[e,N]^T",
+  "reduce_dE", "gemm_gWd[2B,e]^Tx[2B,N]", "reduce_gWd", "gemm_gWe[2B,N]^Tx[2B,e]", "reduce_gWe", "adam_dense_D",
+  "gemm_dF[B,e]x[N,e]^T", "reduce_dF", "gemm_gUb[B,N]x[N,k]", "reduce_gUb", "gemm_gV[B,N]^Tx[B,k]", "reduce_gV",
+  "adam_dense_V", "adam_rows_U", "multi_reduce", "rccl_allreduce", "gemm_scores", "reduce_scores"};
 
 struct ProfRec { int tag; hipEvent_t a, b; double flops, bytes; };
 
@@ -133,9 +133,10 @@ struct ganmf_handle {
   // RCCL
   ncclComm_t comm = nullptr;
   bool has_comm = false;
-  // tuning knobs
-  int split_wgs = 512;
-  int tile_force = 0;
+  // tuning knobs (environment: GANMF_TILE, GANMF_RING, GANMF_NSPLIT; 0 = cost model decides)
+  GemmTune tune;
+  bool debug_plan = false;
+  std::vector<long long> seen_plans;
   // profiling
   bool prof = false;
   std::vector<ProfRec> recs;
@@ -206,21 +207,6 @@ float* slot_ptr(Tensor* t, int slot) {
   }
 }
 
-// split-K plan for a GEMM with `tiles` output tiles: aim at h->split_wgs workgroups, K slices >= 256
-void plan_split(const ganmf_handle* h, int M, int Nn, int K, int& tile, int& nsplit, int& kps) {
-  tile = h->tile_force ? h->tile_force : ((M >= 128 && Nn >= 128) ? 128 : 64);
-  const int tiles = ((M + tile - 1) / tile) * ((Nn + tile - 1) / tile);
-  int want = (h->split_wgs + tiles - 1) / tiles;
-  want = std::min(want, std::max(1, K / 256));
-  split_plan(K, want, nsplit, kps);
-}
-
-size_t slab_need(const ganmf_handle* h, int M, int Nn, int K, int ld) {
-  int tile, ns, kps;
-  plan_split(h, M, Nn, K, tile, ns, kps);
-  return (size_t)ns * M * ld;
-}
-
 inline double gemm_flops(double M, double N, double K) { return 2.0 * M * N * K; }
 inline double gemm_bytes(double M, double N, double K) { return 4.0 * (M * K + N * K + M * N); }
 
@@ -231,24 +217,64 @@ int allreduce(ganmf_handle* h, float* buf, size_t count) {
   return 0;
 }
 
-// split-K GEMM + reduce
-int gemm_splitk(ganmf_handle* h, int tag_gemm, int tag_red, GemmP& g, bool akm, bool bkm, RedP& r) {
-  int tile, ns, kps;
-  plan_split(h, g.M, g.N, g.K, tile, ns, kps);
-  g.nsplit = ns; g.k_per_split = kps;
-  g.C = h->slab; g.ldc = r.ld; g.c_split_stride = (long long)g.M * r.ld;
-  g.epi = EPI_STORE; g.zero_page = h->zero_page;
-  if ((size_t)ns * g.M * r.ld > h->slab_elems) return fail(-4, "internal: split-K slab too small");
-  {
-    Scope s(h, tag_gemm, gemm_flops(g.M, g.N, g.K), gemm_bytes(g.M, g.N, g.K));
-    HIP_TRY(gemm_launch(h->st, g, akm, bkm, tile));
+int ensure_slab(ganmf_handle* h, size_t elems) {
+  if (elems <= h->slab_elems) return 0;
+  HIP_TRY(hipStreamSynchronize(h->st));
+  if (h->slab) hipFree(h->slab);
+  h->slab = nullptr; h->slab_elems = 0;
+  const size_t want = elems + elems / 4 + 1024;
+  TRY(dalloc(&h->slab, want));
+  h->slab_elems = want;
+  return 0;
+}
+
+// One logical GEMM of the step: plan (tile / ring / split-K), launch, and when split the reduce
+// kernel that applies the epilogue.  *sq_count = partial sums per batch written to epi.sq_partials.
+int run_gemm(ganmf_handle* h, int tag_gemm, int tag_red, GemmP g, bool akm, bool bkm, int* sq_count = nullptr,
+             double extra_bytes = 0) {
+  if (g.nbatch < 1) g.nbatch = 1;
+  g.zero_page = h->zero_page;
+  const GemmPlan pl = gemm_plan(g.M, g.N, g.K, g.nbatch, g.epi.sq_partials != nullptr, h->tune);
+  if (pl.nsplit > 1) TRY(ensure_slab(h, gemm_slab_elems(pl, g.M, g.ldc, g.nbatch)));
+  if (sq_count) *sq_count = pl.sq_count;
+  if (h->debug_plan) {
+    const long long key = ((long long)tag_gemm << 48) ^ ((long long)g.M << 32) ^ ((long long)g.N << 16) ^ g.K;
+    if (std::find(h->seen_plans.begin(), h->seen_plans.end(), key) == h->seen_plans.end()) {
+      h->seen_plans.push_back(key);
+      fprintf(stderr, "[ganmf plan] %-28s M=%d N=%d K=%d batch=%d -> tile %d ring %d nsplit %d (kps %d) wgs %d est %.1f us\n",
+              kTagName[tag_gemm], g.M, g.N, g.K, g.nbatch, pl.tile, pl.ring, pl.nsplit, pl.kps,
+              pl.tiles_m * pl.tiles_n * pl.nsplit * g.nbatch, pl.est_us);
+    }
   }
-  r.part = h->slab; r.split_stride = g.c_split_stride; r.nsplit = ns; r.M = g.M; r.N = g.N;
+  if (!h->prof) {
+    HIP_TRY(gemm_run(h->st, g, akm, bkm, pl, h->slab, h->slab_elems));
+    return 0;
+  }
+  // profiled: bracket the GEMM and the reduce separately
+  GemmPlan p1 = pl;
+  const double fl = g.nbatch * gemm_flops(g.M, g.N, g.K), by = gemm_bytes((double)g.nbatch * g.M, g.N, g.K) + extra_bytes;
+  if (pl.nsplit == 1) {
+    Scope s(h, tag_gemm, fl, by);
+    HIP_TRY(gemm_run(h->st, g, akm, bkm, pl, h->slab, h->slab_elems));
+    return 0;
+  }
+  {  // GEMM part only: run with a store epilogue into the slab, then the reduce by hand
+    Scope s(h, tag_gemm, fl, by);
+    GemmP q = g;
+    q.tiles_m = pl.tiles_m; q.tiles_n = pl.tiles_n; q.nsplit = pl.nsplit; q.k_per_split = pl.kps;
+    q.C = h->slab; q.c_split_stride = (long long)g.nbatch * g.M * g.ldc; q.c_batch_stride = (long long)g.M * g.ldc;
+    hipError_t e;
+    if (pl.tile == 128) e = pl.ring == 3 ? gemm_launch_t<128, 128, 32, 3>(h->st, q, akm, bkm) : gemm_launch_t<128, 128, 32, 2>(h->st, q, akm, bkm);
+    else e = pl.ring == 3 ? gemm_launch_t<64, 64, 64, 3>(h->st, q, akm, bkm) : gemm_launch_t<64, 64, 64, 2>(h->st, q, akm, bkm);
+    HIP_TRY(e);
+  }
   {
-    Scope s(h, tag_red, 0, 4.0 * (ns + 1) * g.M * g.N);
-    const long long total = (long long)r.M * (r.N / 4 + 1);
-    const int grid = (int)std::min<long long>(RED_GRID, (total + 255) / 256);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(std::max(grid, 1)), dim3(256), 0, h->st, r);
+    Scope s(h, tag_red, 0, 4.0 * (pl.nsplit + 1) * g.nbatch * g.M * g.N);
+    RedP r{};
+    r.part = h->slab; r.nsplit = pl.nsplit; r.out = g.C; r.ld = g.ldc; r.M = g.M; r.N = g.N;
+    r.batch_stride = g.c_batch_stride; r.epi = g.epi; r.epi.sq_stride = pl.sq_count;
+    r.split_stride = (long long)g.nbatch * g.M * g.ldc;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(GEMM_RED_GRID, g.nbatch), dim3(256), 0, h->st, r);
     HIP_TRY(hipGetLastError());
   }
   return 0;
@@ -277,17 +303,14 @@ int step_front(ganmf_handle* h, const int* rows_dev, int nb, int which) {
     GemmP g{};
     g.A = h->Ub; g.lda = h->ldk; g.B = h->V.p; g.ldb = h->ldk;
     g.C = h->XF + (size_t)nb * h->ldN; g.ldc = h->ldN;
-    g.M = nb; g.N = N; g.K = k; g.epi = EPI_STORE; g.zero_page = h->zero_page;
-    Scope s(h, T_GEMM_GEN, gemm_flops(nb, N, k), gemm_bytes(nb, N, k));
-    HIP_TRY(gemm_launch(h->st, g, false, false, h->tile_force));
+    g.M = nb; g.N = N; g.K = k; g.epi.kind = EPI_STORE;
+    TRY(run_gemm(h, T_GEMM_GEN, T_RED_GEN, g, false, false));
   }
-  {  // E = [X;F | 1] . We_ext  (bias = row N), E[:, e] = 1      (GANMF.py:64-65)
+  {  // E = [X;F | 1] . We_ext  (bias = row N); the ones column E[:, e] is never overwritten  (GANMF.py:64-65)
     GemmP g{};
     g.A = h->XF; g.lda = h->ldN; g.B = h->We.p; g.ldb = h->lde;
-    g.M = 2 * nb; g.N = e; g.K = N + 1;
-    RedP r{};
-    r.out = h->E; r.ld = h->lde; r.epi = RED_ONES_COL;
-    TRY(gemm_splitk(h, T_GEMM_ENC, T_RED_ENC, g, false, true, r));
+    g.C = h->E; g.ldc = h->lde; g.M = 2 * nb; g.N = e; g.K = N + 1; g.epi.kind = EPI_STORE;
+    TRY(run_gemm(h, T_GEMM_ENC, T_RED_ENC, g, false, true));
   }
   return 0;
 }
@@ -297,6 +320,7 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
   const int N = h->N, e = h->e;
   const bool dist = h->has_comm;
   const float inv_bn = 1.0f / ((float)b_global * (float)N);
+  int sqn = 0;
   if (nb > 0) {
     TRY(step_front(h, rows_dev, nb, 0));
     {  // Delta = [E|1].Wd_ext - inp, per-path sum of squares  (GANMF.py:66-68), batch z = path
@@ -304,11 +328,9 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
       g.A = h->E; g.lda = h->lde; g.B = h->Wd.p; g.ldb = h->ldN;
       g.C = h->Dl; g.ldc = h->ldN; g.M = nb; g.N = N; g.K = e + 1;
       g.nbatch = 2; g.a_batch_stride = (long long)nb * h->lde; g.c_batch_stride = (long long)nb * h->ldN;
-      g.aux = h->XF; g.ldaux = h->ldN; g.aux_batch_stride = (long long)nb * h->ldN;
-      g.epi = EPI_SUB_AUX_SQ; g.sq_partials = h->sqp; g.zero_page = h->zero_page;
-      Scope s(h, T_GEMM_DEC, 2 * gemm_flops(nb, N, e + 1), gemm_bytes(2 * nb, N, e + 1) + 4.0 * 2 * nb * N);
-      HIP_TRY(gemm_launch(h->st, g, false, true, h->tile_force));
-      h->sqp_stride = g.tiles_m * g.tiles_n;
+      g.epi.kind = EPI_SUB_AUX_SQ; g.epi.aux = h->XF; g.epi.ldaux = h->ldN;
+      g.epi.aux_batch_stride = (long long)nb * h->ldN; g.epi.sq_partials = h->sqp;
+      TRY(run_gemm(h, T_GEMM_DEC, T_RED_DEC, g, false, true, &sqn, 4.0 * 2 * nb * N));
     }
   } else {
     // rank out of rows: still open the optimizer step and contribute zeros to the collectives
@@ -318,8 +340,8 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
   if (dist) {
     MultiRed mr{};
     mr.count = 2; mr.out = h->scal;
-    mr.e[0] = {h->sqp, nb > 0 ? h->sqp_stride : 0, S_SUM_REAL, 0};
-    mr.e[1] = {h->sqp + h->sqp_stride, nb > 0 ? h->sqp_stride : 0, S_SUM_FAKE, 0};
+    mr.e[0] = {h->sqp, sqn, S_SUM_REAL, 0};
+    mr.e[1] = {h->sqp + sqn, sqn, S_SUM_FAKE, 0};
     {
       Scope s(h, T_MULTIRED, 0, 0);
       hipLaunchKernelGGL(multi_reduce_kernel, dim3(1), dim3(256), 0, h->st, mr);
@@ -331,34 +353,29 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
     Scope s(h, T_DCOEF, 0, 8.0 * 2 * nb * e);
     const long long total = (long long)2 * nb * (h->lde / 4);
     const int grid = (int)std::max<long long>(1, std::min<long long>(128, (total + 1023) / 1024));
-    hipLaunchKernelGGL(d_coef_kernel, dim3(grid), dim3(256), 0, h->st, h->scal, h->sqp, h->sqp_stride,
-                       h->sqp_stride, dist ? 1 : 0, h->cfg.m, nb, inv_bn, h->E, h->Es, h->lde, h->rs, parts);
+    hipLaunchKernelGGL(d_coef_kernel, dim3(grid), dim3(256), 0, h->st, h->scal, h->sqp, sqn, sqn,
+                       dist ? 1 : 0, h->cfg.m, nb, inv_bn, h->E, h->Es, h->lde, h->rs, parts);
     HIP_TRY(hipGetLastError());
   }
   if (nb > 0) {
     {  // dE = rs * (Delta . Wd^T)          (bias row e of Wd_ext is not part of this product)
       GemmP g{};
       g.A = h->Dl; g.lda = h->ldN; g.B = h->Wd.p; g.ldb = h->ldN;
-      g.M = 2 * nb; g.N = e; g.K = N;
-      RedP r{};
-      r.out = h->dE; r.ld = h->lde; r.epi = RED_ROWSCALE; r.rowscale = h->rs;
-      TRY(gemm_splitk(h, T_GEMM_DE, T_RED_DE, g, false, false, r));
+      g.C = h->dE; g.ldc = h->lde; g.M = 2 * nb; g.N = e; g.K = N;
+      g.epi.kind = EPI_ROWSCALE; g.epi.rowscale = h->rs;
+      TRY(run_gemm(h, T_GEMM_DE, T_RED_DE, g, false, false));
     }
     {  // gWd_ext = (rs*[E|1])^T . Delta   -> rows 0..e-1 = gWd, row e = gbd
       GemmP g{};
       g.A = h->Es; g.lda = h->lde; g.B = h->Dl; g.ldb = h->ldN;
-      g.C = h->Wd.g; g.ldc = h->ldN; g.M = e + 1; g.N = N; g.K = 2 * nb; g.epi = EPI_STORE;
-      g.zero_page = h->zero_page;
-      Scope s(h, T_GEMM_GWD, gemm_flops(e + 1, N, 2 * nb), gemm_bytes(e + 1, N, 2 * nb));
-      HIP_TRY(gemm_launch(h->st, g, true, true, h->tile_force));
+      g.C = h->Wd.g; g.ldc = h->ldN; g.M = e + 1; g.N = N; g.K = 2 * nb; g.epi.kind = EPI_STORE;
+      TRY(run_gemm(h, T_GEMM_GWD, T_RED_GWD, g, true, true));
     }
     {  // gWe_ext = [X;F | 1]^T . dE       -> rows 0..N-1 = gWe, row N = gbe
       GemmP g{};
       g.A = h->XF; g.lda = h->ldN; g.B = h->dE; g.ldb = h->lde;
-      g.C = h->We.g; g.ldc = h->lde; g.M = N + 1; g.N = e; g.K = 2 * nb; g.epi = EPI_STORE;
-      g.zero_page = h->zero_page;
-      Scope s(h, T_GEMM_GWE, gemm_flops(N + 1, e, 2 * nb), gemm_bytes(N + 1, e, 2 * nb));
-      HIP_TRY(gemm_launch(h->st, g, true, true, h->tile_force));
+      g.C = h->We.g; g.ldc = h->lde; g.M = N + 1; g.N = e; g.K = 2 * nb; g.epi.kind = EPI_STORE;
+      TRY(run_gemm(h, T_GEMM_GWE, T_RED_GWE, g, true, true));
     }
   } else {
     HIP_TRY(hipMemsetAsync(h->gD, 0, h->gD_elems * sizeof(float), h->st));
@@ -384,17 +401,16 @@ int g_step(ganmf_handle* h, const int* rows_dev, int nb, int start, int b_global
   const int N = h->N, e = h->e, k = h->k;
   const float alpha = h->cfg.recon_coefficient;
   const float inv_bn = 1.0f / ((float)b_global * (float)N);
+  int sqn = 0, fmn = 0;
   if (nb > 0) {
     TRY(step_front(h, rows_dev, nb, 1));
     {  // Delta_f = [Ef|1].Wd_ext - F, sum of squares
       GemmP g{};
       g.A = h->E + (size_t)nb * h->lde; g.lda = h->lde; g.B = h->Wd.p; g.ldb = h->ldN;
       g.C = h->Dl; g.ldc = h->ldN; g.M = nb; g.N = N; g.K = e + 1;
-      g.aux = h->XF + (size_t)nb * h->ldN; g.ldaux = h->ldN;
-      g.epi = EPI_SUB_AUX_SQ; g.sq_partials = h->sqp; g.zero_page = h->zero_page;
-      Scope s(h, T_GEMM_DEC, gemm_flops(nb, N, e + 1), gemm_bytes(nb, N, e + 1) + 4.0 * nb * N);
-      HIP_TRY(gemm_launch(h->st, g, false, true, h->tile_force));
-      h->sqp_stride = g.tiles_m * g.tiles_n;
+      g.epi.kind = EPI_SUB_AUX_SQ; g.epi.aux = h->XF + (size_t)nb * h->ldN; g.epi.ldaux = h->ldN;
+      g.epi.sq_partials = h->sqp;
+      TRY(run_gemm(h, T_GEMM_DEC, T_RED_DEC, g, false, true, &sqn, 4.0 * nb * N));
     }
     // host constants: rsG = (1-alpha)*2/(B*N) ; cfm = alpha*2/(B*e)
     const float rsv = (1.0f - alpha) * (2.0f * inv_bn);
@@ -402,43 +418,34 @@ int g_step(ganmf_handle* h, const int* rows_dev, int nb, int start, int b_global
     {  // dE = rsG*(Delta_f . Wd^T) + cfm*(Ef - Er) ; FM partials
       GemmP g{};
       g.A = h->Dl; g.lda = h->ldN; g.B = h->Wd.p; g.ldb = h->ldN;
-      g.M = nb; g.N = e; g.K = N;
-      RedP r{};
-      r.out = h->dE; r.ld = h->lde; r.epi = RED_G_DE; r.rowscale = nullptr; r.rowscale_c = rsv;
-      r.er = h->E; r.ef = h->E + (size_t)nb * h->lde; r.cfm = cfm; r.sq_partials = h->fmp;
-      HIP_TRY(hipMemsetAsync(h->fmp, 0, RED_GRID * sizeof(float), h->st));
-      TRY(gemm_splitk(h, T_GEMM_DE, T_RED_DE, g, false, false, r));
+      g.C = h->dE; g.ldc = h->lde; g.M = nb; g.N = e; g.K = N;
+      g.epi.kind = EPI_G_DE; g.epi.c = rsv; g.epi.cfm = cfm;
+      g.epi.er = h->E; g.epi.ef = h->E + (size_t)nb * h->lde; g.epi.sq_partials = h->fmp;
+      TRY(run_gemm(h, T_GEMM_DE, T_RED_DE, g, false, false, &fmn));
     }
     {  // dF = dE . We^T - rsG*Delta_f      (MSE gradient reaches F through both arguments)
       GemmP g{};
       g.A = h->dE; g.lda = h->lde; g.B = h->We.p; g.ldb = h->lde;
       g.C = h->dF; g.ldc = h->ldN; g.M = nb; g.N = N; g.K = e;
-      g.epi = EPI_SUB_ROWSCALED_AUX; g.rowscale_c = rsv; g.aux = h->Dl; g.ldaux = h->ldN;
-      g.zero_page = h->zero_page;
-      Scope s(h, T_GEMM_DF, gemm_flops(nb, N, e), gemm_bytes(nb, N, e) + 4.0 * nb * N);
-      HIP_TRY(gemm_launch(h->st, g, false, false, h->tile_force));
+      g.epi.kind = EPI_SUB_SCALED_AUX; g.epi.c = rsv; g.epi.aux = h->Dl; g.epi.ldaux = h->ldN;
+      TRY(run_gemm(h, T_GEMM_DF, T_RED_DF, g, false, false, nullptr, 4.0 * nb * N));
     }
     {  // gUb = dF . V
       GemmP g{};
       g.A = h->dF; g.lda = h->ldN; g.B = h->V.p; g.ldb = h->ldk;
-      g.M = nb; g.N = k; g.K = N;
-      RedP r{};
-      r.out = h->gUb; r.ld = h->ldk; r.epi = RED_PLAIN;
-      TRY(gemm_splitk(h, T_GEMM_GUB, T_RED_GUB, g, false, true, r));
+      g.C = h->gUb; g.ldc = h->ldk; g.M = nb; g.N = k; g.K = N; g.epi.kind = EPI_STORE;
+      TRY(run_gemm(h, T_GEMM_GUB, T_RED_GUB, g, false, true));
     }
     {  // gV = dF^T . Ub
       GemmP g{};
       g.A = h->dF; g.lda = h->ldN; g.B = h->Ub; g.ldb = h->ldk;
-      g.C = h->V.g; g.ldc = h->ldk; g.M = N; g.N = k; g.K = nb; g.epi = EPI_STORE;
-      g.zero_page = h->zero_page;
-      Scope s(h, T_GEMM_GV, gemm_flops(N, k, nb), gemm_bytes(N, k, nb));
-      HIP_TRY(gemm_launch(h->st, g, true, true, h->tile_force));
+      g.C = h->V.g; g.ldc = h->ldk; g.M = N; g.N = k; g.K = nb; g.epi.kind = EPI_STORE;
+      TRY(run_gemm(h, T_GEMM_GV, T_RED_GV, g, true, true));
     }
   } else {
     hipLaunchKernelGGL(open_step_kernel, dim3(1), dim3(64), 0, h->st, h->scal, 1, h->cfg.g_lr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemsetAsync(h->V.g, 0, h->V.padded() * sizeof(float), h->st));
-    HIP_TRY(hipMemsetAsync(h->fmp, 0, RED_GRID * sizeof(float), h->st));
   }
   TRY(allreduce(h, h->V.g, h->V.padded()));
   const bool reg = h->cfg.g_reg != 0.f;
@@ -453,8 +460,8 @@ int g_step(ganmf_handle* h, const int* rows_dev, int nb, int start, int b_global
   {  // parts = {sum Delta_f^2, sum (Ef-Er)^2, sum U^2, sum V^2}
     MultiRed mr{};
     mr.out = parts;
-    mr.e[0] = {h->sqp, nb > 0 ? h->sqp_stride : 0, 0, 0};
-    mr.e[1] = {h->fmp, RED_GRID, 1, 0};
+    mr.e[0] = {h->sqp, sqn, 0, 0};
+    mr.e[1] = {h->fmp, fmn, 1, 0};
     mr.count = 2;
     if (reg) {
       mr.e[2] = {h->regp + 2 * ADAM_GRID, ADAM_GRID, 2, 0};
@@ -527,9 +534,12 @@ int ganmf_create(const ganmf_cfg* cfg, ganmf_handle** out) {
   h->U = (int)cfg->num_users; h->N = (int)cfg->num_items; h->k = cfg->num_factors; h->e = cfg->emb_dim;
   h->B = (int)std::min<int64_t>(cfg->batch_size, cfg->num_users);
   h->ldN = round_up(h->N + 1, LD_ALIGN); h->ldk = round_up(h->k + 1, LD_ALIGN); h->lde = round_up(h->e + 1, LD_ALIGN);
-  h->split_wgs = env_int("GANMF_SPLIT_WGS", 512);
-  h->tile_force = env_int("GANMF_TILE", 0);
-  if (h->tile_force != 0 && h->tile_force != 64 && h->tile_force != 128) h->tile_force = 0;
+  h->tune.tile = env_int("GANMF_TILE", 0);
+  if (h->tune.tile != 0 && h->tune.tile != 64 && h->tune.tile != 128) h->tune.tile = 0;
+  h->tune.ring = env_int("GANMF_RING", 0);
+  if (h->tune.ring != 0 && h->tune.ring != 2 && h->tune.ring != 3) h->tune.ring = 0;
+  h->tune.nsplit = std::max(0, env_int("GANMF_NSPLIT", 0));
+  h->debug_plan = env_int("GANMF_DEBUG_PLAN", 0) != 0;
   HIP_TRY(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
   const int U = h->U, N = h->N, k = h->k, e = h->e, B = h->B;
   // parameters; D gradients contiguous for a single all-reduce
@@ -552,17 +562,15 @@ int ganmf_create(const ganmf_cfg* cfg, ganmf_handle** out) {
   TRY(dalloc(&h->dE, (size_t)2 * B * h->lde));
   TRY(dalloc(&h->dF, (size_t)B * h->ldN));
   TRY(dalloc(&h->gUb, (size_t)B * h->ldk));
-  size_t need = 0;
-  for (int nb = 1; nb <= B; nb = (nb == B ? B + 1 : std::min(B, nb * 2))) {  // plan is monotone enough; take max
-    need = std::max(need, slab_need(h, 2 * nb, e, N + 1, h->lde));
-    need = std::max(need, slab_need(h, nb, e, N, h->lde));
-    need = std::max(need, slab_need(h, nb, k, N, h->ldk));
+  // bias-folding ones columns: XF[:, N] = 1 and E[:, e] = 1 for every row; epilogues never store there
+  {
+    std::vector<float> ones((size_t)2 * B, 1.0f);
+    HIP_TRY(hipMemcpy2D(h->XF + N, (size_t)h->ldN * 4, ones.data(), 4, 4, (size_t)2 * B, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy2D(h->E + e, (size_t)h->lde * 4, ones.data(), 4, 4, (size_t)2 * B, hipMemcpyHostToDevice));
   }
-  h->slab_elems = need + 1024;
-  TRY(dalloc(&h->slab, h->slab_elems));
   TRY(dalloc(&h->rs, (size_t)2 * B));
   TRY(dalloc(&h->scal, S_COUNT));
-  TRY(dalloc(&h->sqp, (size_t)2 * gemm_max_tiles(B, N) + 16));
+  TRY(dalloc(&h->sqp, (size_t)2 * std::max(GEMM_RED_GRID, ((B + 63) / 64) * ((N + 63) / 64)) + 16));
   TRY(dalloc(&h->fmp, RED_GRID));
   TRY(dalloc(&h->regp, (size_t)4 * ADAM_GRID));
   const float pw[4] = {ADAM_B1, ADAM_B2, ADAM_B1, ADAM_B2};
@@ -788,11 +796,8 @@ static int scores_device(ganmf_handle* h, const int* ids_dev, int64_t n, int tra
   HIP_TRY(hipGetLastError());
   GemmP g{};
   g.A = h->sc_rows; g.lda = h->ldk; g.B = colsT.p; g.ldb = h->ldk;
-  g.C = h->sc_out; g.ldc = ldw; g.M = (int)n; g.N = W; g.K = h->k; g.epi = EPI_STORE; g.zero_page = h->zero_page;
-  {
-    Scope s(h, T_SCORE_GEMM, gemm_flops(n, W, h->k), gemm_bytes(n, W, h->k));
-    HIP_TRY(gemm_launch(h->st, g, false, false, h->tile_force));
-  }
+  g.C = h->sc_out; g.ldc = ldw; g.M = (int)n; g.N = W; g.K = h->k; g.epi.kind = EPI_STORE;
+  TRY(run_gemm(h, T_SCORE_GEMM, T_RED_SCORE, g, false, false));
   *out_dev = h->sc_out; *width = W; *ld_out = ldw;
   return 0;
 }
@@ -835,12 +840,15 @@ int ganmf_bench_scores(ganmf_handle* h, int64_t n, int transposed, int32_t iters
   Tensor& colsT = transposed ? h->Ue : h->V;
   GemmP g{};
   g.A = h->sc_rows; g.lda = h->ldk; g.B = colsT.p; g.ldb = h->ldk;
-  g.C = h->sc_out; g.ldc = ldw; g.M = (int)n; g.N = W; g.K = h->k; g.epi = EPI_STORE; g.zero_page = h->zero_page;
+  g.C = h->sc_out; g.ldc = ldw; g.M = (int)n; g.N = W; g.K = h->k; g.epi.kind = EPI_STORE;
   hipEvent_t a, b;
   hipEventCreate(&a); hipEventCreate(&b);
-  gemm_launch(h->st, g, false, false, h->tile_force);
+  const bool was = h->prof;
+  h->prof = false;
+  run_gemm(h, T_SCORE_GEMM, T_RED_SCORE, g, false, false);
   hipEventRecord(a, h->st);
-  for (int i = 0; i < iters; ++i) gemm_launch(h->st, g, false, false, h->tile_force);
+  for (int i = 0; i < iters; ++i) run_gemm(h, T_SCORE_GEMM, T_RED_SCORE, g, false, false);
+  h->prof = was;
   hipEventRecord(b, h->st);
   hipError_t e = hipEventSynchronize(b);
   float ms = 0.f;
@@ -917,35 +925,22 @@ int ganmf_gemm_f32(int device, const float* A, const float* B, float* C, int64_t
   HIP_TRY(hipMemcpy2D(dB, (size_t)ldb * 4, B, (size_t)bc * 4, (size_t)bc * 4, br, hipMemcpyHostToDevice));
   GemmP g{};
   g.A = dA; g.lda = lda; g.B = dB; g.ldb = ldb; g.C = dC; g.ldc = ldc;
-  g.M = (int)M; g.N = (int)N; g.K = (int)K; g.epi = EPI_STORE; g.zero_page = zp;
-  int ns = 1, kps = 0;
-  if (nsplit > 1) {
-    split_plan((int)K, nsplit, ns, kps);
-    TRY(dalloc(&slab, (size_t)ns * M * ldc));
-  }
+  g.M = (int)M; g.N = (int)N; g.K = (int)K; g.nbatch = 1; g.epi.kind = EPI_STORE; g.zero_page = zp;
+  GemmTune tune;
+  tune.tile = tile; tune.nsplit = nsplit;
+  tune.ring = env_int("GANMF_RING", 0);
+  if (tune.ring != 0 && tune.ring != 2 && tune.ring != 3) tune.ring = 0;
+  const GemmPlan pl = gemm_plan(g.M, g.N, g.K, 1, false, tune);
+  const size_t slab_elems = gemm_slab_elems(pl, g.M, ldc, 1);
+  if (slab_elems) TRY(dalloc(&slab, slab_elems));
   hipStream_t st = nullptr;
-  auto run = [&]() -> hipError_t {
-    if (ns > 1) {
-      GemmP q = g;
-      q.nsplit = ns; q.k_per_split = kps; q.C = slab; q.c_split_stride = (long long)M * ldc;
-      hipError_t e = gemm_launch(st, q, a_kmajor, b_kmajor, tile);
-      if (e != hipSuccess) return e;
-      RedP r{};
-      r.part = slab; r.split_stride = q.c_split_stride; r.nsplit = ns; r.out = dC; r.ld = ldc; r.M = (int)M; r.N = (int)N;
-      r.epi = RED_PLAIN;
-      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(RED_GRID), dim3(256), 0, st, r);
-      return hipGetLastError();
-    }
-    GemmP q = g;
-    return gemm_launch(st, q, a_kmajor, b_kmajor, tile);
-  };
-  HIP_TRY(run());
+  HIP_TRY(gemm_run(st, g, a_kmajor, b_kmajor, pl, slab, slab_elems));
   HIP_TRY(hipDeviceSynchronize());
   if (iters > 1 || ms) {
     hipEvent_t a, b;
     hipEventCreate(&a); hipEventCreate(&b);
     hipEventRecord(a, st);
-    for (int i = 0; i < std::max(iters, 1); ++i) run();
+    for (int i = 0; i < std::max(iters, 1); ++i) gemm_run(st, g, a_kmajor, b_kmajor, pl, slab, slab_elems);
     hipEventRecord(b, st);
     hipEventSynchronize(b);
     float t = 0.f;

@@ -29,18 +29,62 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cmath>
+
 namespace ganmf {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int LD_ALIGN = 64;  // floats; every leading dimension is a multiple of this
 
+// Epilogue applied to the K-complete sum; shared by the GEMM kernel (nsplit == 1) and the
+// split-K reduce kernel (nsplit > 1), so every GEMM of the step can be split along K freely.
 enum GemmEpi : int {
-  EPI_STORE = 0,              // C = acc
-  EPI_STORE_ONES_COL = 1,     // C = acc, and C[m, N] = 1 (the bias-folding ones column)
-  EPI_SUB_AUX_SQ = 2,         // C = acc - aux[m,n];  per-block sum(C^2) -> sq_partials
-  EPI_SUB_ROWSCALED_AUX = 3,  // C = acc - rowscale * aux[m,n]
+  EPI_STORE = 0,           // C = acc
+  EPI_SUB_AUX_SQ = 1,      // C = acc - aux[m,n];            sum(C^2) -> sq_partials
+  EPI_SUB_SCALED_AUX = 2,  // C = acc - c * aux[m,n]
+  EPI_ROWSCALE = 3,        // C = rowscale[m] * acc
+  EPI_G_DE = 4,            // C = c * acc + cfm * (ef - er)[m,n];   sum((ef-er)^2) -> sq_partials
 };
+
+struct EpiD {
+  int kind;
+  const float* aux;        // [.., ldaux] (per batch: + bz * aux_batch_stride)
+  int ldaux;
+  long long aux_batch_stride;
+  const float* rowscale;   // [M]
+  float c;
+  const float* er;         // [M, ldc]
+  const float* ef;
+  float cfm;
+  float* sq_partials;      // [nbatch][sq_stride]
+  int sq_stride;
+};
+
+__device__ inline float epi_apply(const EpiD& e, float v, int row, int col, int ldc, const float* __restrict__ aux,
+                                  float& sq) {
+  switch (e.kind) {
+    case EPI_SUB_AUX_SQ:
+      v -= aux[(size_t)row * e.ldaux + col];
+      sq += v * v;
+      break;
+    case EPI_SUB_SCALED_AUX:
+      v -= e.c * aux[(size_t)row * e.ldaux + col];
+      break;
+    case EPI_ROWSCALE:
+      v *= e.rowscale[row];
+      break;
+    case EPI_G_DE: {
+      const float d = e.ef[(size_t)row * ldc + col] - e.er[(size_t)row * ldc + col];
+      v = e.c * v + e.cfm * d;
+      sq += d * d;
+      break;
+    }
+    default: break;
+  }
+  return v;
+}
 
 struct GemmP {
   const float* A;
@@ -49,16 +93,12 @@ struct GemmP {
   int lda, ldb, ldc;
   int M, N, K;
   const float* zero_page;  // >= 16 bytes of zeros in device memory
-  int nsplit;              // >= 1
+  int nsplit;              // >= 1; > 1: C is the slab, epilogue deferred to splitk_reduce_kernel
   int k_per_split;         // multiple of BK
   long long c_split_stride;
   int nbatch;              // >= 1; B is shared between batches
-  long long a_batch_stride, c_batch_stride, aux_batch_stride;
-  int epi;
-  const float* aux;
-  int ldaux;
-  float rowscale_c;
-  float* sq_partials;      // [nbatch][tiles_m * tiles_n]
+  long long a_batch_stride, c_batch_stride;
+  EpiD epi;
   int tiles_m, tiles_n;
 };
 
@@ -243,131 +283,179 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const GemmP p) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
-  // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-  float* __restrict__ C = p.C + (size_t)sp * p.c_split_stride + (size_t)bz * p.c_batch_stride;
-  const float* __restrict__ aux = p.aux ? p.aux + (size_t)bz * p.aux_batch_stride : nullptr;
-  const int epi = p.epi;
-  float sq = 0.f;
+  // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5),
+  // i.e. a lane owns a column.  Stored straight from registers that is one dword per lane per
+  // instruction (measured ~2 TB/s chip-wide on 15-90 MB outputs); instead the tile is staged
+  // through the now idle ring as a natural [BM][BN] image and written as whole rows, 16 B per lane.
+  float* __restrict__ ct = smem;
 #pragma unroll
   for (int a = 0; a < TM; ++a)
 #pragma unroll
-    for (int b = 0; b < TN; ++b) {
-      const int col = n0 + wc * WN + b * 32 + li;
-      const bool colok = col < p.N;
+    for (int b = 0; b < TN; ++b)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wr * WM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (row < p.M) {
-          if (colok) {
-            float v = acc[a][b][r];
-            if (epi == EPI_SUB_AUX_SQ) {
-              v -= aux[(size_t)row * p.ldaux + col];
-              sq += v * v;
-            } else if (epi == EPI_SUB_ROWSCALED_AUX) {
-              v -= p.rowscale_c * aux[(size_t)row * p.ldaux + col];
-            }
-            C[(size_t)row * p.ldc + col] = v;
-          } else if (epi == EPI_STORE_ONES_COL && col == p.N) {
-            C[(size_t)row * p.ldc + col] = 1.0f;
-          }
+      for (int r = 0; r < 16; ++r)
+        ct[(wr * WM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * BN + wc * WN + b * 32 + li] = acc[a][b][r];
+  __syncthreads();
+
+  float* __restrict__ C = p.C + (size_t)sp * p.c_split_stride + (size_t)bz * p.c_batch_stride;
+  const bool deferred = p.nsplit > 1;
+  const EpiD& e = p.epi;
+  const float* __restrict__ aux = e.aux ? e.aux + (size_t)bz * e.aux_batch_stride : nullptr;
+  float sq = 0.f;
+  constexpr int C4 = BN / 4, RPP = 256 / C4;
+  const int tc = tid % C4, tr = tid / C4;
+  const int col = n0 + tc * 4;
+#pragma unroll 4
+  for (int j = 0; j < BM / RPP; ++j) {
+    const int row_l = tr + j * RPP, row = m0 + row_l;
+    if (row < p.M && col < p.N) {
+      const float4 v = *reinterpret_cast<const float4*>(ct + row_l * BN + tc * 4);
+      float o[4] = {v.x, v.y, v.z, v.w};
+      if (col + 3 < p.N) {
+        if (!deferred) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) o[q] = epi_apply(e, o[q], row, col + q, p.ldc, aux, sq);
         }
+        *reinterpret_cast<float4*>(C + (size_t)row * p.ldc + col) = make_float4(o[0], o[1], o[2], o[3]);
+      } else {
+        for (int q = 0; q < 4 && col + q < p.N; ++q)
+          C[(size_t)row * p.ldc + col + q] = deferred ? o[q] : epi_apply(e, o[q], row, col + q, p.ldc, aux, sq);
       }
     }
-  if (epi == EPI_SUB_AUX_SQ) {
+  }
+  if (!deferred && e.sq_partials) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    __syncthreads();   // every wave is done reading the staged tile
     if (lane == 0) smem[wave] = sq;
     __syncthreads();
     if (tid == 0)
-      p.sq_partials[(size_t)bz * p.tiles_m * p.tiles_n + tn * p.tiles_m + tm] =
-          (smem[0] + smem[1]) + (smem[2] + smem[3]);
+      e.sq_partials[(size_t)bz * e.sq_stride + tn * p.tiles_m + tm] = (smem[0] + smem[1]) + (smem[2] + smem[3]);
   }
 }
 
-// Reduce split-K slabs.  out[m,n] = sum_s part[s][m,n], then one of:
-enum RedEpi : int {
-  RED_PLAIN = 0,
-  RED_ONES_COL = 1,  // plain, and out[m, N] = 1 (bias-folding ones column of the encodings)
-  RED_ROWSCALE = 2,  // * rowscale[m]
-  RED_G_DE = 3,      // rowscale_c*sum + cfm*(Ef - Er)[m,n]; per-block sum((Ef-Er)^2) -> sq_partials
-};
-
+// Reduce split-K slabs and apply the deferred epilogue: out[m,n] = epi(sum_s part[s][m,n]).
+// grid = (gx, nbatch); columns >= N are never written (ones / pad columns keep their values).
 struct RedP {
   const float* part;
   long long split_stride;
   int nsplit;
   float* out;
-  int ld;       // shared by part / out / er / ef
+  int ld;       // shared by part / out
   int M, N;
-  int epi;
-  const float* rowscale;  // [M] or nullptr -> rowscale_c
-  float rowscale_c;
-  const float* er;
-  const float* ef;
-  float cfm;              // alpha*2/(B_global*e)
-  float* sq_partials;     // [gridDim.x]
+  long long batch_stride;   // of part and out
+  EpiD epi;
 };
 
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const RedP p) {
-  const int n4 = p.N / 4 + 1;   // covers column N (the ones column) as well; ld >= N + 1 rounded to 64
+  const int bz = blockIdx.y;
+  const int n4 = (p.N + 3) >> 2;
   const long long total = (long long)p.M * n4;
+  const float* __restrict__ part = p.part + (size_t)bz * p.batch_stride;
+  float* __restrict__ out = p.out + (size_t)bz * p.batch_stride;
+  const EpiD& e = p.epi;
+  const float* __restrict__ aux = e.aux ? e.aux + (size_t)bz * e.aux_batch_stride : nullptr;
   float sq = 0.f;
-  const float cfm = p.cfm;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * blockDim.x) {
     const int m = (int)(idx / n4), c = (int)(idx % n4) * 4;
     const size_t off = (size_t)m * p.ld + c;
-    float4 s = *reinterpret_cast<const float4*>(p.part + off);
+    float4 s = *reinterpret_cast<const float4*>(part + off);
     for (int k = 1; k < p.nsplit; ++k) {
-      const float4 q = *reinterpret_cast<const float4*>(p.part + (size_t)k * p.split_stride + off);
+      const float4 q = *reinterpret_cast<const float4*>(part + (size_t)k * p.split_stride + off);
       s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
     }
     float o[4] = {s.x, s.y, s.z, s.w};
-    if (p.epi == RED_ROWSCALE) {
-      const float r = p.rowscale ? p.rowscale[m] : p.rowscale_c;
+    if (c + 3 < p.N) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) o[j] *= r;
-    } else if (p.epi == RED_G_DE) {
-      const float r = p.rowscale ? p.rowscale[m] : p.rowscale_c;
-      const float4 er = *reinterpret_cast<const float4*>(p.er + off);
-      const float4 ef = *reinterpret_cast<const float4*>(p.ef + off);
-      const float d[4] = {ef.x - er.x, ef.y - er.y, ef.z - er.z, ef.w - er.w};
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        o[j] = r * o[j] + cfm * d[j];
-        if (c + j < p.N) sq += d[j] * d[j];
-      }
+      for (int j = 0; j < 4; ++j) o[j] = epi_apply(e, o[j], m, c + j, p.ld, aux, sq);
+      *reinterpret_cast<float4*>(out + off) = make_float4(o[0], o[1], o[2], o[3]);
+    } else {
+      for (int j = 0; j < 4 && c + j < p.N; ++j) out[off + j] = epi_apply(e, o[j], m, c + j, p.ld, aux, sq);
     }
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (c + j >= p.N) o[j] = (p.epi == RED_ONES_COL && c + j == p.N) ? 1.f : 0.f;  // K-padding stays zero
-    *reinterpret_cast<float4*>(p.out + off) = make_float4(o[0], o[1], o[2], o[3]);
   }
-  if (p.epi == RED_G_DE) {
+  if (e.sq_partials) {
     __shared__ float red[4];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sq;
     __syncthreads();
-    if (threadIdx.x == 0) p.sq_partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (threadIdx.x == 0) e.sq_partials[(size_t)bz * e.sq_stride + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
   }
 }
 
-// ---- host-side launcher ---------------------------------------------------------------------
-// Tile configurations: {64x64, BK 64} for skinny problems, {128x128, BK 32} otherwise; both have
-// 32 KiB ring slots.  NS = 3 slots (96 KiB, one workgroup per CU, two K-tiles in flight).
+// ---- host side: plan (tile, ring depth, split-K) and launch ------------------------------------
+// Tile configurations: {128x128, BK 32} and {64x64, BK 64}; both have 32 KiB ring slots.
+// Ring depth 2 (64 KiB, two workgroups per CU) or 3 (96 KiB, one per CU).
 constexpr int GEMM_K_ALIGN = 64;   // split-K slices are multiples of this (>= every BK)
-constexpr int GEMM_NS = 3;
+constexpr int GEMM_CUS = 256;
+constexpr int GEMM_RED_GRID = 256;
 
-inline int gemm_pick_tile(int M, int N, int nsplit, int nbatch) {
-  const long long t128 = (long long)((M + 127) / 128) * ((N + 127) / 128) * nsplit * nbatch;
-  return t128 >= 192 ? 128 : 64;
+struct GemmPlan {
+  int tile = 128, ring = 2, nsplit = 1, kps = 0;
+  int tiles_m = 0, tiles_n = 0;
+  int sq_count = 0;          // sq partial entries per batch this plan produces
+  double est_us = 0;
+};
+
+struct GemmTune {            // overrides (0 = automatic), settable from the environment
+  int tile = 0, ring = 0, nsplit = 0;
+};
+
+inline void split_plan(int K, int want, int& nsplit, int& kps) {
+  int chunks = (K + GEMM_K_ALIGN - 1) / GEMM_K_ALIGN;
+  if (want < 1) want = 1;
+  if (want > chunks) want = chunks;
+  int cps = (chunks + want - 1) / want;
+  kps = cps * GEMM_K_ALIGN;
+  nsplit = (chunks + cps - 1) / cps;
+}
+
+// Cost model (cycles at ~2.1 GHz under fp32 MFMA load).  Every GEMM of the step is small
+// (<= 1.9 GFLOP, >= 12 us at the MFMA roof), so the plan is about filling 256 CUs evenly and
+// keeping each workgroup's serial K-walk short; split-K pays a slab round trip + one launch.
+inline GemmPlan gemm_plan(int M, int N, int K, int nbatch, bool wants_sq, const GemmTune& tune) {
+  GemmPlan best;
+  best.est_us = 1e30;
+  const int tiles[2] = {128, 64};
+  for (int ti = 0; ti < 2; ++ti) {
+    const int tile = tiles[ti];
+    if (tune.tile && tune.tile != tile) continue;
+    const int tm = (M + tile - 1) / tile, tn = (N + tile - 1) / tile;
+    const long long T = (long long)tm * tn * nbatch;
+    const int bk = tile == 128 ? 32 : 64;
+    // 64x64 tiles move 16 B/clk/CU through L2 -> LDS, above what L2/MALL sustains chip-wide
+    const double cyc_tile = tile == 128 ? 4096.0 : 2900.0;
+    const int max_split = std::max(1, (K + GEMM_K_ALIGN - 1) / GEMM_K_ALIGN);
+    for (int want = 1; want <= max_split; want = want < 4 ? want + 1 : want + (want + 3) / 4) {
+      if (tune.nsplit) want = std::min(tune.nsplit, max_split);   // forced: evaluate exactly this one
+      int ns, kps;
+      split_plan(K, want, ns, kps);
+      const long long wgs = T * ns;
+      const double k_tiles = std::ceil((double)std::min(kps, K) / bk);
+      const double per_wg = 5000.0 + k_tiles * cyc_tile;          // prologue + epilogue + K walk
+      const double rounds = std::ceil((double)wgs / GEMM_CUS);
+      double us = rounds * per_wg / 2100.0;
+      if (ns > 1) us += 2.5 + (double)(ns + 1) * M * N * nbatch * 4.0 / 3.0e6;   // launch + slab traffic at ~3 TB/s
+      if (us < best.est_us) {
+        best.est_us = us; best.tile = tile; best.nsplit = ns; best.kps = kps; best.tiles_m = tm; best.tiles_n = tn;
+      }
+      if (tune.nsplit) break;
+    }
+  }
+  const long long wgs = (long long)best.tiles_m * best.tiles_n * nbatch * best.nsplit;
+  best.ring = tune.ring ? tune.ring : (wgs > GEMM_CUS ? 2 : 3);
+  if (best.nsplit == 1) best.kps = ((K + GEMM_K_ALIGN - 1) / GEMM_K_ALIGN) * GEMM_K_ALIGN;
+  best.sq_count = wants_sq ? (best.nsplit > 1 ? GEMM_RED_GRID : best.tiles_m * best.tiles_n) : 0;
+  return best;
+}
+
+inline size_t gemm_slab_elems(const GemmPlan& pl, int M, int ldc, int nbatch) {
+  return pl.nsplit > 1 ? (size_t)pl.nsplit * nbatch * M * ldc : 0;
 }
 
 template <int BM, int BN, int BK, int NS>
-inline hipError_t gemm_launch_t(hipStream_t st, GemmP& p, bool akm, bool bkm) {
-  p.tiles_m = (p.M + BM - 1) / BM;
-  p.tiles_n = (p.N + BN - 1) / BN;
+inline hipError_t gemm_launch_t(hipStream_t st, const GemmP& p, bool akm, bool bkm) {
   const int grid = p.tiles_m * p.tiles_n * p.nsplit * p.nbatch;
   if (grid <= 0) return hipSuccess;
   if (!akm && !bkm) hipLaunchKernelGGL((gemm_f32_mfma<BM, BN, BK, NS, false, false>), dim3(grid), dim3(256), 0, st, p);
@@ -377,26 +465,31 @@ inline hipError_t gemm_launch_t(hipStream_t st, GemmP& p, bool akm, bool bkm) {
   return hipGetLastError();
 }
 
-inline hipError_t gemm_launch(hipStream_t st, GemmP& p, bool akm, bool bkm, int tile) {
-  if (p.nsplit < 1) p.nsplit = 1;
+// Logical GEMM: C[bz] = epi(op(A[bz]) . op(B)).  `p` carries the operands, shapes, batch strides
+// and the epilogue; C/ldc/c_batch_stride describe the FINAL output.  slab: workspace for split-K.
+inline hipError_t gemm_run(hipStream_t st, GemmP p, bool akm, bool bkm, const GemmPlan& pl, float* slab,
+                           size_t slab_elems, hipStream_t* /*unused*/ = nullptr) {
   if (p.nbatch < 1) p.nbatch = 1;
-  if (p.nsplit == 1) p.k_per_split = ((p.K + GEMM_K_ALIGN - 1) / GEMM_K_ALIGN) * GEMM_K_ALIGN;
   if (!p.zero_page || (p.lda % LD_ALIGN) || (p.ldb % LD_ALIGN)) return hipErrorInvalidValue;
-  if (tile == 0) tile = gemm_pick_tile(p.M, p.N, p.nsplit, p.nbatch);
-  if (tile == 128) return gemm_launch_t<128, 128, 32, GEMM_NS>(st, p, akm, bkm);
-  return gemm_launch_t<64, 64, 64, GEMM_NS>(st, p, akm, bkm);
-}
-
-// number of tiles the partial buffer must hold for EPI_SUB_AUX_SQ (worst case tile = 64)
-inline int gemm_max_tiles(int M, int N) { return ((M + 63) / 64) * ((N + 63) / 64); }
-
-inline void split_plan(int K, int want, int& nsplit, int& kps) {
-  int chunks = (K + GEMM_K_ALIGN - 1) / GEMM_K_ALIGN;
-  if (want < 1) want = 1;
-  if (want > chunks) want = chunks;
-  int cps = (chunks + want - 1) / want;
-  kps = cps * GEMM_K_ALIGN;
-  nsplit = (chunks + cps - 1) / cps;
+  p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n;
+  p.nsplit = pl.nsplit; p.k_per_split = pl.kps;
+  p.epi.sq_stride = pl.sq_count;
+  RedP r{};
+  if (pl.nsplit > 1) {
+    if (gemm_slab_elems(pl, p.M, p.ldc, p.nbatch) > slab_elems) return hipErrorOutOfMemory;
+    r.part = slab; r.nsplit = pl.nsplit; r.out = p.C; r.ld = p.ldc; r.M = p.M; r.N = p.N;
+    r.batch_stride = p.c_batch_stride; r.epi = p.epi;
+    // slab layout [split][batch][M, ldc]
+    r.split_stride = (long long)p.nbatch * p.M * p.ldc;
+    if (p.nbatch > 1 && p.c_batch_stride != (long long)p.M * p.ldc) return hipErrorInvalidValue;
+    p.C = slab; p.c_split_stride = r.split_stride; p.c_batch_stride = (long long)p.M * p.ldc;
+  }
+  hipError_t e;
+  if (pl.tile == 128) e = pl.ring == 3 ? gemm_launch_t<128, 128, 32, 3>(st, p, akm, bkm) : gemm_launch_t<128, 128, 32, 2>(st, p, akm, bkm);
+  else e = pl.ring == 3 ? gemm_launch_t<64, 64, 64, 3>(st, p, akm, bkm) : gemm_launch_t<64, 64, 64, 2>(st, p, akm, bkm);
+  if (e != hipSuccess || pl.nsplit == 1) return e;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(GEMM_RED_GRID, p.nbatch), dim3(256), 0, st, r);
+  return hipGetLastError();
 }
 
 }  // namespace ganmf
