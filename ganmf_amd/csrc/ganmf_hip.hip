@@ -100,6 +100,9 @@ struct ganmf_handle {
   ganmf_cfg cfg;
   int dev = 0;
   hipStream_t st = nullptr;
+  hipStream_t st2 = nullptr;             // side lane: independent kernels overlap the main lane
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_mid = nullptr;
+  bool overlap = true;
   int U = 0, N = 0, k = 0, e = 0, B = 0;
   int ldN = 0, ldk = 0, lde = 0;
   Tensor We, Wd, Ue, V;   // We = We_ext [N+1, e] (row N = encoder bias), Wd = Wd_ext [e+1, N] (row e = decoder bias)
@@ -119,6 +122,8 @@ struct ganmf_handle {
   float* zero_page = nullptr;
   float* slab = nullptr;
   size_t slab_elems = 0;
+  float* slab2 = nullptr;                // split-K workspace of the side lane
+  size_t slab2_elems = 0;
   float* rs = nullptr;
   float* scal = nullptr;
   float *sqp = nullptr;  // [2][max_tiles]
@@ -148,15 +153,17 @@ struct Scope {
   ganmf_handle* h;
   bool on;
   ProfRec r;
-  Scope(ganmf_handle* h_, int tag, double flops, double bytes) : h(h_), on(h_->prof) {
+  hipStream_t s;
+  Scope(ganmf_handle* h_, int tag, double flops, double bytes, hipStream_t st = nullptr)
+      : h(h_), on(h_->prof), s(st ? st : h_->st) {
     if (on) {
       r.tag = tag; r.flops = flops; r.bytes = bytes;
       hipEventCreate(&r.a); hipEventCreate(&r.b);
-      hipEventRecord(r.a, h->st);
+      hipEventRecord(r.a, s);
     }
   }
   ~Scope() {
-    if (on) { hipEventRecord(r.b, h->st); h->recs.push_back(r); }
+    if (on) { hipEventRecord(r.b, s); h->recs.push_back(r); }
   }
 };
 
@@ -217,25 +224,31 @@ int allreduce(ganmf_handle* h, float* buf, size_t count) {
   return 0;
 }
 
-int ensure_slab(ganmf_handle* h, size_t elems) {
-  if (elems <= h->slab_elems) return 0;
+int ensure_slab(ganmf_handle* h, size_t elems, int lane) {
+  float*& slab = lane ? h->slab2 : h->slab;
+  size_t& cap = lane ? h->slab2_elems : h->slab_elems;
+  if (elems <= cap) return 0;
   HIP_TRY(hipStreamSynchronize(h->st));
-  if (h->slab) hipFree(h->slab);
-  h->slab = nullptr; h->slab_elems = 0;
+  HIP_TRY(hipStreamSynchronize(h->st2));
+  if (slab) hipFree(slab);
+  slab = nullptr; cap = 0;
   const size_t want = elems + elems / 4 + 1024;
-  TRY(dalloc(&h->slab, want));
-  h->slab_elems = want;
+  TRY(dalloc(&slab, want));
+  cap = want;
   return 0;
 }
 
 // One logical GEMM of the step: plan (tile / ring / split-K), launch, and when split the reduce
 // kernel that applies the epilogue.  *sq_count = partial sums per batch written to epi.sq_partials.
 int run_gemm(ganmf_handle* h, int tag_gemm, int tag_red, GemmP g, bool akm, bool bkm, int* sq_count = nullptr,
-             double extra_bytes = 0) {
+             double extra_bytes = 0, int lane = 0) {
   if (g.nbatch < 1) g.nbatch = 1;
   g.zero_page = h->zero_page;
+  hipStream_t st = lane ? h->st2 : h->st;
   const GemmPlan pl = gemm_plan(g.M, g.N, g.K, g.nbatch, g.epi.sq_partials != nullptr, h->tune);
-  if (pl.nsplit > 1) TRY(ensure_slab(h, gemm_slab_elems(pl, g.M, g.ldc, g.nbatch)));
+  if (pl.nsplit > 1) TRY(ensure_slab(h, gemm_slab_elems(pl, g.M, g.ldc, g.nbatch), lane));
+  float* slab = lane ? h->slab2 : h->slab;
+  const size_t slab_elems = lane ? h->slab2_elems : h->slab_elems;
   if (sq_count) *sq_count = pl.sq_count;
   if (h->debug_plan) {
     const long long key = ((long long)tag_gemm << 48) ^ ((long long)g.M << 32) ^ ((long long)g.N << 16) ^ g.K;
@@ -247,43 +260,56 @@ int run_gemm(ganmf_handle* h, int tag_gemm, int tag_red, GemmP g, bool akm, bool
     }
   }
   if (!h->prof) {
-    HIP_TRY(gemm_run(h->st, g, akm, bkm, pl, h->slab, h->slab_elems));
+    HIP_TRY(gemm_run(st, g, akm, bkm, pl, slab, slab_elems));
     return 0;
   }
   // profiled: bracket the GEMM and the reduce separately
-  GemmPlan p1 = pl;
   const double fl = g.nbatch * gemm_flops(g.M, g.N, g.K), by = gemm_bytes((double)g.nbatch * g.M, g.N, g.K) + extra_bytes;
   if (pl.nsplit == 1) {
-    Scope s(h, tag_gemm, fl, by);
-    HIP_TRY(gemm_run(h->st, g, akm, bkm, pl, h->slab, h->slab_elems));
+    Scope s(h, tag_gemm, fl, by, st);
+    HIP_TRY(gemm_run(st, g, akm, bkm, pl, slab, slab_elems));
     return 0;
   }
   {  // GEMM part only: run with a store epilogue into the slab, then the reduce by hand
-    Scope s(h, tag_gemm, fl, by);
+    Scope s(h, tag_gemm, fl, by, st);
     GemmP q = g;
     q.tiles_m = pl.tiles_m; q.tiles_n = pl.tiles_n; q.nsplit = pl.nsplit; q.k_per_split = pl.kps;
-    q.C = h->slab; q.c_split_stride = (long long)g.nbatch * g.M * g.ldc; q.c_batch_stride = (long long)g.M * g.ldc;
+    q.C = slab; q.c_split_stride = (long long)g.nbatch * g.M * g.ldc; q.c_batch_stride = (long long)g.M * g.ldc;
     hipError_t e;
-    if (pl.tile == 128) e = pl.ring == 3 ? gemm_launch_t<128, 128, 32, 3>(h->st, q, akm, bkm) : gemm_launch_t<128, 128, 32, 2>(h->st, q, akm, bkm);
-    else e = pl.ring == 3 ? gemm_launch_t<64, 64, 64, 3>(h->st, q, akm, bkm) : gemm_launch_t<64, 64, 64, 2>(h->st, q, akm, bkm);
+    if (pl.tile == 128) e = pl.ring == 3 ? gemm_launch_t<128, 128, 32, 3>(st, q, akm, bkm) : gemm_launch_t<128, 128, 32, 2>(st, q, akm, bkm);
+    else e = pl.ring == 3 ? gemm_launch_t<64, 64, 64, 3>(st, q, akm, bkm) : gemm_launch_t<64, 64, 64, 2>(st, q, akm, bkm);
     HIP_TRY(e);
   }
   {
-    Scope s(h, tag_red, 0, 4.0 * (pl.nsplit + 1) * g.nbatch * g.M * g.N);
+    Scope s(h, tag_red, 0, 4.0 * (pl.nsplit + 1) * g.nbatch * g.M * g.N, st);
     RedP r{};
-    r.part = h->slab; r.nsplit = pl.nsplit; r.out = g.C; r.ld = g.ldc; r.M = g.M; r.N = g.N;
+    r.part = slab; r.nsplit = pl.nsplit; r.out = g.C; r.ld = g.ldc; r.M = g.M; r.N = g.N;
     r.batch_stride = g.c_batch_stride; r.epi = g.epi; r.epi.sq_stride = pl.sq_count;
     r.split_stride = (long long)g.nbatch * g.M * g.ldc;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(GEMM_RED_GRID, g.nbatch), dim3(256), 0, h->st, r);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(GEMM_RED_GRID, g.nbatch), dim3(256), 0, st, r);
     HIP_TRY(hipGetLastError());
   }
   return 0;
 }
 
-int adam_dense(ganmf_handle* h, int tag, Tensor& t, const float* g, int alpha_idx, float reg, float* sq) {
+// fork: the side lane starts after everything enqueued so far on the main lane
+int lane_fork(ganmf_handle* h) {
+  HIP_TRY(hipEventRecord(h->ev_fork, h->st));
+  HIP_TRY(hipStreamWaitEvent(h->st2, h->ev_fork, 0));
+  return 0;
+}
+// join: the main lane continues after everything enqueued so far on the side lane
+int lane_join(ganmf_handle* h) {
+  HIP_TRY(hipEventRecord(h->ev_join, h->st2));
+  HIP_TRY(hipStreamWaitEvent(h->st, h->ev_join, 0));
+  return 0;
+}
+
+int adam_dense(ganmf_handle* h, int tag, Tensor& t, const float* g, int alpha_idx, float reg, float* sq, int lane = 0) {
   const long long n4 = (long long)t.padded() / 4;
-  Scope s(h, tag, 0, 28.0 * t.count());
-  hipLaunchKernelGGL(adam_dense_kernel, dim3(ADAM_GRID), dim3(256), 0, h->st, t.p, t.m, t.v, g, n4, h->scal,
+  hipStream_t st = lane ? h->st2 : h->st;
+  Scope s(h, tag, 0, 28.0 * t.count(), st);
+  hipLaunchKernelGGL(adam_dense_kernel, dim3(ADAM_GRID), dim3(256), 0, st, t.p, t.m, t.v, g, n4, h->scal,
                      alpha_idx, reg, sq);
   HIP_TRY(hipGetLastError());
   return 0;
@@ -358,6 +384,18 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
     HIP_TRY(hipGetLastError());
   }
   if (nb > 0) {
+    // Two lanes: the decoder-gradient GEMM and its Adam update only need Delta and the scaled
+    // encodings, so they run beside dE -> gWe_ext -> Adam(We_ext); MFMA-bound and HBM-bound kernels
+    // overlap and the fixed prologue/epilogue phases of one kernel hide behind the other.
+    const bool two = h->overlap && !dist;
+    const bool regD = h->cfg.d_reg != 0.f;
+    if (two) TRY(lane_fork(h));
+    {  // gWd_ext = (rs*[E|1])^T . Delta   -> rows 0..e-1 = gWd, row e = gbd
+      GemmP g{};
+      g.A = h->Es; g.lda = h->lde; g.B = h->Dl; g.ldb = h->ldN;
+      g.C = h->Wd.g; g.ldc = h->ldN; g.M = e + 1; g.N = N; g.K = 2 * nb; g.epi.kind = EPI_STORE;
+      TRY(run_gemm(h, T_GEMM_GWD, T_RED_GWD, g, true, true, nullptr, 0, two ? 1 : 0));
+    }
     {  // dE = rs * (Delta . Wd^T)          (bias row e of Wd_ext is not part of this product)
       GemmP g{};
       g.A = h->Dl; g.lda = h->ldN; g.B = h->Wd.p; g.ldb = h->ldN;
@@ -365,11 +403,11 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
       g.epi.kind = EPI_ROWSCALE; g.epi.rowscale = h->rs;
       TRY(run_gemm(h, T_GEMM_DE, T_RED_DE, g, false, false));
     }
-    {  // gWd_ext = (rs*[E|1])^T . Delta   -> rows 0..e-1 = gWd, row e = gbd
-      GemmP g{};
-      g.A = h->Es; g.lda = h->lde; g.B = h->Dl; g.ldb = h->ldN;
-      g.C = h->Wd.g; g.ldc = h->ldN; g.M = e + 1; g.N = N; g.K = 2 * nb; g.epi.kind = EPI_STORE;
-      TRY(run_gemm(h, T_GEMM_GWD, T_RED_GWD, g, true, true));
+    if (two) {
+      // the dE product reads the OLD decoder weights: Adam(Wd_ext) on the side lane must wait for it
+      HIP_TRY(hipEventRecord(h->ev_mid, h->st));
+      HIP_TRY(hipStreamWaitEvent(h->st2, h->ev_mid, 0));
+      TRY(adam_dense(h, T_ADAM_D, h->Wd, h->Wd.g, S_ALPHA_D, h->cfg.d_reg, regD ? h->regp + ADAM_GRID : nullptr, 1));
     }
     {  // gWe_ext = [X;F | 1]^T . dE       -> rows 0..N-1 = gWe, row N = gbe
       GemmP g{};
@@ -377,13 +415,19 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
       g.C = h->We.g; g.ldc = h->lde; g.M = N + 1; g.N = e; g.K = 2 * nb; g.epi.kind = EPI_STORE;
       TRY(run_gemm(h, T_GEMM_GWE, T_RED_GWE, g, true, true));
     }
+    if (two) {
+      TRY(adam_dense(h, T_ADAM_D, h->We, h->We.g, S_ALPHA_D, h->cfg.d_reg, regD ? h->regp : nullptr));
+      TRY(lane_join(h));
+    }
   } else {
     HIP_TRY(hipMemsetAsync(h->gD, 0, h->gD_elems * sizeof(float), h->st));
   }
-  TRY(allreduce(h, h->gD, h->gD_elems));
   const bool reg = h->cfg.d_reg != 0.f;
-  TRY(adam_dense(h, T_ADAM_D, h->We, h->We.g, S_ALPHA_D, h->cfg.d_reg, reg ? h->regp : nullptr));
-  TRY(adam_dense(h, T_ADAM_D, h->Wd, h->Wd.g, S_ALPHA_D, h->cfg.d_reg, reg ? h->regp + ADAM_GRID : nullptr));
+  if (!(h->overlap && !dist) || nb == 0) {
+    TRY(allreduce(h, h->gD, h->gD_elems));
+    TRY(adam_dense(h, T_ADAM_D, h->We, h->We.g, S_ALPHA_D, h->cfg.d_reg, reg ? h->regp : nullptr));
+    TRY(adam_dense(h, T_ADAM_D, h->Wd, h->Wd.g, S_ALPHA_D, h->cfg.d_reg, reg ? h->regp + ADAM_GRID : nullptr));
+  }
   if (reg) {
     MultiRed mr{};
     mr.count = 2; mr.out = parts;
@@ -430,26 +474,38 @@ int g_step(ganmf_handle* h, const int* rows_dev, int nb, int start, int b_global
       g.epi.kind = EPI_SUB_SCALED_AUX; g.epi.c = rsv; g.epi.aux = h->Dl; g.epi.ldaux = h->ldN;
       TRY(run_gemm(h, T_GEMM_DF, T_RED_DF, g, false, false, nullptr, 4.0 * nb * N));
     }
+    const bool two = h->overlap && !h->has_comm;
+    const bool regG = h->cfg.g_reg != 0.f;
+    if (two) TRY(lane_fork(h));
+    {  // gV = dF^T . Ub      (side lane when overlapping)
+      GemmP g{};
+      g.A = h->dF; g.lda = h->ldN; g.B = h->Ub; g.ldb = h->ldk;
+      g.C = h->V.g; g.ldc = h->ldk; g.M = N; g.N = k; g.K = nb; g.epi.kind = EPI_STORE;
+      TRY(run_gemm(h, T_GEMM_GV, T_RED_GV, g, true, true, nullptr, 0, two ? 1 : 0));
+    }
     {  // gUb = dF . V
       GemmP g{};
       g.A = h->dF; g.lda = h->ldN; g.B = h->V.p; g.ldb = h->ldk;
       g.C = h->gUb; g.ldc = h->ldk; g.M = nb; g.N = k; g.K = N; g.epi.kind = EPI_STORE;
       TRY(run_gemm(h, T_GEMM_GUB, T_RED_GUB, g, false, true));
     }
-    {  // gV = dF^T . Ub
-      GemmP g{};
-      g.A = h->dF; g.lda = h->ldN; g.B = h->Ub; g.ldb = h->ldk;
-      g.C = h->V.g; g.ldc = h->ldk; g.M = N; g.N = k; g.K = nb; g.epi.kind = EPI_STORE;
-      TRY(run_gemm(h, T_GEMM_GV, T_RED_GV, g, true, true));
+    if (two) {
+      // gUb reads the OLD item embeddings: Adam(V) on the side lane waits for it
+      HIP_TRY(hipEventRecord(h->ev_mid, h->st));
+      HIP_TRY(hipStreamWaitEvent(h->st2, h->ev_mid, 0));
+      TRY(adam_dense(h, T_ADAM_V, h->V, h->V.g, S_ALPHA_G, h->cfg.g_reg, regG ? h->regp + 3 * ADAM_GRID : nullptr, 1));
     }
   } else {
     hipLaunchKernelGGL(open_step_kernel, dim3(1), dim3(64), 0, h->st, h->scal, 1, h->cfg.g_lr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemsetAsync(h->V.g, 0, h->V.padded() * sizeof(float), h->st));
   }
-  TRY(allreduce(h, h->V.g, h->V.padded()));
   const bool reg = h->cfg.g_reg != 0.f;
-  TRY(adam_dense(h, T_ADAM_V, h->V, h->V.g, S_ALPHA_G, h->cfg.g_reg, reg ? h->regp + 3 * ADAM_GRID : nullptr));
+  const bool overlapped = h->overlap && !h->has_comm && nb > 0;
+  if (!overlapped) {
+    TRY(allreduce(h, h->V.g, h->V.padded()));
+    TRY(adam_dense(h, T_ADAM_V, h->V, h->V.g, S_ALPHA_G, h->cfg.g_reg, reg ? h->regp + 3 * ADAM_GRID : nullptr));
+  }
   {
     Scope s(h, T_ADAM_U, 0, 24.0 * h->Ue.count());
     hipLaunchKernelGGL(adam_rows_kernel, dim3(ADAM_GRID), dim3(256), 0, h->st, h->Ue.p, h->Ue.m, h->Ue.v, h->gUb,
@@ -457,6 +513,7 @@ int g_step(ganmf_handle* h, const int* rows_dev, int nb, int start, int b_global
                        reg ? h->regp + 2 * ADAM_GRID : nullptr);
     HIP_TRY(hipGetLastError());
   }
+  if (overlapped) TRY(lane_join(h));
   {  // parts = {sum Delta_f^2, sum (Ef-Er)^2, sum U^2, sum V^2}
     MultiRed mr{};
     mr.out = parts;
@@ -541,6 +598,11 @@ int ganmf_create(const ganmf_cfg* cfg, ganmf_handle** out) {
   h->tune.nsplit = std::max(0, env_int("GANMF_NSPLIT", 0));
   h->debug_plan = env_int("GANMF_DEBUG_PLAN", 0) != 0;
   HIP_TRY(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
+  HIP_TRY(hipStreamCreateWithFlags(&h->st2, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&h->ev_mid, hipEventDisableTiming));
+  h->overlap = env_int("GANMF_OVERLAP", 0) != 0;
   const int U = h->U, N = h->N, k = h->k, e = h->e, B = h->B;
   // parameters; D gradients contiguous for a single all-reduce
   TRY(alloc_tensor(h->We, N + 1, e, false));   // We_ext: row N = encoder bias
@@ -592,7 +654,11 @@ int ganmf_destroy(ganmf_handle* h) {
   hipFree(h->slab); hipFree(h->rs); hipFree(h->scal); hipFree(h->sqp); hipFree(h->fmp);
   hipFree(h->regp); hipFree(h->d_parts); hipFree(h->g_parts); hipFree(h->sc_rows); hipFree(h->sc_out);
   for (auto& r : h->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+  hipStreamSynchronize(h->st2);
+  hipEventDestroy(h->ev_fork); hipEventDestroy(h->ev_join); hipEventDestroy(h->ev_mid);
+  hipStreamDestroy(h->st2);
   hipStreamDestroy(h->st);
+  hipFree(h->slab2);
   delete h;
   return 0;
 }

@@ -361,7 +361,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const RedP p) {
     const int m = (int)(idx / n4), c = (int)(idx % n4) * 4;
     const size_t off = (size_t)m * p.ld + c;
     float4 s = *reinterpret_cast<const float4*>(part + off);
-    for (int k = 1; k < p.nsplit; ++k) {
+#pragma unroll 8
+    for (int k = 1; k < p.nsplit; ++k) {   // independent loads: keep several slabs in flight
       const float4 q = *reinterpret_cast<const float4*>(part + (size_t)k * p.split_stride + off);
       s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
     }
@@ -389,7 +390,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const RedP p) {
 // Ring depth 2 (64 KiB, two workgroups per CU) or 3 (96 KiB, one per CU).
 constexpr int GEMM_K_ALIGN = 64;   // split-K slices are multiples of this (>= every BK)
 constexpr int GEMM_CUS = 256;
-constexpr int GEMM_RED_GRID = 256;
+constexpr int GEMM_RED_GRID = 512;
 
 struct GemmPlan {
   int tile = 128, ring = 2, nsplit = 1, kps = 0;
@@ -425,7 +426,7 @@ inline GemmPlan gemm_plan(int M, int N, int K, int nbatch, bool wants_sq, const 
     const long long T = (long long)tm * tn * nbatch;
     const int bk = tile == 128 ? 32 : 64;
     // 64x64 tiles move 16 B/clk/CU through L2 -> LDS, above what L2/MALL sustains chip-wide
-    const double cyc_tile = tile == 128 ? 4096.0 : 2900.0;
+    const double cyc_tile = tile == 128 ? 4800.0 : 2900.0;   // measured 2.4 / 1.25 us per K-tile
     const int max_split = std::max(1, (K + GEMM_K_ALIGN - 1) / GEMM_K_ALIGN);
     for (int want = 1; want <= max_split; want = want < 4 ? want + 1 : want + (want + 3) / 4) {
       if (tune.nsplit) want = std::min(tune.nsplit, max_split);   // forced: evaluate exactly this one
@@ -433,10 +434,10 @@ inline GemmPlan gemm_plan(int M, int N, int K, int nbatch, bool wants_sq, const 
       split_plan(K, want, ns, kps);
       const long long wgs = T * ns;
       const double k_tiles = std::ceil((double)std::min(kps, K) / bk);
-      const double per_wg = 5000.0 + k_tiles * cyc_tile;          // prologue + epilogue + K walk
+      const double per_wg = (tile == 128 ? 9000.0 : 6000.0) + k_tiles * cyc_tile;   // prologue + epilogue + K walk (K sweep, MI355X)
       const double rounds = std::ceil((double)wgs / GEMM_CUS);
       double us = rounds * per_wg / 2100.0;
-      if (ns > 1) us += 2.5 + (double)(ns + 1) * M * N * nbatch * 4.0 / 3.0e6;   // launch + slab traffic at ~3 TB/s
+      if (ns > 1) us += 3.0 + (double)(ns + 1) * M * N * nbatch * 4.0 / 3.0e6;   // launch + slab traffic at ~3 TB/s
       if (us < best.est_us) {
         best.est_us = us; best.tile = tile; best.nsplit = ns; best.kps = kps; best.tiles_m = tm; best.tiles_n = tn;
       }

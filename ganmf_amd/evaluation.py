@@ -133,7 +133,7 @@ class EvaluatorHoldout(object):
                 ratings = self.get_user_test_ratings(user)
                 user_rmse = rmse(scores_batch[bi], relevant, ratings)
                 recommended = rec_lists[bi]
-                is_relevant = np.in1d(recommended, relevant, assume_unique=True)
+                is_relevant = np.isin(recommended, relevant, assume_unique=True)
                 n_eval += 1
                 for c in self.cutoff_list:
                     r = results[c]

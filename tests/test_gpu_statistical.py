@@ -1,0 +1,36 @@
+"""Long-horizon parity: full training with the reference's tuned hyper-parameters on the
+reference's own MovieLens-1M split must land on the published accuracy
+(test_results/GANMF_user_1M/test_results.txt:1; SURVEY F12: a +-0.005 band on MAP@5 / NDCG@5 is
+the realistic acceptance criterion because TF's seeded Glorot init is not reproducible)."""
+import json
+import os
+import time
+
+import numpy as np
+import pytest
+import scipy.sparse as sps
+
+pytestmark = [pytest.mark.gpu, pytest.mark.slow]
+
+
+def test_ml1m_user_full_training_reaches_published_map(golden_dir):
+    from ganmf_amd.GANMF import GANMF
+    from ganmf_amd.evaluation import EvaluatorHoldout
+    kat = json.load(open(os.path.join(golden_dir, "statistical_kat_ml1m_user.json")))
+    train = sps.load_npz(os.path.join(golden_dir, "Movielens1M_URM_train.npz")).tocsr()
+    test = sps.load_npz(os.path.join(golden_dir, "Movielens1M_URM_test.npz")).tocsr()
+    np.random.seed(1337)                                  # RecSysExp.set_seed (RecSysExp.py:104-108)
+    model = GANMF(train, mode='user', seed=1337, is_experiment=True)
+    t0 = time.time()
+    ret = model.fit(validation_set=None, sample_every=None, validation_evaluator=None, **kat["best_params"])
+    train_s = time.time() - t0
+    assert ret == kat["best_params"]["epochs"] + 1
+    res, _ = EvaluatorHoldout(test, [5, 10, 20, 50]).evaluateRecommender(model)
+    pub = kat["published"]
+    steps = kat["best_params"]["epochs"] * 2 * -(-train.shape[0] // kat["best_params"]["batch_size"])
+    print("ML-1M GANMF-user: %d updates in %.2f s (%.0f steps/s); MAP@5 %.4f (published %.4f) NDCG@5 %.4f (%.4f)"
+          % (steps, train_s, steps / train_s, res[5]["MAP"], pub["5"]["MAP"], res[5]["NDCG"], pub["5"]["NDCG"]))
+    for metric in ("MAP", "NDCG", "PRECISION", "RECALL"):
+        assert abs(res[5][metric] - pub["5"][metric]) <= 0.005, (metric, res[5][metric], pub["5"][metric])
+    for c in ("10", "20", "50"):
+        assert abs(res[int(c)]["MAP"] - pub[c]["MAP"]) <= 0.005, (c, res[int(c)]["MAP"], pub[c]["MAP"])
