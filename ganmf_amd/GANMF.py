@@ -134,6 +134,12 @@ class GANMF(BaseRecommender):
                     recon_coefficient=recon_coefficient)
         self._init_weights()
 
+        return self._epoch_loop(epochs, d_steps, g_steps, allow_worse, freq, after, metrics, sample_every,
+                                validation_evaluator, validation_set)
+
+    def _epoch_loop(self, epochs, d_steps, g_steps, allow_worse, freq, after, metrics, sample_every,
+                    validation_evaluator, validation_set):
+        """The `while epoch` loop shared by GANMF and DisGANMF (GANMF.py:151-244, DisGANMF.py:152-244)."""
         self._stop_training = False
         if validation_evaluator is not None:
             early_stop = EarlyStoppingScheduler(self, evaluator=validation_evaluator, allow_worse=allow_worse,

@@ -83,14 +83,17 @@ struct Tensor {
 enum Tag : int {
   T_DENSIFY, T_GEMM_GEN, T_RED_GEN, T_GEMM_ENC, T_RED_ENC, T_GEMM_DEC, T_RED_DEC, T_DCOEF, T_GEMM_DE, T_RED_DE,
   T_GEMM_GWD, T_RED_GWD, T_GEMM_GWE, T_RED_GWE, T_ADAM_D, T_GEMM_DF, T_RED_DF, T_GEMM_GUB, T_RED_GUB, T_GEMM_GV,
-  T_RED_GV, T_ADAM_V, T_ADAM_U, T_MULTIRED, T_ALLREDUCE, T_SCORE_GEMM, T_RED_SCORE, T_COUNT
+  T_RED_GV, T_ADAM_V, T_ADAM_U, T_MULTIRED, T_ALLREDUCE, T_SCORE_GEMM, T_RED_SCORE, T_DIS_FWD, T_RED_DIS_FWD, T_DIS_HEAD,
+  T_DIS_GW, T_RED_DIS_GW, T_DIS_BWD, T_RED_DIS_BWD, T_COUNT
 };
 const char* const kTagName[T_COUNT] = {
   "densify_rows+gather", "gemm_generator[B,k]x[N,k]^T", "reduce_generator", "gemm_encode[2B,N]x[N,e]",
   "reduce_encode", "gemm_decode[2B,e]x[e,N]", "reduce_decode+mse", "d_coef+scale", "gemm_dE[2B,N]x[e,N]^T",
   "reduce_dE", "gemm_gWd[2B,e]^Tx[2B,N]", "reduce_gWd", "gemm_gWe[2B,N]^Tx[2B,e]", "reduce_gWe", "adam_dense_D",
   "gemm_dF[B,e]x[N,e]^T", "reduce_dF", "gemm_gUb[B,N]x[N,k]", "reduce_gUb", "gemm_gV[B,N]^Tx[B,k]", "reduce_gV",
-  "adam_dense_V", "adam_rows_U", "multi_reduce", "rccl_allreduce", "gemm_scores", "reduce_scores"};
+  "adam_dense_V", "adam_rows_U", "multi_reduce", "rccl_allreduce", "gemm_scores", "reduce_scores",
+  "gemm_dis_layer_fwd", "reduce_dis_layer_fwd", "dis_head", "gemm_dis_gW", "reduce_dis_gW", "gemm_dis_bwd",
+  "reduce_dis_bwd"};
 
 struct ProfRec { int tag; hipEvent_t a, b; double flops, bytes; };
 
@@ -105,6 +108,12 @@ struct ganmf_handle {
   bool overlap = true;
   int U = 0, N = 0, k = 0, e = 0, B = 0;
   int ldN = 0, ldk = 0, lde = 0;
+  // DisGANMF (model 1): hidden layers W_l_ext and the output unit; see the DisGANMF section below
+  int L = 0, act = 0;
+  std::vector<Tensor> Wl;   // l = 0: [N+2, e] rows 0..N-1 profile weights, row N bias, row N+1 the float(uid) weight; l > 0: [e+1, e]
+  Tensor Wo;                // [1, e+1]: output kernel (e) then output bias
+  std::vector<float*> Al;   // layer outputs [2B, lde] with the ones column at e
+  float *dz0 = nullptr, *dz1 = nullptr, *dlogit = nullptr, *lossrow = nullptr;
   Tensor We, Wd, Ue, V;   // We = We_ext [N+1, e] (row N = encoder bias), Wd = Wd_ext [e+1, N] (row e = decoder bias)
   float* gD = nullptr;  // contiguous [gWe_ext | gWd_ext] (one all-reduce)
   size_t gD_elems = 0;
@@ -189,19 +198,46 @@ void free_tensor(Tensor& t, bool grad_separate) {
   if (grad_separate) hipFree(t.g);
 }
 
-// A view of one reference variable inside the folded tensors: rows x cols at p + row0 * ld.
-struct View { Tensor* t; int row0, rows, cols; };
+// A reference variable as up to two row segments of a folded tensor.
+struct Seg { Tensor* t; int row0, col0, rows, cols, host_row0; };
+struct View { int rows, cols, nseg; Seg seg[2]; };
 
 bool find_view(ganmf_handle* h, int id, View* v) {
-  switch (id) {
-    case 0: *v = {&h->We, 0, h->N, h->e}; return true;      // autoencoder/encoding/kernel
-    case 1: *v = {&h->We, h->N, 1, h->e}; return true;      // autoencoder/encoding/bias  (row N of We_ext)
-    case 2: *v = {&h->Wd, 0, h->e, h->N}; return true;      // autoencoder/decoding/kernel
-    case 3: *v = {&h->Wd, h->e, 1, h->N}; return true;      // autoencoder/decoding/bias  (row e of Wd_ext)
-    case GANMF_T_USER_EMB: *v = {&h->Ue, 0, h->U, h->k}; return true;
-    case GANMF_T_ITEM_EMB: *v = {&h->V, 0, h->N, h->k}; return true;
-    default: return false;
+  auto one = [&](Tensor* t, int row0, int col0, int rows, int cols) {
+    v->rows = rows; v->cols = cols; v->nseg = 1; v->seg[0] = {t, row0, col0, rows, cols, 0};
+    return true;
+  };
+  if (id == GANMF_T_USER_EMB) return one(&h->Ue, 0, 0, h->U, h->k);
+  if (id == GANMF_T_ITEM_EMB) return one(&h->V, 0, 0, h->N, h->k);
+  if (h->cfg.model == GANMF_MODEL_GANMF) {
+    switch (id) {
+      case 0: return one(&h->We, 0, 0, h->N, h->e);      // autoencoder/encoding/kernel
+      case 1: return one(&h->We, h->N, 0, 1, h->e);      // autoencoder/encoding/bias  (row N of We_ext)
+      case 2: return one(&h->Wd, 0, 0, h->e, h->N);      // autoencoder/decoding/kernel
+      case 3: return one(&h->Wd, h->e, 0, 1, h->N);      // autoencoder/decoding/bias  (row e of Wd_ext)
+      default: return false;
+    }
   }
+  // DisGANMF: 2l layer_l/kernel, 2l+1 layer_l/bias, 2L D_output/kernel [e,1], 2L+1 D_output/bias [1]
+  if (id < 0 || id > 2 * h->L + 1) return false;
+  if (id == 2 * h->L) { v->rows = h->e; v->cols = 1; v->nseg = 1; v->seg[0] = {&h->Wo, 0, 0, 1, h->e, 0}; return true; }
+  if (id == 2 * h->L + 1) return one(&h->Wo, 0, h->e, 1, 1);
+  const int l = id / 2;
+  Tensor* t = &h->Wl[l];
+  if (id & 1) return one(t, l == 0 ? h->N : h->e, 0, 1, h->e);
+  if (l > 0) return one(t, 0, 0, h->e, h->e);
+  // layer_0/kernel is [N+1, e] in the reference with row 0 multiplying float(uid) (DisGANMF.py:59)
+  v->rows = h->N + 1; v->cols = h->e; v->nseg = 2;
+  v->seg[0] = {t, h->N + 1, 0, 1, h->e, 0};
+  v->seg[1] = {t, 0, 0, h->N, h->e, 1};
+  return true;
+}
+
+std::vector<Tensor*> all_tensors(ganmf_handle* h) {
+  std::vector<Tensor*> v = {&h->Ue, &h->V};
+  if (h->cfg.model == GANMF_MODEL_GANMF) { v.push_back(&h->We); v.push_back(&h->Wd); }
+  else { for (auto& t : h->Wl) v.push_back(&t); v.push_back(&h->Wo); }
+  return v;
 }
 
 float* slot_ptr(Tensor* t, int slot) {
@@ -322,7 +358,7 @@ int step_front(ganmf_handle* h, const int* rows_dev, int nb, int which) {
     Scope s(h, T_DENSIFY, 0, 4.0 * nb * (N + 2 * k));
     hipLaunchKernelGGL(densify_rows_kernel, dim3(nb), dim3(256), 0, h->st, h->indptr, h->indices, h->data,
                        rows_dev, nb, N, h->XF, h->ldN, h->Ue.p, h->ldk, h->Ub, h->scal, which,
-                       which ? h->cfg.g_lr : h->cfg.d_lr);
+                       which ? h->cfg.g_lr : h->cfg.d_lr, -1, 0);
     HIP_TRY(hipGetLastError());
   }
   {  // F = Ub . V^T  -> rows [nb, 2nb) of XF            (GANMF.py:83)
@@ -532,6 +568,196 @@ int g_step(ganmf_handle* h, const int* rows_dev, int nb, int start, int b_global
   return 0;
 }
 
+// =================================================================================================
+// DisGANMF (GANRec/DisGANMF.py:57-79,110-140): binary MLP discriminator on [float(uid) | profile].
+// Layer-0 input = XF with the ones column at N and float(uid) at column N+1; W_0_ext rows follow the
+// same order (profile rows, bias row, uid row), so the uid term is an exact fp32 rank-1 part of the
+// same GEMM.  Hidden outputs carry a ones column at e (bias folding as in GANMF).
+// =================================================================================================
+int dis_forward(ganmf_handle* h, const int* rows_dev, int nb, int which) {
+  const int N = h->N, k = h->k, e = h->e;
+  {
+    Scope s(h, T_DENSIFY, 0, 4.0 * nb * (N + 2 * k));
+    hipLaunchKernelGGL(densify_rows_kernel, dim3(nb), dim3(256), 0, h->st, h->indptr, h->indices, h->data,
+                       rows_dev, nb, N, h->XF, h->ldN, h->Ue.p, h->ldk, h->Ub, h->scal, which,
+                       which ? h->cfg.g_lr : h->cfg.d_lr, N + 1, (int)h->cfg.row_offset);
+    HIP_TRY(hipGetLastError());
+  }
+  {  // F = Ub . V^T   (DisGANMF.py:77-78)
+    GemmP g{};
+    g.A = h->Ub; g.lda = h->ldk; g.B = h->V.p; g.ldb = h->ldk;
+    g.C = h->XF + (size_t)nb * h->ldN; g.ldc = h->ldN;
+    g.M = nb; g.N = N; g.K = k; g.epi.kind = EPI_STORE;
+    TRY(run_gemm(h, T_GEMM_GEN, T_RED_GEN, g, false, false));
+  }
+  for (int l = 0; l < h->L; ++l) {  // a_l = act([a_{l-1} | 1 (| uid)] . W_l_ext)   (DisGANMF.py:60-62)
+    GemmP g{};
+    g.A = l == 0 ? h->XF : h->Al[l - 1]; g.lda = l == 0 ? h->ldN : h->lde;
+    g.B = h->Wl[l].p; g.ldb = h->lde;
+    g.C = h->Al[l]; g.ldc = h->lde; g.M = 2 * nb; g.N = e; g.K = l == 0 ? N + 2 : e + 1;
+    g.epi.kind = EPI_ACT; g.epi.act = h->act;
+    TRY(run_gemm(h, T_DIS_FWD, T_RED_DIS_FWD, g, false, true));
+  }
+  return 0;
+}
+
+// dz_{l-1} = (dz_l . W_l[0:e]^T) * act'(a_{l-1}) for rows [row0, row0+nrows); returns the dz_0 buffer
+int dis_backprop_hidden(ganmf_handle* h, int row0, int nrows, bool param_grads, float** dz0_out) {
+  const int N = h->N, e = h->e;
+  float* cur = h->dz0;   // dz_{L-1} was written here by dis_dz_top_kernel
+  float* nxt = h->dz1;
+  for (int l = h->L - 1; l >= 0; --l) {
+    if (param_grads) {  // gW_l_ext = [a_{l-1} | 1 (| uid)]^T . dz_l  (all 2B rows: row0 = 0)
+      GemmP g{};
+      g.A = l == 0 ? h->XF : h->Al[l - 1]; g.lda = l == 0 ? h->ldN : h->lde;
+      g.B = cur; g.ldb = h->lde;
+      g.C = h->Wl[l].g; g.ldc = h->lde; g.M = l == 0 ? N + 2 : e + 1; g.N = e; g.K = nrows;
+      g.epi.kind = EPI_STORE;
+      TRY(run_gemm(h, T_DIS_GW, T_RED_DIS_GW, g, true, true));
+    }
+    if (l > 0) {
+      GemmP g{};
+      g.A = cur + (size_t)row0 * h->lde; g.lda = h->lde; g.B = h->Wl[l].p; g.ldb = h->lde;
+      g.C = nxt + (size_t)row0 * h->lde; g.ldc = h->lde; g.M = nrows; g.N = e; g.K = e;
+      g.epi.kind = EPI_MUL_ACTGRAD; g.epi.act = h->act;
+      g.epi.aux = h->Al[l - 1] + (size_t)row0 * h->lde; g.epi.ldaux = h->lde;
+      TRY(run_gemm(h, T_DIS_BWD, T_RED_DIS_BWD, g, false, false));
+      std::swap(cur, nxt);
+    }
+  }
+  *dz0_out = cur;
+  return 0;
+}
+
+int dis_d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* parts) {
+  const int e = h->e;
+  const float inv_b = 1.0f / (float)b_global;
+  if (nb > 0) {
+    TRY(dis_forward(h, rows_dev, nb, 0));
+    float* feat = h->Al[h->L - 1];
+    {
+      Scope s(h, T_DIS_HEAD, 0, 4.0 * 2 * nb * e * 3);
+      hipLaunchKernelGGL(dis_head_kernel, dim3((2 * nb + 3) / 4), dim3(256), 0, h->st, feat, h->lde, e + 1,
+                         h->Wo.p, 0, 2 * nb, nb, inv_b, h->dlogit, h->lossrow);
+      hipLaunchKernelGGL(dis_dz_top_kernel, dim3((e + 1 + 63) / 64), dim3(256), 0, h->st, feat, h->lde, e,
+                         h->Wo.p, h->dlogit, 0, 2 * nb, 0, 0.f, h->act, h->dz0, h->Wo.g, (float*)nullptr);
+      HIP_TRY(hipGetLastError());
+    }
+    float* dz0;
+    TRY(dis_backprop_hidden(h, 0, 2 * nb, true, &dz0));
+  } else {
+    hipLaunchKernelGGL(open_step_kernel, dim3(1), dim3(64), 0, h->st, h->scal, 0, h->cfg.d_lr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemsetAsync(h->gD, 0, h->gD_elems * sizeof(float), h->st));
+    HIP_TRY(hipMemsetAsync(h->lossrow, 0, (size_t)2 * h->B * sizeof(float), h->st));
+  }
+  TRY(allreduce(h, h->gD, h->gD_elems));
+  const bool reg = h->cfg.d_reg != 0.f;
+  for (int l = 0; l < h->L; ++l)
+    TRY(adam_dense(h, T_ADAM_D, h->Wl[l], h->Wl[l].g, S_ALPHA_D, h->cfg.d_reg, reg ? h->regp + (4 + l) * ADAM_GRID : nullptr));
+  TRY(adam_dense(h, T_ADAM_D, h->Wo, h->Wo.g, S_ALPHA_D, h->cfg.d_reg, reg ? h->regp + (4 + h->L) * ADAM_GRID : nullptr));
+  {  // parts = {sum sce(real), sum sce(fake), sum theta_D^2}
+    MultiRed mr{};
+    mr.out = parts;
+    mr.e[0] = {h->lossrow, nb, 0, 0};
+    mr.e[1] = {h->lossrow + nb, nb, 1, 0};
+    mr.count = 2;
+    Scope s(h, T_MULTIRED, 0, 0);
+    hipLaunchKernelGGL(multi_reduce_kernel, dim3(1), dim3(256), 0, h->st, mr);
+    if (reg) {
+      for (int i = 0; i <= h->L; i += 6) {
+        MultiRed m2{};
+        m2.out = parts;
+        m2.count = std::min(6, h->L + 1 - i);
+        for (int j = 0; j < m2.count; ++j) m2.e[j] = {h->regp + (4 + i + j) * ADAM_GRID, ADAM_GRID, 2, (i + j) ? 1 : 0};
+        hipLaunchKernelGGL(multi_reduce_kernel, dim3(1), dim3(256), 0, h->st, m2);
+      }
+    }
+    HIP_TRY(hipGetLastError());
+  }
+  return 0;
+}
+
+int dis_g_step(ganmf_handle* h, const int* rows_dev, int nb, int start, int b_global, float* parts) {
+  const int N = h->N, e = h->e, k = h->k;
+  const float alpha = h->cfg.recon_coefficient;
+  const float inv_b = 1.0f / (float)b_global;
+  int fmn = 0;
+  if (nb > 0) {
+    TRY(dis_forward(h, rows_dev, nb, 1));
+    float* feat = h->Al[h->L - 1];
+    const float fmc = alpha * 2.0f / ((float)b_global * (float)e);
+    {  // generator loss = loss_fake + alpha * FM  (DisGANMF.py:135-136): generated rows only, label 0
+      Scope s(h, T_DIS_HEAD, 0, 4.0 * 2 * nb * e * 3);
+      hipLaunchKernelGGL(dis_head_kernel, dim3((nb + 3) / 4), dim3(256), 0, h->st, feat, h->lde, e + 1, h->Wo.p,
+                         nb, nb, nb, inv_b, h->dlogit, h->lossrow);
+      fmn = (e + 1 + 63) / 64;
+      hipLaunchKernelGGL(dis_dz_top_kernel, dim3(fmn), dim3(256), 0, h->st, feat, h->lde, e, h->Wo.p, h->dlogit,
+                         nb, nb, nb, fmc, h->act, h->dz0, (float*)nullptr, h->fmp);
+      HIP_TRY(hipGetLastError());
+    }
+    float* dz0;
+    TRY(dis_backprop_hidden(h, nb, nb, false, &dz0));
+    {  // dF = dz_0 . W_0[profile rows]^T     (the uid column of the input is dropped, DisGANMF.py:59)
+      GemmP g{};
+      g.A = dz0 + (size_t)nb * h->lde; g.lda = h->lde; g.B = h->Wl[0].p; g.ldb = h->lde;
+      g.C = h->dF; g.ldc = h->ldN; g.M = nb; g.N = N; g.K = e; g.epi.kind = EPI_STORE;
+      TRY(run_gemm(h, T_GEMM_DF, T_RED_DF, g, false, false));
+    }
+    {  // gUb = dF . V
+      GemmP g{};
+      g.A = h->dF; g.lda = h->ldN; g.B = h->V.p; g.ldb = h->ldk;
+      g.C = h->gUb; g.ldc = h->ldk; g.M = nb; g.N = k; g.K = N; g.epi.kind = EPI_STORE;
+      TRY(run_gemm(h, T_GEMM_GUB, T_RED_GUB, g, false, true));
+    }
+    {  // gV = dF^T . Ub
+      GemmP g{};
+      g.A = h->dF; g.lda = h->ldN; g.B = h->Ub; g.ldb = h->ldk;
+      g.C = h->V.g; g.ldc = h->ldk; g.M = N; g.N = k; g.K = nb; g.epi.kind = EPI_STORE;
+      TRY(run_gemm(h, T_GEMM_GV, T_RED_GV, g, true, true));
+    }
+  } else {
+    hipLaunchKernelGGL(open_step_kernel, dim3(1), dim3(64), 0, h->st, h->scal, 1, h->cfg.g_lr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemsetAsync(h->V.g, 0, h->V.padded() * sizeof(float), h->st));
+  }
+  TRY(allreduce(h, h->V.g, h->V.padded()));
+  const bool reg = h->cfg.g_reg != 0.f;
+  TRY(adam_dense(h, T_ADAM_V, h->V, h->V.g, S_ALPHA_G, h->cfg.g_reg, reg ? h->regp + 3 * ADAM_GRID : nullptr));
+  {
+    Scope s(h, T_ADAM_U, 0, 24.0 * h->Ue.count());
+    hipLaunchKernelGGL(adam_rows_kernel, dim3(ADAM_GRID), dim3(256), 0, h->st, h->Ue.p, h->Ue.m, h->Ue.v, h->gUb,
+                       h->pos, start, nb, h->U, h->ldk, h->scal, S_ALPHA_G, h->cfg.g_reg,
+                       reg ? h->regp + 2 * ADAM_GRID : nullptr);
+    HIP_TRY(hipGetLastError());
+  }
+  {  // parts = {sum sce(fake), sum (feat_f - feat_r)^2, sum U^2, sum V^2}
+    MultiRed mr{};
+    mr.out = parts;
+    mr.e[0] = {h->lossrow + nb, nb, 0, 0};
+    mr.e[1] = {h->fmp, fmn, 1, 0};
+    mr.count = 2;
+    if (reg) {
+      mr.e[2] = {h->regp + 2 * ADAM_GRID, ADAM_GRID, 2, 0};
+      mr.e[3] = {h->regp + 3 * ADAM_GRID, ADAM_GRID, 3, 0};
+      mr.count = 4;
+    }
+    Scope s(h, T_MULTIRED, 0, 0);
+    hipLaunchKernelGGL(multi_reduce_kernel, dim3(1), dim3(256), 0, h->st, mr);
+    HIP_TRY(hipGetLastError());
+  }
+  return 0;
+}
+
+// model dispatch
+int any_d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* parts) {
+  return h->cfg.model == GANMF_MODEL_GANMF ? d_step(h, rows_dev, nb, b_global, parts) : dis_d_step(h, rows_dev, nb, b_global, parts);
+}
+int any_g_step(ganmf_handle* h, const int* rows_dev, int nb, int start, int b_global, float* parts) {
+  return h->cfg.model == GANMF_MODEL_GANMF ? g_step(h, rows_dev, nb, start, b_global, parts)
+                                           : dis_g_step(h, rows_dev, nb, start, b_global, parts);
+}
+
 int ensure_parts(ganmf_handle* h, int64_t steps) {
   if (steps <= h->parts_cap) return 0;
   if (h->d_parts) hipFree(h->d_parts);
@@ -547,6 +773,19 @@ void finish_losses(const ganmf_handle* h, const std::vector<float>& dp, const st
                    const std::vector<int>& bglob, int64_t nd, int64_t ng, int64_t per_pass, float* d_losses,
                    float* g_losses) {
   const float alpha = h->cfg.recon_coefficient;
+  if (h->cfg.model == GANMF_MODEL_DISGANMF) {
+    for (int64_t i = 0; i < nd && d_losses; ++i) {
+      const float bg = (float)bglob[i % per_pass];
+      d_losses[i] = (dp[4 * i] / bg + dp[4 * i + 1] / bg) + h->cfg.d_reg * (dp[4 * i + 2] / 2.0f);
+    }
+    for (int64_t i = 0; i < ng && g_losses; ++i) {
+      const float bg = (float)bglob[i % per_pass];
+      float sv = gp[4 * i + 3];
+      if (h->has_comm && h->cfg.world_size > 1) sv /= (float)h->cfg.world_size;
+      g_losses[i] = (gp[4 * i] / bg + alpha * (gp[4 * i + 1] / (bg * (float)h->e))) + h->cfg.g_reg * ((gp[4 * i + 2] + sv) / 2.0f);
+    }
+    return;
+  }
   for (int64_t i = 0; i < nd && d_losses; ++i)
     d_losses[i] = dp[4 * i] + h->cfg.d_reg * (dp[4 * i + 2] / 2.0f);
   for (int64_t i = 0; i < ng && g_losses; ++i) {
@@ -576,7 +815,9 @@ int ganmf_device_count(void) {
 int ganmf_create(const ganmf_cfg* cfg, ganmf_handle** out) {
   if (!cfg || !out) return fail(-1, "ganmf_create: null argument");
   if (cfg->abi_version != GANMF_ABI_VERSION) return fail(-1, "ganmf_create: ABI version %d != %d", cfg->abi_version, GANMF_ABI_VERSION);
-  if (cfg->model != GANMF_MODEL_GANMF) return fail(-5, "ganmf_create: model %d has no device path yet", cfg->model);
+  if (cfg->model != GANMF_MODEL_GANMF && cfg->model != GANMF_MODEL_DISGANMF) return fail(-1, "ganmf_create: unknown model %d", cfg->model);
+  if (cfg->model == GANMF_MODEL_DISGANMF && (cfg->d_layers < 1 || cfg->d_layers > 16 || cfg->d_act < 0 || cfg->d_act > 3))
+    return fail(-1, "ganmf_create: DisGANMF needs 1 <= d_layers <= 16 and a known activation");
   if (cfg->num_users < 1 || cfg->num_items < 1 || cfg->num_factors < 1 || cfg->emb_dim < 1 || cfg->batch_size < 1)
     return fail(-1, "ganmf_create: non-positive dimension");
   if (cfg->num_users > (1LL << 30) || cfg->num_items > (1LL << 30)) return fail(-1, "ganmf_create: dimension too large");
@@ -590,7 +831,7 @@ int ganmf_create(const ganmf_cfg* cfg, ganmf_handle** out) {
   h->dev = cfg->device;
   h->U = (int)cfg->num_users; h->N = (int)cfg->num_items; h->k = cfg->num_factors; h->e = cfg->emb_dim;
   h->B = (int)std::min<int64_t>(cfg->batch_size, cfg->num_users);
-  h->ldN = round_up(h->N + 1, LD_ALIGN); h->ldk = round_up(h->k + 1, LD_ALIGN); h->lde = round_up(h->e + 1, LD_ALIGN);
+  h->ldN = round_up(h->N + 2, LD_ALIGN); h->ldk = round_up(h->k + 1, LD_ALIGN); h->lde = round_up(h->e + 1, LD_ALIGN);
   h->tune.tile = env_int("GANMF_TILE", 0);
   if (h->tune.tile != 0 && h->tune.tile != 64 && h->tune.tile != 128) h->tune.tile = 0;
   h->tune.ring = env_int("GANMF_RING", 0);
@@ -604,37 +845,68 @@ int ganmf_create(const ganmf_cfg* cfg, ganmf_handle** out) {
   HIP_TRY(hipEventCreateWithFlags(&h->ev_mid, hipEventDisableTiming));
   h->overlap = env_int("GANMF_OVERLAP", 0) != 0;
   const int U = h->U, N = h->N, k = h->k, e = h->e, B = h->B;
+  const bool dis = cfg->model == GANMF_MODEL_DISGANMF;
   // parameters; D gradients contiguous for a single all-reduce
-  TRY(alloc_tensor(h->We, N + 1, e, false));   // We_ext: row N = encoder bias
-  TRY(alloc_tensor(h->Wd, e + 1, N, false));   // Wd_ext: row e = decoder bias
   TRY(alloc_tensor(h->Ue, U, k, false));
   TRY(alloc_tensor(h->V, N, k, true));
-  h->gD_elems = h->We.padded() + h->Wd.padded();
-  TRY(dalloc(&h->gD, h->gD_elems));
-  h->We.g = h->gD;
-  h->Wd.g = h->We.g + h->We.padded();
+  if (!dis) {
+    TRY(alloc_tensor(h->We, N + 1, e, false));   // We_ext: row N = encoder bias
+    TRY(alloc_tensor(h->Wd, e + 1, N, false));   // Wd_ext: row e = decoder bias
+    h->Wd.ld = h->ldN;                           // shares the leading dimension of the [.., N] work buffers
+    hipFree(h->Wd.p); hipFree(h->Wd.m); hipFree(h->Wd.v); hipFree(h->Wd.best);
+    TRY(dalloc(&h->Wd.p, h->Wd.padded())); TRY(dalloc(&h->Wd.m, h->Wd.padded()));
+    TRY(dalloc(&h->Wd.v, h->Wd.padded())); TRY(dalloc(&h->Wd.best, h->Wd.padded()));
+    h->gD_elems = h->We.padded() + h->Wd.padded();
+    TRY(dalloc(&h->gD, h->gD_elems));
+    h->We.g = h->gD;
+    h->Wd.g = h->We.g + h->We.padded();
+  } else {
+    h->L = cfg->d_layers; h->act = cfg->d_act;
+    h->Wl.resize(h->L);
+    h->gD_elems = 0;
+    for (int l = 0; l < h->L; ++l) {
+      TRY(alloc_tensor(h->Wl[l], l == 0 ? N + 2 : e + 1, e, false));
+      h->gD_elems += h->Wl[l].padded();
+    }
+    TRY(alloc_tensor(h->Wo, 1, e + 1, false));
+    h->gD_elems += h->Wo.padded();
+    TRY(dalloc(&h->gD, h->gD_elems));
+    float* gp = h->gD;
+    for (int l = 0; l < h->L; ++l) { h->Wl[l].g = gp; gp += h->Wl[l].padded(); }
+    h->Wo.g = gp;
+  }
   TRY(dalloc(&h->zero_page, 64));
   TRY(dalloc((float**)&h->perm, U));
   TRY(dalloc((float**)&h->pos, U));
   TRY(dalloc(&h->XF, (size_t)2 * B * h->ldN));
   TRY(dalloc(&h->Ub, (size_t)B * h->ldk));
-  TRY(dalloc(&h->E, (size_t)2 * B * h->lde));
-  TRY(dalloc(&h->Es, (size_t)2 * B * h->lde));
-  TRY(dalloc(&h->Dl, (size_t)2 * B * h->ldN));
-  TRY(dalloc(&h->dE, (size_t)2 * B * h->lde));
   TRY(dalloc(&h->dF, (size_t)B * h->ldN));
   TRY(dalloc(&h->gUb, (size_t)B * h->ldk));
-  // bias-folding ones columns: XF[:, N] = 1 and E[:, e] = 1 for every row; epilogues never store there
-  {
-    std::vector<float> ones((size_t)2 * B, 1.0f);
-    HIP_TRY(hipMemcpy2D(h->XF + N, (size_t)h->ldN * 4, ones.data(), 4, 4, (size_t)2 * B, hipMemcpyHostToDevice));
+  // bias-folding ones columns: XF[:, N] = 1 (and E[:, e] = 1 / a_l[:, e] = 1) for every row; epilogues never store there
+  std::vector<float> ones((size_t)2 * B, 1.0f);
+  HIP_TRY(hipMemcpy2D(h->XF + N, (size_t)h->ldN * 4, ones.data(), 4, 4, (size_t)2 * B, hipMemcpyHostToDevice));
+  if (!dis) {
+    TRY(dalloc(&h->E, (size_t)2 * B * h->lde));
+    TRY(dalloc(&h->Es, (size_t)2 * B * h->lde));
+    TRY(dalloc(&h->Dl, (size_t)2 * B * h->ldN));
+    TRY(dalloc(&h->dE, (size_t)2 * B * h->lde));
     HIP_TRY(hipMemcpy2D(h->E + e, (size_t)h->lde * 4, ones.data(), 4, 4, (size_t)2 * B, hipMemcpyHostToDevice));
+  } else {
+    h->Al.resize(h->L, nullptr);
+    for (int l = 0; l < h->L; ++l) {
+      TRY(dalloc(&h->Al[l], (size_t)2 * B * h->lde));
+      HIP_TRY(hipMemcpy2D(h->Al[l] + e, (size_t)h->lde * 4, ones.data(), 4, 4, (size_t)2 * B, hipMemcpyHostToDevice));
+    }
+    TRY(dalloc(&h->dz0, (size_t)2 * B * h->lde));
+    TRY(dalloc(&h->dz1, (size_t)2 * B * h->lde));
+    TRY(dalloc(&h->dlogit, (size_t)2 * B));
+    TRY(dalloc(&h->lossrow, (size_t)2 * B));
   }
   TRY(dalloc(&h->rs, (size_t)2 * B));
   TRY(dalloc(&h->scal, S_COUNT));
   TRY(dalloc(&h->sqp, (size_t)2 * std::max(GEMM_RED_GRID, ((B + 63) / 64) * ((N + 63) / 64)) + 16));
-  TRY(dalloc(&h->fmp, RED_GRID));
-  TRY(dalloc(&h->regp, (size_t)4 * ADAM_GRID));
+  TRY(dalloc(&h->fmp, std::max(RED_GRID, (e + 64) / 64 + 1)));
+  TRY(dalloc(&h->regp, (size_t)(4 + 17 + 1) * ADAM_GRID));
   const float pw[4] = {ADAM_B1, ADAM_B2, ADAM_B1, ADAM_B2};
   HIP_TRY(hipMemcpy(h->scal, pw, sizeof pw, hipMemcpyHostToDevice));
   HIP_TRY(hipDeviceSynchronize());
@@ -648,6 +920,10 @@ int ganmf_destroy(ganmf_handle* h) {
   hipStreamSynchronize(h->st);
   if (h->has_comm) ncclCommDestroy(h->comm);
   free_tensor(h->We, false); free_tensor(h->Wd, false); hipFree(h->zero_page); hipFree(h->Es);
+  for (auto& t : h->Wl) free_tensor(t, false);
+  free_tensor(h->Wo, false);
+  for (float* a : h->Al) hipFree(a);
+  hipFree(h->dz0); hipFree(h->dz1); hipFree(h->dlogit); hipFree(h->lossrow);
   free_tensor(h->Ue, false); free_tensor(h->V, true);
   hipFree(h->gD); hipFree(h->indptr); hipFree(h->indices); hipFree(h->data); hipFree(h->perm); hipFree(h->pos);
   hipFree(h->XF); hipFree(h->Ub); hipFree(h->E); hipFree(h->Dl); hipFree(h->dE); hipFree(h->dF); hipFree(h->gUb);
@@ -714,28 +990,32 @@ int ganmf_tensor_shape(ganmf_handle* h, int tensor_id, int64_t* rows, int64_t* c
   return 0;
 }
 
-int ganmf_set_tensor(ganmf_handle* h, int tensor_id, int slot, const float* host, int64_t n) {
+static int copy_view(ganmf_handle* h, int tensor_id, int slot, float* host, int64_t n, bool to_device, const char* who) {
   View v;
-  if (!h || !host || !find_view(h, tensor_id, &v)) return fail(-1, "ganmf_set_tensor: unknown tensor id %d", tensor_id);
-  float* d = slot_ptr(v.t, slot);
-  if (!d) return fail(-1, "ganmf_set_tensor: bad slot %d", slot);
-  if (n != (int64_t)v.rows * v.cols) return fail(-1, "ganmf_set_tensor: tensor %d has %lld elements, got %lld", tensor_id, (long long)v.rows * v.cols, (long long)n);
+  if (!h || !host || !find_view(h, tensor_id, &v)) return fail(-1, "%s: unknown tensor id %d", who, tensor_id);
+  if (n != (int64_t)v.rows * v.cols) return fail(-1, "%s: tensor %d has %lld elements, got %lld", who, tensor_id, (long long)v.rows * v.cols, (long long)n);
   HIP_TRY(hipSetDevice(h->dev));
   HIP_TRY(hipStreamSynchronize(h->st));
-  HIP_TRY(hipMemcpy2D(d + (size_t)v.row0 * v.t->ld, (size_t)v.t->ld * 4, host, (size_t)v.cols * 4, (size_t)v.cols * 4, v.rows, hipMemcpyHostToDevice));
+  for (int i = 0; i < v.nseg; ++i) {
+    const Seg& sg = v.seg[i];
+    float* d = slot_ptr(sg.t, slot);
+    if (!d) return fail(-1, "%s: bad slot %d", who, slot);
+    d += (size_t)sg.row0 * sg.t->ld + sg.col0;
+    float* hp = host + (size_t)sg.host_row0 * v.cols;
+    // a [e,1] view stored as one row of e floats: host pitch is the segment's own width
+    const size_t hpitch = (size_t)sg.cols * 4, dpitch = (size_t)sg.t->ld * 4;
+    if (to_device) HIP_TRY(hipMemcpy2D(d, dpitch, hp, hpitch, (size_t)sg.cols * 4, sg.rows, hipMemcpyHostToDevice));
+    else HIP_TRY(hipMemcpy2D(hp, hpitch, d, dpitch, (size_t)sg.cols * 4, sg.rows, hipMemcpyDeviceToHost));
+  }
   return 0;
 }
 
+int ganmf_set_tensor(ganmf_handle* h, int tensor_id, int slot, const float* host, int64_t n) {
+  return copy_view(h, tensor_id, slot, const_cast<float*>(host), n, true, "ganmf_set_tensor");
+}
+
 int ganmf_get_tensor(ganmf_handle* h, int tensor_id, int slot, float* host, int64_t n) {
-  View v;
-  if (!h || !host || !find_view(h, tensor_id, &v)) return fail(-1, "ganmf_get_tensor: unknown tensor id %d", tensor_id);
-  float* d = slot_ptr(v.t, slot);
-  if (!d) return fail(-1, "ganmf_get_tensor: bad slot %d", slot);
-  if (n != (int64_t)v.rows * v.cols) return fail(-1, "ganmf_get_tensor: tensor %d has %lld elements, got %lld", tensor_id, (long long)v.rows * v.cols, (long long)n);
-  HIP_TRY(hipSetDevice(h->dev));
-  HIP_TRY(hipStreamSynchronize(h->st));
-  HIP_TRY(hipMemcpy2D(host, (size_t)v.cols * 4, d + (size_t)v.row0 * v.t->ld, (size_t)v.t->ld * 4, (size_t)v.cols * 4, v.rows, hipMemcpyDeviceToHost));
-  return 0;
+  return copy_view(h, tensor_id, slot, host, n, false, "ganmf_get_tensor");
 }
 
 int ganmf_get_adam_powers(ganmf_handle* h, float out4[4]) {
@@ -793,14 +1073,14 @@ int ganmf_train_epoch(ganmf_handle* h, const int32_t* perm, int64_t n, int32_t d
     for (int64_t i = 0; i < per_pass; ++i, ++idx) {
       const int64_t a = i * B;
       const int nb = (int)std::max<int64_t>(0, std::min<int64_t>(B, n - a));
-      TRY(d_step(h, h->perm + std::min<int64_t>(a, std::max<int64_t>(n - 1, 0)), nb, bglob[i], h->d_parts + 4 * idx));
+      TRY(any_d_step(h, h->perm + std::min<int64_t>(a, std::max<int64_t>(n - 1, 0)), nb, bglob[i], h->d_parts + 4 * idx));
     }
   idx = 0;
   for (int p = 0; p < g_steps; ++p)
     for (int64_t i = 0; i < per_pass; ++i, ++idx) {
       const int64_t a = i * B;
       const int nb = (int)std::max<int64_t>(0, std::min<int64_t>(B, n - a));
-      TRY(g_step(h, h->perm + std::min<int64_t>(a, std::max<int64_t>(n - 1, 0)), nb, (int)a, bglob[i], h->g_parts + 4 * idx));
+      TRY(any_g_step(h, h->perm + std::min<int64_t>(a, std::max<int64_t>(n - 1, 0)), nb, (int)a, bglob[i], h->g_parts + 4 * idx));
     }
   if (dist && ng > 0) TRY(allreduce(h, h->g_parts, (size_t)ng * 4));
   std::vector<float> dp((size_t)std::max<int64_t>(nd, 1) * 4), gp((size_t)std::max<int64_t>(ng, 1) * 4);
@@ -829,8 +1109,8 @@ int ganmf_train_step(ganmf_handle* h, int kind, const int32_t* uids, int32_t n, 
   HIP_TRY(hipMemcpyAsync(h->pos, pos.data(), (size_t)h->U * sizeof(int), hipMemcpyHostToDevice, h->st));
   HIP_TRY(hipMemsetAsync(h->d_parts, 0, 4 * sizeof(float), h->st));
   HIP_TRY(hipMemsetAsync(h->g_parts, 0, 4 * sizeof(float), h->st));
-  if (kind == 0) TRY(d_step(h, h->perm, n, n, h->d_parts));
-  else TRY(g_step(h, h->perm, n, 0, n, h->g_parts));
+  if (kind == 0) TRY(any_d_step(h, h->perm, n, n, h->d_parts));
+  else TRY(any_g_step(h, h->perm, n, 0, n, h->g_parts));
   std::vector<float> dp(4), gp(4);
   HIP_TRY(hipMemcpyAsync(dp.data(), h->d_parts, 4 * sizeof(float), hipMemcpyDeviceToHost, h->st));
   HIP_TRY(hipMemcpyAsync(gp.data(), h->g_parts, 4 * sizeof(float), hipMemcpyDeviceToHost, h->st));
@@ -929,7 +1209,7 @@ int ganmf_bench_scores(ganmf_handle* h, int64_t n, int transposed, int32_t iters
 int ganmf_snapshot_best(ganmf_handle* h) {
   if (!h) return fail(-1, "null handle");
   HIP_TRY(hipSetDevice(h->dev));
-  for (Tensor* t : {&h->We, &h->Wd, &h->Ue, &h->V})
+  for (Tensor* t : all_tensors(h))
     HIP_TRY(hipMemcpyAsync(t->best, t->p, t->padded() * sizeof(float), hipMemcpyDeviceToDevice, h->st));
   HIP_TRY(hipStreamSynchronize(h->st));
   return 0;
@@ -938,7 +1218,7 @@ int ganmf_snapshot_best(ganmf_handle* h) {
 int ganmf_restore_best(ganmf_handle* h) {
   if (!h) return fail(-1, "null handle");
   HIP_TRY(hipSetDevice(h->dev));
-  for (Tensor* t : {&h->We, &h->Wd, &h->Ue, &h->V})
+  for (Tensor* t : all_tensors(h))
     HIP_TRY(hipMemcpyAsync(t->p, t->best, t->padded() * sizeof(float), hipMemcpyDeviceToDevice, h->st));
   HIP_TRY(hipStreamSynchronize(h->st));
   return 0;

@@ -46,7 +46,28 @@ enum GemmEpi : int {
   EPI_SUB_SCALED_AUX = 2,  // C = acc - c * aux[m,n]
   EPI_ROWSCALE = 3,        // C = rowscale[m] * acc
   EPI_G_DE = 4,            // C = c * acc + cfm * (ef - er)[m,n];   sum((ef-er)^2) -> sq_partials
+  EPI_ACT = 5,             // C = act(acc)                      (DisGANMF hidden layers)
+  EPI_MUL_ACTGRAD = 6,     // C = acc * act'(aux[m,n]) from the layer OUTPUT aux   (DisGANMF backward)
 };
+
+enum ActKind : int { ACT_LINEAR = 0, ACT_TANH = 1, ACT_RELU = 2, ACT_SIGMOID = 3 };
+
+__device__ inline float act_apply(int act, float z) {
+  switch (act) {
+    case ACT_TANH: return tanhf(z);
+    case ACT_RELU: return fmaxf(z, 0.f);
+    case ACT_SIGMOID: return 1.f / (1.f + expf(-z));
+    default: return z;
+  }
+}
+__device__ inline float act_grad_out(int act, float a) {
+  switch (act) {
+    case ACT_TANH: return 1.f - a * a;
+    case ACT_RELU: return a > 0.f ? 1.f : 0.f;
+    case ACT_SIGMOID: return a * (1.f - a);
+    default: return 1.f;
+  }
+}
 
 struct EpiD {
   int kind;
@@ -60,6 +81,7 @@ struct EpiD {
   float cfm;
   float* sq_partials;      // [nbatch][sq_stride]
   int sq_stride;
+  int act;                 // ActKind for EPI_ACT / EPI_MUL_ACTGRAD
 };
 
 __device__ inline float epi_apply(const EpiD& e, float v, int row, int col, int ldc, const float* __restrict__ aux,
@@ -81,6 +103,12 @@ __device__ inline float epi_apply(const EpiD& e, float v, int row, int col, int 
       sq += d * d;
       break;
     }
+    case EPI_ACT:
+      v = act_apply(e.act, v);
+      break;
+    case EPI_MUL_ACTGRAD:
+      v *= act_grad_out(e.act, aux[(size_t)row * e.ldaux + col]);
+      break;
     default: break;
   }
   return v;

@@ -5,6 +5,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "gemm_f32.hpp"
+
 namespace ganmf {
 
 // ---- device scalar block (floats) ----------------------------------------------------------
@@ -45,7 +47,7 @@ __global__ __launch_bounds__(256) void densify_rows_kernel(const long long* __re
                                                            float* __restrict__ X, int ldx,
                                                            const float* __restrict__ Uemb, int ldk,
                                                            float* __restrict__ Ub, float* __restrict__ scal,
-                                                           int which, float lr) {
+                                                           int which, float lr, int uid_col, int row_offset) {
   const int b = blockIdx.x;
   if (b == 0 && threadIdx.x == 0) {
     const int o = which ? S_B1P_G : S_B1P_D;
@@ -67,6 +69,10 @@ __global__ __launch_bounds__(256) void densify_rows_kernel(const long long* __re
   if (threadIdx.x == 0) {
     x[ncols] = 1.0f;
     X[(size_t)(nb + b) * ldx + ncols] = 1.0f;
+    if (uid_col >= 0) {   // DisGANMF conditions D on float(uid) (DisGANMF.py:59,110-111)
+      x[uid_col] = (float)(row_offset + r);
+      X[(size_t)(nb + b) * ldx + uid_col] = (float)(row_offset + r);
+    }
   }
 }
 
@@ -236,6 +242,71 @@ __global__ __launch_bounds__(256) void adam_rows_kernel(float* __restrict__ th, 
   if (sq_partials) {
     const float s = block_sum_256(sq, red);
     if (threadIdx.x == 0) sq_partials[blockIdx.x] = s;
+  }
+}
+
+// ---- DisGANMF discriminator head (DisGANMF.py:63,114-117) ---------------------------------------
+// One wave per row: logit = [feat | 1] . wo_ext ; sigmoid cross-entropy against the row's label
+// (real rows 1, generated rows 0); dlogit = (sigmoid(logit) - label) / B_global.
+// row0 / nrows select the rows (D-step: all 2B; G-step: the generated half only).
+__global__ __launch_bounds__(256) void dis_head_kernel(const float* __restrict__ feat, int ld, int e1,
+                                                       const float* __restrict__ wo, int row0, int nrows,
+                                                       int n_real, float inv_b, float* __restrict__ dlogit,
+                                                       float* __restrict__ loss_row) {
+  const int r = row0 + blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= row0 + nrows) return;
+  const int lane = threadIdx.x & 63;
+  float s = 0.f;
+  for (int j = lane; j < e1; j += 64) s += feat[(size_t)r * ld + j] * wo[j];
+  s = wave_sum(s);
+  if (lane == 0) {
+    const float z = r < n_real ? 1.f : 0.f;
+    // max(x,0) - x*z + log1p(exp(-|x|))   (tf.nn.sigmoid_cross_entropy_with_logits)
+    loss_row[r] = fmaxf(s, 0.f) - s * z + log1pf(expf(-fabsf(s)));
+    dlogit[r] = (1.f / (1.f + expf(-s)) - z) * inv_b;
+  }
+}
+
+// Top of the backward pass, rows [row0, row0+nrows), columns [0, e1):
+//   dh = dlogit[r] * wo[j] + fmc * (feat[r, j] - feat[r - pair_off, j])      (fmc != 0: G-step)
+//   dz[r, j] = dh * act'(feat[r, j])                 (columns < e only)
+//   gwo[j] = sum_r feat[r, j] * dlogit[r]            (D-step; column e = 1 gives the bias gradient)
+//   fm partial = sum (feat_f - feat_r)^2             (G-step)
+__global__ __launch_bounds__(256) void dis_dz_top_kernel(const float* __restrict__ feat, int ld, int e,
+                                                         const float* __restrict__ wo,
+                                                         const float* __restrict__ dlogit, int row0, int nrows,
+                                                         int pair_off, float fmc, int act, float* __restrict__ dz,
+                                                         float* __restrict__ gwo, float* __restrict__ fm_partials) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int g = threadIdx.x >> 6;
+  float acc = 0.f, fm = 0.f;
+  if (c <= e) {
+    const float w = wo[c];
+    for (int r = row0 + g; r < row0 + nrows; r += 4) {
+      const float a = feat[(size_t)r * ld + c];
+      const float dl = dlogit[r];
+      acc += a * dl;
+      if (c < e) {
+        float dh = dl * w;
+        if (pair_off > 0) {   // G-step: feature matching against the paired real row
+          const float d = a - feat[(size_t)(r - pair_off) * ld + c];
+          dh += fmc * d;
+          fm += d * d;
+        }
+        dz[(size_t)r * ld + c] = dh * act_grad_out(act, a);
+      }
+    }
+  }
+  red[g][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (g == 0 && c <= e && gwo) gwo[c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  if (fm_partials) {
+    __syncthreads();
+    fm = wave_sum(fm);
+    if ((threadIdx.x & 63) == 0) red[0][g] = fm;
+    __syncthreads();
+    if (threadIdx.x == 0) fm_partials[blockIdx.x] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
   }
 }
 
