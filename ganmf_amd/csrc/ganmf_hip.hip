@@ -138,7 +138,9 @@ struct ganmf_handle {
   float *sqp = nullptr;  // [2][max_tiles]
   int sqp_stride = 0;
   float* fmp = nullptr;   // [RED_GRID]
-  float* regp = nullptr;  // [4][ADAM_GRID]: We_ext, Wd_ext, U, V
+  float* regp = nullptr;  // [slots][reg_cap] block partials of sum(theta^2): We_ext, Wd_ext, U, V, (DisGANMF layers)
+  int reg_cap = 0;
+  bool fuse_adam = true;  // single GPU: Adam runs in the epilogue of the weight-gradient GEMMs
   float *d_parts = nullptr, *g_parts = nullptr;  // [cap][4]
   int64_t parts_cap = 0;
   // scoring scratch
@@ -277,11 +279,12 @@ int ensure_slab(ganmf_handle* h, size_t elems, int lane) {
 // One logical GEMM of the step: plan (tile / ring / split-K), launch, and when split the reduce
 // kernel that applies the epilogue.  *sq_count = partial sums per batch written to epi.sq_partials.
 int run_gemm(ganmf_handle* h, int tag_gemm, int tag_red, GemmP g, bool akm, bool bkm, int* sq_count = nullptr,
-             double extra_bytes = 0, int lane = 0) {
+             double extra_bytes = 0, int lane = 0, const GemmTune* force = nullptr) {
   if (g.nbatch < 1) g.nbatch = 1;
   g.zero_page = h->zero_page;
   hipStream_t st = lane ? h->st2 : h->st;
-  const GemmPlan pl = gemm_plan(g.M, g.N, g.K, g.nbatch, g.epi.sq_partials != nullptr, h->tune);
+  const GemmPlan pl = gemm_plan(g.M, g.N, g.K, g.nbatch, g.epi.sq_partials != nullptr, force ? *force : h->tune,
+                                g.epi.kind == EPI_ADAM);
   if (pl.nsplit > 1) TRY(ensure_slab(h, gemm_slab_elems(pl, g.M, g.ldc, g.nbatch), lane));
   float* slab = lane ? h->slab2 : h->slab;
   const size_t slab_elems = lane ? h->slab2_elems : h->slab_elems;
@@ -383,6 +386,8 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
   const bool dist = h->has_comm;
   const float inv_bn = 1.0f / ((float)b_global * (float)N);
   int sqn = 0;
+  bool fused = false;
+  int regn[2] = {ADAM_GRID, ADAM_GRID};
   if (nb > 0) {
     TRY(step_front(h, rows_dev, nb, 0));
     {  // Delta = [E|1].Wd_ext - inp, per-path sum of squares  (GANMF.py:66-68), batch z = path
@@ -420,54 +425,57 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
     HIP_TRY(hipGetLastError());
   }
   if (nb > 0) {
-    // Two lanes: the decoder-gradient GEMM and its Adam update only need Delta and the scaled
-    // encodings, so they run beside dE -> gWe_ext -> Adam(We_ext); MFMA-bound and HBM-bound kernels
-    // overlap and the fixed prologue/epilogue phases of one kernel hide behind the other.
-    const bool two = h->overlap && !dist;
     const bool regD = h->cfg.d_reg != 0.f;
-    if (two) TRY(lane_fork(h));
-    {  // gWd_ext = (rs*[E|1])^T . Delta   -> rows 0..e-1 = gWd, row e = gbd
-      GemmP g{};
-      g.A = h->Es; g.lda = h->lde; g.B = h->Dl; g.ldb = h->ldN;
-      g.C = h->Wd.g; g.ldc = h->ldN; g.M = e + 1; g.N = N; g.K = 2 * nb; g.epi.kind = EPI_STORE;
-      TRY(run_gemm(h, T_GEMM_GWD, T_RED_GWD, g, true, true, nullptr, 0, two ? 1 : 0));
-    }
-    {  // dE = rs * (Delta . Wd^T)          (bias row e of Wd_ext is not part of this product)
+    fused = h->fuse_adam && !dist;
+    {  // dE = rs * (Delta . Wd^T)          (bias row e of Wd_ext is not part of this product; reads the OLD Wd)
       GemmP g{};
       g.A = h->Dl; g.lda = h->ldN; g.B = h->Wd.p; g.ldb = h->ldN;
       g.C = h->dE; g.ldc = h->lde; g.M = 2 * nb; g.N = e; g.K = N;
       g.epi.kind = EPI_ROWSCALE; g.epi.rowscale = h->rs;
       TRY(run_gemm(h, T_GEMM_DE, T_RED_DE, g, false, false));
     }
-    if (two) {
-      // the dE product reads the OLD decoder weights: Adam(Wd_ext) on the side lane must wait for it
-      HIP_TRY(hipEventRecord(h->ev_mid, h->st));
-      HIP_TRY(hipStreamWaitEvent(h->st2, h->ev_mid, 0));
-      TRY(adam_dense(h, T_ADAM_D, h->Wd, h->Wd.g, S_ALPHA_D, h->cfg.d_reg, regD ? h->regp + ADAM_GRID : nullptr, 1));
+    // Weight-gradient GEMMs.  Single GPU: the gradient tile never leaves the CU -- the epilogue
+    // applies TF-Adam to theta/m/v in place (64x64 tiles, two workgroups per CU, so one
+    // workgroup's HBM-bound Adam phase overlaps its neighbour's MFMA phase).  Data-parallel: the
+    // gradients are stored, all-reduced and a separate Adam kernel follows.
+    GemmTune ft;
+    ft.tile = 64; ft.ring = 2; ft.nsplit = 1;
+    {  // gWd_ext = (rs*[E|1])^T . Delta   -> rows 0..e-1 = gWd, row e = gbd
+      GemmP g{};
+      g.A = h->Es; g.lda = h->lde; g.B = h->Dl; g.ldb = h->ldN;
+      g.C = h->Wd.g; g.ldc = h->ldN; g.M = e + 1; g.N = N; g.K = 2 * nb; g.epi.kind = EPI_STORE;
+      if (fused) {
+        g.epi.kind = EPI_ADAM; g.epi.adam_theta = h->Wd.p; g.epi.adam_m = h->Wd.m; g.epi.adam_v = h->Wd.v;
+        g.epi.adam_alpha = h->scal + S_ALPHA_D; g.epi.adam_reg = h->cfg.d_reg;
+        g.epi.sq_partials = regD ? h->regp + h->reg_cap : nullptr;
+      }
+      TRY(run_gemm(h, T_GEMM_GWD, T_RED_GWD, g, true, true, &regn[1], fused ? 24.0 * h->Wd.count() : 0, 0, fused ? &ft : nullptr));
     }
     {  // gWe_ext = [X;F | 1]^T . dE       -> rows 0..N-1 = gWe, row N = gbe
       GemmP g{};
       g.A = h->XF; g.lda = h->ldN; g.B = h->dE; g.ldb = h->lde;
       g.C = h->We.g; g.ldc = h->lde; g.M = N + 1; g.N = e; g.K = 2 * nb; g.epi.kind = EPI_STORE;
-      TRY(run_gemm(h, T_GEMM_GWE, T_RED_GWE, g, true, true));
-    }
-    if (two) {
-      TRY(adam_dense(h, T_ADAM_D, h->We, h->We.g, S_ALPHA_D, h->cfg.d_reg, regD ? h->regp : nullptr));
-      TRY(lane_join(h));
+      if (fused) {
+        g.epi.kind = EPI_ADAM; g.epi.adam_theta = h->We.p; g.epi.adam_m = h->We.m; g.epi.adam_v = h->We.v;
+        g.epi.adam_alpha = h->scal + S_ALPHA_D; g.epi.adam_reg = h->cfg.d_reg;
+        g.epi.sq_partials = regD ? h->regp : nullptr;
+      }
+      TRY(run_gemm(h, T_GEMM_GWE, T_RED_GWE, g, true, true, &regn[0], fused ? 24.0 * h->We.count() : 0, 0, fused ? &ft : nullptr));
     }
   } else {
     HIP_TRY(hipMemsetAsync(h->gD, 0, h->gD_elems * sizeof(float), h->st));
   }
   const bool reg = h->cfg.d_reg != 0.f;
-  if (!(h->overlap && !dist) || nb == 0) {
+  if (!fused) {
     TRY(allreduce(h, h->gD, h->gD_elems));
     TRY(adam_dense(h, T_ADAM_D, h->We, h->We.g, S_ALPHA_D, h->cfg.d_reg, reg ? h->regp : nullptr));
-    TRY(adam_dense(h, T_ADAM_D, h->Wd, h->Wd.g, S_ALPHA_D, h->cfg.d_reg, reg ? h->regp + ADAM_GRID : nullptr));
+    TRY(adam_dense(h, T_ADAM_D, h->Wd, h->Wd.g, S_ALPHA_D, h->cfg.d_reg, reg ? h->regp + h->reg_cap : nullptr));
+    regn[0] = regn[1] = ADAM_GRID;
   }
   if (reg) {
     MultiRed mr{};
     mr.count = 2; mr.out = parts;
-    for (int i = 0; i < 2; ++i) mr.e[i] = {h->regp + i * ADAM_GRID, ADAM_GRID, 2, i ? 1 : 0};
+    for (int i = 0; i < 2; ++i) mr.e[i] = {h->regp + i * h->reg_cap, regn[i], 2, i ? 1 : 0};
     Scope s(h, T_MULTIRED, 0, 0);
     hipLaunchKernelGGL(multi_reduce_kernel, dim3(1), dim3(256), 0, h->st, mr);
     HIP_TRY(hipGetLastError());
@@ -529,7 +537,7 @@ int g_step(ganmf_handle* h, const int* rows_dev, int nb, int start, int b_global
       // gUb reads the OLD item embeddings: Adam(V) on the side lane waits for it
       HIP_TRY(hipEventRecord(h->ev_mid, h->st));
       HIP_TRY(hipStreamWaitEvent(h->st2, h->ev_mid, 0));
-      TRY(adam_dense(h, T_ADAM_V, h->V, h->V.g, S_ALPHA_G, h->cfg.g_reg, regG ? h->regp + 3 * ADAM_GRID : nullptr, 1));
+      TRY(adam_dense(h, T_ADAM_V, h->V, h->V.g, S_ALPHA_G, h->cfg.g_reg, regG ? h->regp + 3 * h->reg_cap : nullptr, 1));
     }
   } else {
     hipLaunchKernelGGL(open_step_kernel, dim3(1), dim3(64), 0, h->st, h->scal, 1, h->cfg.g_lr);
@@ -540,13 +548,13 @@ int g_step(ganmf_handle* h, const int* rows_dev, int nb, int start, int b_global
   const bool overlapped = h->overlap && !h->has_comm && nb > 0;
   if (!overlapped) {
     TRY(allreduce(h, h->V.g, h->V.padded()));
-    TRY(adam_dense(h, T_ADAM_V, h->V, h->V.g, S_ALPHA_G, h->cfg.g_reg, reg ? h->regp + 3 * ADAM_GRID : nullptr));
+    TRY(adam_dense(h, T_ADAM_V, h->V, h->V.g, S_ALPHA_G, h->cfg.g_reg, reg ? h->regp + 3 * h->reg_cap : nullptr));
   }
   {
     Scope s(h, T_ADAM_U, 0, 24.0 * h->Ue.count());
     hipLaunchKernelGGL(adam_rows_kernel, dim3(ADAM_GRID), dim3(256), 0, h->st, h->Ue.p, h->Ue.m, h->Ue.v, h->gUb,
                        h->pos, start, nb, h->U, h->ldk, h->scal, S_ALPHA_G, h->cfg.g_reg,
-                       reg ? h->regp + 2 * ADAM_GRID : nullptr);
+                       reg ? h->regp + 2 * h->reg_cap : nullptr);
     HIP_TRY(hipGetLastError());
   }
   if (overlapped) TRY(lane_join(h));
@@ -557,8 +565,8 @@ int g_step(ganmf_handle* h, const int* rows_dev, int nb, int start, int b_global
     mr.e[1] = {h->fmp, fmn, 1, 0};
     mr.count = 2;
     if (reg) {
-      mr.e[2] = {h->regp + 2 * ADAM_GRID, ADAM_GRID, 2, 0};
-      mr.e[3] = {h->regp + 3 * ADAM_GRID, ADAM_GRID, 3, 0};
+      mr.e[2] = {h->regp + 2 * h->reg_cap, ADAM_GRID, 2, 0};
+      mr.e[3] = {h->regp + 3 * h->reg_cap, ADAM_GRID, 3, 0};
       mr.count = 4;
     }
     Scope s(h, T_MULTIRED, 0, 0);
@@ -654,8 +662,8 @@ int dis_d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float
   TRY(allreduce(h, h->gD, h->gD_elems));
   const bool reg = h->cfg.d_reg != 0.f;
   for (int l = 0; l < h->L; ++l)
-    TRY(adam_dense(h, T_ADAM_D, h->Wl[l], h->Wl[l].g, S_ALPHA_D, h->cfg.d_reg, reg ? h->regp + (4 + l) * ADAM_GRID : nullptr));
-  TRY(adam_dense(h, T_ADAM_D, h->Wo, h->Wo.g, S_ALPHA_D, h->cfg.d_reg, reg ? h->regp + (4 + h->L) * ADAM_GRID : nullptr));
+    TRY(adam_dense(h, T_ADAM_D, h->Wl[l], h->Wl[l].g, S_ALPHA_D, h->cfg.d_reg, reg ? h->regp + (4 + l) * h->reg_cap : nullptr));
+  TRY(adam_dense(h, T_ADAM_D, h->Wo, h->Wo.g, S_ALPHA_D, h->cfg.d_reg, reg ? h->regp + (4 + h->L) * h->reg_cap : nullptr));
   {  // parts = {sum sce(real), sum sce(fake), sum theta_D^2}
     MultiRed mr{};
     mr.out = parts;
@@ -669,7 +677,7 @@ int dis_d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float
         MultiRed m2{};
         m2.out = parts;
         m2.count = std::min(6, h->L + 1 - i);
-        for (int j = 0; j < m2.count; ++j) m2.e[j] = {h->regp + (4 + i + j) * ADAM_GRID, ADAM_GRID, 2, (i + j) ? 1 : 0};
+        for (int j = 0; j < m2.count; ++j) m2.e[j] = {h->regp + (4 + i + j) * h->reg_cap, ADAM_GRID, 2, (i + j) ? 1 : 0};
         hipLaunchKernelGGL(multi_reduce_kernel, dim3(1), dim3(256), 0, h->st, m2);
       }
     }
@@ -723,12 +731,12 @@ int dis_g_step(ganmf_handle* h, const int* rows_dev, int nb, int start, int b_gl
   }
   TRY(allreduce(h, h->V.g, h->V.padded()));
   const bool reg = h->cfg.g_reg != 0.f;
-  TRY(adam_dense(h, T_ADAM_V, h->V, h->V.g, S_ALPHA_G, h->cfg.g_reg, reg ? h->regp + 3 * ADAM_GRID : nullptr));
+  TRY(adam_dense(h, T_ADAM_V, h->V, h->V.g, S_ALPHA_G, h->cfg.g_reg, reg ? h->regp + 3 * h->reg_cap : nullptr));
   {
     Scope s(h, T_ADAM_U, 0, 24.0 * h->Ue.count());
     hipLaunchKernelGGL(adam_rows_kernel, dim3(ADAM_GRID), dim3(256), 0, h->st, h->Ue.p, h->Ue.m, h->Ue.v, h->gUb,
                        h->pos, start, nb, h->U, h->ldk, h->scal, S_ALPHA_G, h->cfg.g_reg,
-                       reg ? h->regp + 2 * ADAM_GRID : nullptr);
+                       reg ? h->regp + 2 * h->reg_cap : nullptr);
     HIP_TRY(hipGetLastError());
   }
   {  // parts = {sum sce(fake), sum (feat_f - feat_r)^2, sum U^2, sum V^2}
@@ -738,8 +746,8 @@ int dis_g_step(ganmf_handle* h, const int* rows_dev, int nb, int start, int b_gl
     mr.e[1] = {h->fmp, fmn, 1, 0};
     mr.count = 2;
     if (reg) {
-      mr.e[2] = {h->regp + 2 * ADAM_GRID, ADAM_GRID, 2, 0};
-      mr.e[3] = {h->regp + 3 * ADAM_GRID, ADAM_GRID, 3, 0};
+      mr.e[2] = {h->regp + 2 * h->reg_cap, ADAM_GRID, 2, 0};
+      mr.e[3] = {h->regp + 3 * h->reg_cap, ADAM_GRID, 3, 0};
       mr.count = 4;
     }
     Scope s(h, T_MULTIRED, 0, 0);
@@ -844,6 +852,7 @@ int ganmf_create(const ganmf_cfg* cfg, ganmf_handle** out) {
   HIP_TRY(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&h->ev_mid, hipEventDisableTiming));
   h->overlap = env_int("GANMF_OVERLAP", 0) != 0;
+  h->fuse_adam = env_int("GANMF_FUSE_ADAM", 1) != 0;
   const int U = h->U, N = h->N, k = h->k, e = h->e, B = h->B;
   const bool dis = cfg->model == GANMF_MODEL_DISGANMF;
   // parameters; D gradients contiguous for a single all-reduce
@@ -906,7 +915,9 @@ int ganmf_create(const ganmf_cfg* cfg, ganmf_handle** out) {
   TRY(dalloc(&h->scal, S_COUNT));
   TRY(dalloc(&h->sqp, (size_t)2 * std::max(GEMM_RED_GRID, ((B + 63) / 64) * ((N + 63) / 64)) + 16));
   TRY(dalloc(&h->fmp, std::max(RED_GRID, (e + 64) / 64 + 1)));
-  TRY(dalloc(&h->regp, (size_t)(4 + 17 + 1) * ADAM_GRID));
+  h->reg_cap = std::max(ADAM_GRID, ((std::max(N, e) + 1 + 63) / 64) * ((std::max(N, e) + 63) / 64 + 1));
+  h->reg_cap = std::min(h->reg_cap, 1 << 20);
+  TRY(dalloc(&h->regp, (size_t)(4 + 17 + 1) * h->reg_cap));
   const float pw[4] = {ADAM_B1, ADAM_B2, ADAM_B1, ADAM_B2};
   HIP_TRY(hipMemcpy(h->scal, pw, sizeof pw, hipMemcpyHostToDevice));
   HIP_TRY(hipDeviceSynchronize());

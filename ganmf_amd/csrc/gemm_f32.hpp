@@ -48,7 +48,11 @@ enum GemmEpi : int {
   EPI_G_DE = 4,            // C = c * acc + cfm * (ef - er)[m,n];   sum((ef-er)^2) -> sq_partials
   EPI_ACT = 5,             // C = act(acc)                      (DisGANMF hidden layers)
   EPI_MUL_ACTGRAD = 6,     // C = acc * act'(aux[m,n]) from the layer OUTPUT aux   (DisGANMF backward)
+  EPI_ADAM = 7,            // acc is the gradient: TF ApplyAdam on theta/m/v in place, nothing stored to C;
+                           // sum(theta_old^2) -> sq_partials.  Never split along K.
 };
+
+constexpr float ADAM_B1 = 0.9f, ADAM_B2 = 0.999f, ADAM_EPS = 1e-8f;
 
 enum ActKind : int { ACT_LINEAR = 0, ACT_TANH = 1, ACT_RELU = 2, ACT_SIGMOID = 3 };
 
@@ -82,7 +86,22 @@ struct EpiD {
   float* sq_partials;      // [nbatch][sq_stride]
   int sq_stride;
   int act;                 // ActKind for EPI_ACT / EPI_MUL_ACTGRAD
+  float* adam_theta;       // EPI_ADAM: parameter and moments, same [M, ldc] geometry as C
+  float* adam_m;
+  float* adam_v;
+  const float* adam_alpha; // device scalar lr_t of the step in flight
+  float adam_reg;          // gradient += adam_reg * theta  (the L2 term of the loss)
 };
+
+// TF ApplyAdam on one element (GANMF.py:104-105,138; training_ops ApplyAdam functor)
+__device__ inline void adam_update(float g, float alpha, float reg, float& th, float& m, float& v, float& sq) {
+  const float x = th;
+  sq += x * x;
+  const float gr = g + reg * x;
+  m += (gr - m) * (1.f - ADAM_B1);
+  v += (gr * gr - v) * (1.f - ADAM_B2);
+  th = x - (m * alpha) / (sqrtf(v) + ADAM_EPS);
+}
 
 __device__ inline float epi_apply(const EpiD& e, float v, int row, int col, int ldc, const float* __restrict__ aux,
                                   float& sq) {
@@ -333,12 +352,33 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const GemmP p) {
   constexpr int C4 = BN / 4, RPP = 256 / C4;
   const int tc = tid % C4, tr = tid / C4;
   const int col = n0 + tc * 4;
+  const bool adam = !deferred && e.kind == EPI_ADAM;
+  const float alpha = adam ? *e.adam_alpha : 0.f;
 #pragma unroll 4
   for (int j = 0; j < BM / RPP; ++j) {
     const int row_l = tr + j * RPP, row = m0 + row_l;
     if (row < p.M && col < p.N) {
       const float4 v = *reinterpret_cast<const float4*>(ct + row_l * BN + tc * 4);
       float o[4] = {v.x, v.y, v.z, v.w};
+      if (adam) {   // the tile is a gradient: update parameter and moments in place (never stored)
+        const size_t off = (size_t)row * p.ldc + col;
+        if (col + 3 < p.N) {
+          float4 t4 = *reinterpret_cast<float4*>(e.adam_theta + off);
+          float4 m4 = *reinterpret_cast<float4*>(e.adam_m + off);
+          float4 v4 = *reinterpret_cast<float4*>(e.adam_v + off);
+          adam_update(o[0], alpha, e.adam_reg, t4.x, m4.x, v4.x, sq);
+          adam_update(o[1], alpha, e.adam_reg, t4.y, m4.y, v4.y, sq);
+          adam_update(o[2], alpha, e.adam_reg, t4.z, m4.z, v4.z, sq);
+          adam_update(o[3], alpha, e.adam_reg, t4.w, m4.w, v4.w, sq);
+          *reinterpret_cast<float4*>(e.adam_theta + off) = t4;
+          *reinterpret_cast<float4*>(e.adam_m + off) = m4;
+          *reinterpret_cast<float4*>(e.adam_v + off) = v4;
+        } else {
+          for (int q = 0; q < 4 && col + q < p.N; ++q)
+            adam_update(o[q], alpha, e.adam_reg, e.adam_theta[off + q], e.adam_m[off + q], e.adam_v[off + q], sq);
+        }
+        continue;
+      }
       if (col + 3 < p.N) {
         if (!deferred) {
 #pragma unroll
@@ -443,7 +483,7 @@ inline void split_plan(int K, int want, int& nsplit, int& kps) {
 // Cost model (cycles at ~2.1 GHz under fp32 MFMA load).  Every GEMM of the step is small
 // (<= 1.9 GFLOP, >= 12 us at the MFMA roof), so the plan is about filling 256 CUs evenly and
 // keeping each workgroup's serial K-walk short; split-K pays a slab round trip + one launch.
-inline GemmPlan gemm_plan(int M, int N, int K, int nbatch, bool wants_sq, const GemmTune& tune) {
+inline GemmPlan gemm_plan(int M, int N, int K, int nbatch, bool wants_sq, const GemmTune& tune, bool no_split = false) {
   GemmPlan best;
   best.est_us = 1e30;
   const int tiles[2] = {128, 64};
@@ -455,7 +495,7 @@ inline GemmPlan gemm_plan(int M, int N, int K, int nbatch, bool wants_sq, const 
     const int bk = tile == 128 ? 32 : 64;
     // 64x64 tiles move 16 B/clk/CU through L2 -> LDS, above what L2/MALL sustains chip-wide
     const double cyc_tile = tile == 128 ? 4800.0 : 2900.0;   // measured 2.4 / 1.25 us per K-tile
-    const int max_split = std::max(1, (K + GEMM_K_ALIGN - 1) / GEMM_K_ALIGN);
+    const int max_split = no_split ? 1 : std::max(1, (K + GEMM_K_ALIGN - 1) / GEMM_K_ALIGN);
     for (int want = 1; want <= max_split; want = want < 4 ? want + 1 : want + (want + 3) / 4) {
       if (tune.nsplit) want = std::min(tune.nsplit, max_split);   // forced: evaluate exactly this one
       int ns, kps;

@@ -17,7 +17,6 @@ enum Scal : int {
   S_COUNT = 16
 };
 
-constexpr float ADAM_B1 = 0.9f, ADAM_B2 = 0.999f, ADAM_EPS = 1e-8f;
 
 __device__ inline float wave_sum(float v) {
 #pragma unroll
