@@ -71,6 +71,7 @@ int env_int(const char* name, int dflt) {
 
 constexpr int ADAM_GRID = 1024;
 constexpr int RED_GRID = GEMM_RED_GRID;
+constexpr int COUNTER_CAP = 1 << 16;
 
 struct Tensor {
   int rows = 0, cols = 0, ld = 0;
@@ -133,6 +134,9 @@ struct ganmf_handle {
   size_t slab_elems = 0;
   float* slab2 = nullptr;                // split-K workspace of the side lane
   size_t slab2_elems = 0;
+  unsigned *counters = nullptr, *counters2 = nullptr;   // split-K arrival counters (zero between launches)
+  bool inkernel_reduce = true;
+  int inlaunch_max = 4;
   float* rs = nullptr;
   float* scal = nullptr;
   float *sqp = nullptr;  // [2][max_tiles]
@@ -288,31 +292,33 @@ int run_gemm(ganmf_handle* h, int tag_gemm, int tag_red, GemmP g, bool akm, bool
   if (pl.nsplit > 1) TRY(ensure_slab(h, gemm_slab_elems(pl, g.M, g.ldc, g.nbatch), lane));
   float* slab = lane ? h->slab2 : h->slab;
   const size_t slab_elems = lane ? h->slab2_elems : h->slab_elems;
-  if (sq_count) *sq_count = pl.sq_count;
+  unsigned* counters = h->inkernel_reduce ? (lane ? h->counters2 : h->counters) : nullptr;
+  const size_t n_tiles = (size_t)pl.tiles_m * pl.tiles_n * g.nbatch;
+  // the last-arriving workgroup reads nsplit slab tiles alone (~60-120 GB/s per block): in-launch
+  // reduction only pays for shallow splits; deep splits keep the chip-wide reduce kernel
+  const bool in_launch = pl.nsplit > 1 && pl.nsplit <= h->inlaunch_max && counters && n_tiles <= (size_t)COUNTER_CAP;
+  const bool wants_sq = g.epi.sq_partials != nullptr;
+  const int sqc = !wants_sq ? 0 : (pl.nsplit > 1 && !in_launch ? GEMM_RED_GRID : pl.sq_count);
+  if (sq_count) *sq_count = sqc;
   if (h->debug_plan) {
     const long long key = ((long long)tag_gemm << 48) ^ ((long long)g.M << 32) ^ ((long long)g.N << 16) ^ g.K;
     if (std::find(h->seen_plans.begin(), h->seen_plans.end(), key) == h->seen_plans.end()) {
       h->seen_plans.push_back(key);
-      fprintf(stderr, "[ganmf plan] %-28s M=%d N=%d K=%d batch=%d -> tile %d ring %d nsplit %d (kps %d) wgs %d est %.1f us\n",
+      fprintf(stderr, "[ganmf plan] %-28s M=%d N=%d K=%d batch=%d -> tile %d ring %d nsplit %d (kps %d) wgs %d est %.1f us%s\n",
               kTagName[tag_gemm], g.M, g.N, g.K, g.nbatch, pl.tile, pl.ring, pl.nsplit, pl.kps,
-              pl.tiles_m * pl.tiles_n * pl.nsplit * g.nbatch, pl.est_us);
+              pl.tiles_m * pl.tiles_n * pl.nsplit * g.nbatch, pl.est_us, in_launch ? " (in-launch reduce)" : "");
     }
   }
-  if (!h->prof) {
-    HIP_TRY(gemm_run(st, g, akm, bkm, pl, slab, slab_elems));
-    return 0;
-  }
-  // profiled: bracket the GEMM and the reduce separately
   const double fl = g.nbatch * gemm_flops(g.M, g.N, g.K), by = gemm_bytes((double)g.nbatch * g.M, g.N, g.K) + extra_bytes;
-  if (pl.nsplit == 1) {
-    Scope s(h, tag_gemm, fl, by, st);
-    HIP_TRY(gemm_run(st, g, akm, bkm, pl, slab, slab_elems));
+  if (!h->prof || pl.nsplit == 1 || in_launch) {
+    Scope s(h, tag_gemm, fl, by + (pl.nsplit > 1 ? 8.0 * pl.nsplit * g.nbatch * g.M * g.N : 0), st);
+    HIP_TRY(gemm_run(st, g, akm, bkm, pl, slab, slab_elems, in_launch ? counters : nullptr, COUNTER_CAP));
     return 0;
   }
-  {  // GEMM part only: run with a store epilogue into the slab, then the reduce by hand
+  {  // profiled, separate reduce kernel: bracket the GEMM and the reduce separately
     Scope s(h, tag_gemm, fl, by, st);
     GemmP q = g;
-    q.tiles_m = pl.tiles_m; q.tiles_n = pl.tiles_n; q.nsplit = pl.nsplit; q.k_per_split = pl.kps;
+    q.tiles_m = pl.tiles_m; q.tiles_n = pl.tiles_n; q.nsplit = pl.nsplit; q.k_per_split = pl.kps; q.counters = nullptr;
     q.C = slab; q.c_split_stride = (long long)g.nbatch * g.M * g.ldc; q.c_batch_stride = (long long)g.M * g.ldc;
     hipError_t e;
     if (pl.tile == 128) e = pl.ring == 3 ? gemm_launch_t<128, 128, 32, 3>(st, q, akm, bkm) : gemm_launch_t<128, 128, 32, 2>(st, q, akm, bkm);
@@ -323,7 +329,7 @@ int run_gemm(ganmf_handle* h, int tag_gemm, int tag_red, GemmP g, bool akm, bool
     Scope s(h, tag_red, 0, 4.0 * (pl.nsplit + 1) * g.nbatch * g.M * g.N, st);
     RedP r{};
     r.part = slab; r.nsplit = pl.nsplit; r.out = g.C; r.ld = g.ldc; r.M = g.M; r.N = g.N;
-    r.batch_stride = g.c_batch_stride; r.epi = g.epi; r.epi.sq_stride = pl.sq_count;
+    r.batch_stride = g.c_batch_stride; r.epi = g.epi; r.epi.sq_stride = GEMM_RED_GRID;
     r.split_stride = (long long)g.nbatch * g.M * g.ldc;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(GEMM_RED_GRID, g.nbatch), dim3(256), 0, st, r);
     HIP_TRY(hipGetLastError());
@@ -853,6 +859,10 @@ int ganmf_create(const ganmf_cfg* cfg, ganmf_handle** out) {
   HIP_TRY(hipEventCreateWithFlags(&h->ev_mid, hipEventDisableTiming));
   h->overlap = env_int("GANMF_OVERLAP", 0) != 0;
   h->fuse_adam = env_int("GANMF_FUSE_ADAM", 1) != 0;
+  h->inkernel_reduce = env_int("GANMF_INKERNEL_REDUCE", 0) != 0;   // measured slower than the chip-wide reduce kernel
+  h->inlaunch_max = env_int("GANMF_INLAUNCH_MAX", 4);
+  TRY(dalloc((float**)&h->counters, COUNTER_CAP));
+  TRY(dalloc((float**)&h->counters2, COUNTER_CAP));
   const int U = h->U, N = h->N, k = h->k, e = h->e, B = h->B;
   const bool dis = cfg->model == GANMF_MODEL_DISGANMF;
   // parameters; D gradients contiguous for a single all-reduce
@@ -914,7 +924,8 @@ int ganmf_create(const ganmf_cfg* cfg, ganmf_handle** out) {
   TRY(dalloc(&h->rs, (size_t)2 * B));
   TRY(dalloc(&h->scal, S_COUNT));
   TRY(dalloc(&h->sqp, (size_t)2 * std::max(GEMM_RED_GRID, ((B + 63) / 64) * ((N + 63) / 64)) + 16));
-  TRY(dalloc(&h->fmp, std::max(RED_GRID, (e + 64) / 64 + 1)));
+  // FM partials: one per tile of the [B, e] dE output or per reduce block
+  TRY(dalloc(&h->fmp, std::max(RED_GRID, ((B + 63) / 64) * ((e + 63) / 64) + (e + 64) / 64 + 1)));
   h->reg_cap = std::max(ADAM_GRID, ((std::max(N, e) + 1 + 63) / 64) * ((std::max(N, e) + 63) / 64 + 1));
   h->reg_cap = std::min(h->reg_cap, 1 << 20);
   TRY(dalloc(&h->regp, (size_t)(4 + 17 + 1) * h->reg_cap));
@@ -945,7 +956,7 @@ int ganmf_destroy(ganmf_handle* h) {
   hipEventDestroy(h->ev_fork); hipEventDestroy(h->ev_join); hipEventDestroy(h->ev_mid);
   hipStreamDestroy(h->st2);
   hipStreamDestroy(h->st);
-  hipFree(h->slab2);
+  hipFree(h->slab2); hipFree(h->counters); hipFree(h->counters2);
   delete h;
   return 0;
 }
@@ -1290,14 +1301,17 @@ int ganmf_gemm_f32(int device, const float* A, const float* B, float* C, int64_t
   const GemmPlan pl = gemm_plan(g.M, g.N, g.K, 1, false, tune);
   const size_t slab_elems = gemm_slab_elems(pl, g.M, ldc, 1);
   if (slab_elems) TRY(dalloc(&slab, slab_elems));
+  unsigned* counters = nullptr;
+  const bool inl = env_int("GANMF_INKERNEL_REDUCE", 0) != 0;
+  if (inl) TRY(dalloc((float**)&counters, COUNTER_CAP));
   hipStream_t st = nullptr;
-  HIP_TRY(gemm_run(st, g, a_kmajor, b_kmajor, pl, slab, slab_elems));
+  HIP_TRY(gemm_run(st, g, a_kmajor, b_kmajor, pl, slab, slab_elems, counters, COUNTER_CAP));
   HIP_TRY(hipDeviceSynchronize());
   if (iters > 1 || ms) {
     hipEvent_t a, b;
     hipEventCreate(&a); hipEventCreate(&b);
     hipEventRecord(a, st);
-    for (int i = 0; i < std::max(iters, 1); ++i) gemm_run(st, g, a_kmajor, b_kmajor, pl, slab, slab_elems);
+    for (int i = 0; i < std::max(iters, 1); ++i) gemm_run(st, g, a_kmajor, b_kmajor, pl, slab, slab_elems, counters, COUNTER_CAP);
     hipEventRecord(b, st);
     hipEventSynchronize(b);
     float t = 0.f;
@@ -1308,6 +1322,7 @@ int ganmf_gemm_f32(int device, const float* A, const float* B, float* C, int64_t
   HIP_TRY(hipMemcpy2D(C, (size_t)N * 4, dC, (size_t)ldc * 4, (size_t)N * 4, M, hipMemcpyDeviceToHost));
   hipFree(dA); hipFree(dB); hipFree(dC); hipFree(zp);
   if (slab) hipFree(slab);
+  if (counters) hipFree(counters);
   return 0;
 }
 

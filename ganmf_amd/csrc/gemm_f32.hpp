@@ -147,6 +147,11 @@ struct GemmP {
   long long a_batch_stride, c_batch_stride;
   EpiD epi;
   int tiles_m, tiles_n;
+  // split-K finished inside the launch: the last workgroup to arrive at a tile (agent-scope
+  // arrival counter) sums the slabs in split order and applies the epilogue into Cf
+  unsigned* counters;      // [nbatch * tiles]; zero between launches (the reducer re-zeroes its word)
+  float* Cf;               // final output [M, ldc] per batch
+  long long cf_batch_stride;
 };
 
 #define GANMF_WAIT_VMCNT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
@@ -354,6 +359,9 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const GemmP p) {
   const int col = n0 + tc * 4;
   const bool adam = !deferred && e.kind == EPI_ADAM;
   const float alpha = adam ? *e.adam_alpha : 0.f;
+  const bool publish = deferred && p.counters != nullptr;
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t slab_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)C, (short)0, 0x7fffffff, 0x00020000);
 #pragma unroll 4
   for (int j = 0; j < BM / RPP; ++j) {
     const int row_l = tr + j * RPP, row = m0 + row_l;
@@ -379,7 +387,20 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const GemmP p) {
         }
         continue;
       }
-      if (col + 3 < p.N) {
+      if (publish) {
+        // slab tile handed to another workgroup inside this launch: WRITE-THROUGH (sc1) stores,
+        // so no release fence is needed (cdna guide §6 Guideline 16, R1)
+        const int boff = (int)(((size_t)row * p.ldc + col) * sizeof(float));
+        if (col + 3 < p.N) {
+          u32x4 bits;
+          bits[0] = __float_as_uint(o[0]); bits[1] = __float_as_uint(o[1]);
+          bits[2] = __float_as_uint(o[2]); bits[3] = __float_as_uint(o[3]);
+          __builtin_amdgcn_raw_buffer_store_b128(bits, slab_rsrc, boff, 0, 16 /* sc1 */);
+        } else {
+          for (int q = 0; q < 4 && col + q < p.N; ++q)
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o[q]), slab_rsrc, boff + 4 * q, 0, 16);
+        }
+      } else if (col + 3 < p.N) {
         if (!deferred) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) o[q] = epi_apply(e, o[q], row, col + q, p.ldc, aux, sq);
@@ -391,10 +412,57 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const GemmP p) {
       }
     }
   }
-  if (!deferred && e.sq_partials) {
+  bool write_sq = !deferred && e.sq_partials;
+  if (deferred && p.counters) {
+    // ---- in-launch split-K reduction (cdna guide §5 "In-launch split-K reduction", sc1 form):
+    // write-through slab stores -> every wave drains vmcnt -> workgroup barrier -> lane 0 relaxed
+    // agent fetch_add; the workgroup that draws nsplit-1 acquires (L1 invalidate) and reduces.
+    // Correct for any placement of a tile's slices over XCDs; the sum runs in split order.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* flag = reinterpret_cast<int*>(smem);
+    if (tid == 0) {
+      unsigned* cnt = p.counters + (size_t)bz * p.tiles_m * p.tiles_n + tn * p.tiles_m + tm;
+      const unsigned prev = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = prev == (unsigned)(p.nsplit - 1);
+      if (last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      *flag = last;
+    }
+    __syncthreads();
+    if (!*flag) return;
+    const float* __restrict__ slab = p.C + (size_t)bz * p.c_batch_stride;
+    float* __restrict__ Cf = p.Cf + (size_t)bz * p.cf_batch_stride;
+#pragma unroll 2
+    for (int j = 0; j < BM / RPP; ++j) {
+      const int row = m0 + tr + j * RPP;
+      if (row < p.M && col < p.N) {
+        const size_t off = (size_t)row * p.ldc + col;
+        float4 s4 = *reinterpret_cast<const float4*>(slab + off);
+#pragma unroll 4
+        for (int k = 1; k < p.nsplit; ++k) {
+          const float4 q = *reinterpret_cast<const float4*>(slab + (size_t)k * p.c_split_stride + off);
+          s4.x += q.x; s4.y += q.y; s4.z += q.z; s4.w += q.w;
+        }
+        float o[4] = {s4.x, s4.y, s4.z, s4.w};
+        if (col + 3 < p.N) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) o[q] = epi_apply(e, o[q], row, col + q, p.ldc, aux, sq);
+          *reinterpret_cast<float4*>(Cf + off) = make_float4(o[0], o[1], o[2], o[3]);
+        } else {
+          for (int q = 0; q < 4 && col + q < p.N; ++q) Cf[off + q] = epi_apply(e, o[q], row, col + q, p.ldc, aux, sq);
+        }
+      }
+    }
+    write_sq = e.sq_partials != nullptr;
+  }
+  if (write_sq) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
-    __syncthreads();   // every wave is done reading the staged tile
+    __syncthreads();   // every wave is done reading the staged tile / the flag
     if (lane == 0) smem[wave] = sq;
     __syncthreads();
     if (tid == 0)
@@ -505,7 +573,7 @@ inline GemmPlan gemm_plan(int M, int N, int K, int nbatch, bool wants_sq, const 
       const double per_wg = (tile == 128 ? 9000.0 : 6000.0) + k_tiles * cyc_tile;   // prologue + epilogue + K walk (K sweep, MI355X)
       const double rounds = std::ceil((double)wgs / GEMM_CUS);
       double us = rounds * per_wg / 2100.0;
-      if (ns > 1) us += 3.0 + (double)(ns + 1) * M * N * nbatch * 4.0 / 3.0e6;   // launch + slab traffic at ~3 TB/s
+      if (ns > 1) us += 1.5 + (double)(ns + 1) * M * N * nbatch * 4.0 / 3.0e6;   // in-launch reduce tail + slab traffic at ~3 TB/s
       if (us < best.est_us) {
         best.est_us = us; best.tile = tile; best.nsplit = ns; best.kps = kps; best.tiles_m = tm; best.tiles_n = tn;
       }
@@ -515,7 +583,7 @@ inline GemmPlan gemm_plan(int M, int N, int K, int nbatch, bool wants_sq, const 
   const long long wgs = (long long)best.tiles_m * best.tiles_n * nbatch * best.nsplit;
   best.ring = tune.ring ? tune.ring : (wgs > GEMM_CUS ? 2 : 3);
   if (best.nsplit == 1) best.kps = ((K + GEMM_K_ALIGN - 1) / GEMM_K_ALIGN) * GEMM_K_ALIGN;
-  best.sq_count = wants_sq ? (best.nsplit > 1 ? GEMM_RED_GRID : best.tiles_m * best.tiles_n) : 0;
+  best.sq_count = wants_sq ? best.tiles_m * best.tiles_n : 0;   // (separate reduce kernel: GEMM_RED_GRID, set by gemm_run)
   return best;
 }
 
@@ -537,12 +605,14 @@ inline hipError_t gemm_launch_t(hipStream_t st, const GemmP& p, bool akm, bool b
 // Logical GEMM: C[bz] = epi(op(A[bz]) . op(B)).  `p` carries the operands, shapes, batch strides
 // and the epilogue; C/ldc/c_batch_stride describe the FINAL output.  slab: workspace for split-K.
 inline hipError_t gemm_run(hipStream_t st, GemmP p, bool akm, bool bkm, const GemmPlan& pl, float* slab,
-                           size_t slab_elems, hipStream_t* /*unused*/ = nullptr) {
+                           size_t slab_elems, unsigned* counters = nullptr, size_t n_counters = 0) {
   if (p.nbatch < 1) p.nbatch = 1;
   if (!p.zero_page || (p.lda % LD_ALIGN) || (p.ldb % LD_ALIGN)) return hipErrorInvalidValue;
   p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n;
   p.nsplit = pl.nsplit; p.k_per_split = pl.kps;
   p.epi.sq_stride = pl.sq_count;
+  p.counters = nullptr;
+  const bool in_launch = pl.nsplit > 1 && counters && (size_t)pl.tiles_m * pl.tiles_n * p.nbatch <= n_counters;
   RedP r{};
   if (pl.nsplit > 1) {
     if (gemm_slab_elems(pl, p.M, p.ldc, p.nbatch) > slab_elems) return hipErrorOutOfMemory;
@@ -551,12 +621,14 @@ inline hipError_t gemm_run(hipStream_t st, GemmP p, bool akm, bool bkm, const Ge
     // slab layout [split][batch][M, ldc]
     r.split_stride = (long long)p.nbatch * p.M * p.ldc;
     if (p.nbatch > 1 && p.c_batch_stride != (long long)p.M * p.ldc) return hipErrorInvalidValue;
+    if (in_launch) { p.counters = counters; p.Cf = p.C; p.cf_batch_stride = p.c_batch_stride; }
+    else if (p.epi.sq_partials) { p.epi.sq_stride = GEMM_RED_GRID; r.epi.sq_stride = GEMM_RED_GRID; }
     p.C = slab; p.c_split_stride = r.split_stride; p.c_batch_stride = (long long)p.M * p.ldc;
   }
   hipError_t e;
   if (pl.tile == 128) e = pl.ring == 3 ? gemm_launch_t<128, 128, 32, 3>(st, p, akm, bkm) : gemm_launch_t<128, 128, 32, 2>(st, p, akm, bkm);
   else e = pl.ring == 3 ? gemm_launch_t<64, 64, 64, 3>(st, p, akm, bkm) : gemm_launch_t<64, 64, 64, 2>(st, p, akm, bkm);
-  if (e != hipSuccess || pl.nsplit == 1) return e;
+  if (e != hipSuccess || pl.nsplit == 1 || in_launch) return e;
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(GEMM_RED_GRID, p.nbatch), dim3(256), 0, st, r);
   return hipGetLastError();
 }
