@@ -189,6 +189,19 @@ def main():
                     "unit": "TFLOP/s", "frac": round(dom_tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
                     "flops_per_launch": dom["flops"] / dom["launches"],
                     "avg_launch_us": round(dom["ms"] / dom["launches"] * 1e3, 2)}
+        # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in
+        # separate runs, gfx950 read correction applied: tools/collect_traffic.py); null when no profile matches
+        try:
+            import glob
+            tf = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))[-1]
+            cands = [v for k, v in json.load(open(tf)).items() if k.startswith(dom["name"])]
+            if cands:
+                best = max(cands, key=lambda v: v["hbm_bytes_per_launch"])
+                roofline["traffic"] = best["hbm_bytes_per_launch"]
+                roofline["traffic_source"] = os.path.basename(tf)
+                roofline["algorithmic_bytes_per_launch"] = best["algorithmic_bytes"]
+        except Exception:
+            pass
         step_flops = sum(p["flops"] for p in prof)
         step_ms = sum(p["ms"] for p in prof)
         roofline["whole_step_tflops_kernel_time"] = round(step_flops / step_ms / 1e9, 2)

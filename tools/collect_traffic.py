@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""HBM traffic per launch of each GEMM class of the bench step from rocprofv3 PMC passes.
+
+    tools/collect_traffic.py PLAN_LOG FETCH_DIR WRITE_DIR > profiles/rNN_traffic.json
+
+PLAN_LOG holds the `[ganmf plan]` lines (GANMF_DEBUG_PLAN=1) mapping a kernel class of the step to its
+template instantiation and grid; FETCH_DIR / WRITE_DIR are the outputs of two separate rocprofv3
+--pmc passes (FETCH_SIZE, WRITE_SIZE: they do not fit one pass, MI355X_MICROARCH §rocprofv3 PMC slots).
+Corrections per MI355X_MICROARCH §HBM: counters are in KiB; on gfx950 FETCH_SIZE reports exactly half
+the bytes of wide coalesced reads (16 B/lane global_load and global_load_lds alike) -> doubled."""
+import collections
+import csv
+import glob
+import json
+import re
+import sys
+
+LAYOUT = {"gemm_generator": ("false", "false"), "gemm_encode": ("false", "true"), "gemm_decode": ("false", "true"),
+          "gemm_dE": ("false", "false"), "gemm_gWd": ("true", "true"), "gemm_gWe": ("true", "true"),
+          "gemm_dF": ("false", "false"), "gemm_gUb": ("false", "true"), "gemm_gV": ("true", "true"),
+          "gemm_scores": ("false", "false")}
+
+
+def counters(d, name):
+    f = glob.glob(d + "/*/*counter_collection.csv")[0]
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == name:
+            acc[(r["Kernel_Name"], r["Grid_Size"])].append(float(r["Counter_Value"]))
+    return acc
+
+
+plan_log, fdir, wdir = sys.argv[1:4]
+fetch, write = counters(fdir, "FETCH_SIZE"), counters(wdir, "WRITE_SIZE")
+out = {}
+for line in open(plan_log):
+    m = re.search(r"\[ganmf plan\] (\S+)\s+M=(\d+) N=(\d+) K=(\d+) batch=(\d+) -> tile (\d+) ring (\d+) nsplit (\d+) \(kps \d+\) wgs (\d+)", line)
+    if not m:
+        continue
+    tag, M, N, K, nb, tile, ring, ns, wgs = m.group(1), *map(int, m.groups()[1:])
+    base = tag.split("[")[0]
+    if base not in LAYOUT:
+        continue
+    a, b = LAYOUT[base]
+    bk = 32 if tile == 128 else 64
+    pat = "gemm_f32_mfma<%d, %d, %d, %d, %s, %s>" % (tile, tile, bk, ring, a, b)
+    key = [k for k in fetch if pat in k[0] and int(k[1]) == wgs * 256]
+    if not key:
+        continue
+    k0 = key[0]
+    f_kib = sum(fetch[k0]) / len(fetch[k0])
+    w_kib = sum(write[k0]) / len(write[k0]) if k0 in write else 0.0
+    name = "%s M=%d N=%d K=%d batch=%d" % (tag, M, N, K, nb)
+    out[name] = {"kernel": pat, "grid_threads": wgs * 256, "launches_sampled": len(fetch[k0]),
+                 "FETCH_SIZE_KiB_raw": round(f_kib, 1), "WRITE_SIZE_KiB_raw": round(w_kib, 1),
+                 "hbm_bytes_per_launch": int((2 * f_kib + w_kib) * 1024),
+                 "algorithmic_bytes": 4 * nb * (M * K + M * N) + 4 * N * K,
+                 "note": "shared (kernel, grid) with another class" if sum(1 for l in open(plan_log) if "wgs %d " % wgs in l and "tile %d " % tile in l) > 1 else ""}
+json.dump(out, sys.stdout, indent=1)
