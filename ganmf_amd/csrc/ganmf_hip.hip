@@ -489,6 +489,50 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
   return 0;
 }
 
+// Generator parameter update shared by GANMF and DisGANMF: gUb = dF.V (reads the OLD V), gV = dF^T.Ub,
+// Adam on V (fused into the gV GEMM epilogue on a single GPU) and the all-rows Adam on U.
+// *regn_v = number of sum(V^2) partials written (when g_reg != 0).
+int gen_update(ganmf_handle* h, int nb, int start, int* regn_v) {
+  const int N = h->N, k = h->k;
+  const bool reg = h->cfg.g_reg != 0.f;
+  const bool fused = h->fuse_adam && !h->has_comm && nb > 0;
+  *regn_v = ADAM_GRID;
+  if (nb > 0) {
+    {  // gUb = dF . V
+      GemmP g{};
+      g.A = h->dF; g.lda = h->ldN; g.B = h->V.p; g.ldb = h->ldk;
+      g.C = h->gUb; g.ldc = h->ldk; g.M = nb; g.N = k; g.K = N; g.epi.kind = EPI_STORE;
+      TRY(run_gemm(h, T_GEMM_GUB, T_RED_GUB, g, false, true));
+    }
+    {  // gV = dF^T . Ub
+      GemmP g{};
+      g.A = h->dF; g.lda = h->ldN; g.B = h->Ub; g.ldb = h->ldk;
+      g.C = h->V.g; g.ldc = h->ldk; g.M = N; g.N = k; g.K = nb; g.epi.kind = EPI_STORE;
+      if (fused) {
+        g.epi.kind = EPI_ADAM; g.epi.adam_theta = h->V.p; g.epi.adam_m = h->V.m; g.epi.adam_v = h->V.v;
+        g.epi.adam_alpha = h->scal + S_ALPHA_G; g.epi.adam_reg = h->cfg.g_reg;
+        g.epi.sq_partials = reg ? h->regp + 3 * h->reg_cap : nullptr;
+      }
+      TRY(run_gemm(h, T_GEMM_GV, T_RED_GV, g, true, true, regn_v, fused ? 24.0 * h->V.count() : 0));
+      if (!fused) *regn_v = ADAM_GRID;
+    }
+  } else {
+    HIP_TRY(hipMemsetAsync(h->V.g, 0, h->V.padded() * sizeof(float), h->st));
+  }
+  if (!fused) {
+    TRY(allreduce(h, h->V.g, h->V.padded()));
+    TRY(adam_dense(h, T_ADAM_V, h->V, h->V.g, S_ALPHA_G, h->cfg.g_reg, reg ? h->regp + 3 * h->reg_cap : nullptr));
+  }
+  {
+    Scope s(h, T_ADAM_U, 0, 24.0 * h->Ue.count());
+    hipLaunchKernelGGL(adam_rows_kernel, dim3(ADAM_GRID), dim3(256), 0, h->st, h->Ue.p, h->Ue.m, h->Ue.v, h->gUb,
+                       h->pos, start, nb, h->U, h->ldk, h->scal, S_ALPHA_G, h->cfg.g_reg,
+                       reg ? h->regp + 2 * h->reg_cap : nullptr);
+    HIP_TRY(hipGetLastError());
+  }
+  return 0;
+}
+
 // One generator update (GANMF.py:133-135,139,200-201).  `start` = position of the batch in the
 // epoch permutation (adam_rows_kernel finds batch rows through pos[]).
 int g_step(ganmf_handle* h, const int* rows_dev, int nb, int start, int b_global, float* parts) {
@@ -524,46 +568,13 @@ int g_step(ganmf_handle* h, const int* rows_dev, int nb, int start, int b_global
       g.epi.kind = EPI_SUB_SCALED_AUX; g.epi.c = rsv; g.epi.aux = h->Dl; g.epi.ldaux = h->ldN;
       TRY(run_gemm(h, T_GEMM_DF, T_RED_DF, g, false, false, nullptr, 4.0 * nb * N));
     }
-    const bool two = h->overlap && !h->has_comm;
-    const bool regG = h->cfg.g_reg != 0.f;
-    if (two) TRY(lane_fork(h));
-    {  // gV = dF^T . Ub      (side lane when overlapping)
-      GemmP g{};
-      g.A = h->dF; g.lda = h->ldN; g.B = h->Ub; g.ldb = h->ldk;
-      g.C = h->V.g; g.ldc = h->ldk; g.M = N; g.N = k; g.K = nb; g.epi.kind = EPI_STORE;
-      TRY(run_gemm(h, T_GEMM_GV, T_RED_GV, g, true, true, nullptr, 0, two ? 1 : 0));
-    }
-    {  // gUb = dF . V
-      GemmP g{};
-      g.A = h->dF; g.lda = h->ldN; g.B = h->V.p; g.ldb = h->ldk;
-      g.C = h->gUb; g.ldc = h->ldk; g.M = nb; g.N = k; g.K = N; g.epi.kind = EPI_STORE;
-      TRY(run_gemm(h, T_GEMM_GUB, T_RED_GUB, g, false, true));
-    }
-    if (two) {
-      // gUb reads the OLD item embeddings: Adam(V) on the side lane waits for it
-      HIP_TRY(hipEventRecord(h->ev_mid, h->st));
-      HIP_TRY(hipStreamWaitEvent(h->st2, h->ev_mid, 0));
-      TRY(adam_dense(h, T_ADAM_V, h->V, h->V.g, S_ALPHA_G, h->cfg.g_reg, regG ? h->regp + 3 * h->reg_cap : nullptr, 1));
-    }
   } else {
     hipLaunchKernelGGL(open_step_kernel, dim3(1), dim3(64), 0, h->st, h->scal, 1, h->cfg.g_lr);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemsetAsync(h->V.g, 0, h->V.padded() * sizeof(float), h->st));
   }
   const bool reg = h->cfg.g_reg != 0.f;
-  const bool overlapped = h->overlap && !h->has_comm && nb > 0;
-  if (!overlapped) {
-    TRY(allreduce(h, h->V.g, h->V.padded()));
-    TRY(adam_dense(h, T_ADAM_V, h->V, h->V.g, S_ALPHA_G, h->cfg.g_reg, reg ? h->regp + 3 * h->reg_cap : nullptr));
-  }
-  {
-    Scope s(h, T_ADAM_U, 0, 24.0 * h->Ue.count());
-    hipLaunchKernelGGL(adam_rows_kernel, dim3(ADAM_GRID), dim3(256), 0, h->st, h->Ue.p, h->Ue.m, h->Ue.v, h->gUb,
-                       h->pos, start, nb, h->U, h->ldk, h->scal, S_ALPHA_G, h->cfg.g_reg,
-                       reg ? h->regp + 2 * h->reg_cap : nullptr);
-    HIP_TRY(hipGetLastError());
-  }
-  if (overlapped) TRY(lane_join(h));
+  int regn_v = ADAM_GRID;
+  TRY(gen_update(h, nb, start, &regn_v));
   {  // parts = {sum Delta_f^2, sum (Ef-Er)^2, sum U^2, sum V^2}
     MultiRed mr{};
     mr.out = parts;
@@ -572,7 +583,7 @@ int g_step(ganmf_handle* h, const int* rows_dev, int nb, int start, int b_global
     mr.count = 2;
     if (reg) {
       mr.e[2] = {h->regp + 2 * h->reg_cap, ADAM_GRID, 2, 0};
-      mr.e[3] = {h->regp + 3 * h->reg_cap, ADAM_GRID, 3, 0};
+      mr.e[3] = {h->regp + 3 * h->reg_cap, regn_v, 3, 0};
       mr.count = 4;
     }
     Scope s(h, T_MULTIRED, 0, 0);
@@ -718,33 +729,13 @@ int dis_g_step(ganmf_handle* h, const int* rows_dev, int nb, int start, int b_gl
       g.C = h->dF; g.ldc = h->ldN; g.M = nb; g.N = N; g.K = e; g.epi.kind = EPI_STORE;
       TRY(run_gemm(h, T_GEMM_DF, T_RED_DF, g, false, false));
     }
-    {  // gUb = dF . V
-      GemmP g{};
-      g.A = h->dF; g.lda = h->ldN; g.B = h->V.p; g.ldb = h->ldk;
-      g.C = h->gUb; g.ldc = h->ldk; g.M = nb; g.N = k; g.K = N; g.epi.kind = EPI_STORE;
-      TRY(run_gemm(h, T_GEMM_GUB, T_RED_GUB, g, false, true));
-    }
-    {  // gV = dF^T . Ub
-      GemmP g{};
-      g.A = h->dF; g.lda = h->ldN; g.B = h->Ub; g.ldb = h->ldk;
-      g.C = h->V.g; g.ldc = h->ldk; g.M = N; g.N = k; g.K = nb; g.epi.kind = EPI_STORE;
-      TRY(run_gemm(h, T_GEMM_GV, T_RED_GV, g, true, true));
-    }
   } else {
     hipLaunchKernelGGL(open_step_kernel, dim3(1), dim3(64), 0, h->st, h->scal, 1, h->cfg.g_lr);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemsetAsync(h->V.g, 0, h->V.padded() * sizeof(float), h->st));
   }
-  TRY(allreduce(h, h->V.g, h->V.padded()));
   const bool reg = h->cfg.g_reg != 0.f;
-  TRY(adam_dense(h, T_ADAM_V, h->V, h->V.g, S_ALPHA_G, h->cfg.g_reg, reg ? h->regp + 3 * h->reg_cap : nullptr));
-  {
-    Scope s(h, T_ADAM_U, 0, 24.0 * h->Ue.count());
-    hipLaunchKernelGGL(adam_rows_kernel, dim3(ADAM_GRID), dim3(256), 0, h->st, h->Ue.p, h->Ue.m, h->Ue.v, h->gUb,
-                       h->pos, start, nb, h->U, h->ldk, h->scal, S_ALPHA_G, h->cfg.g_reg,
-                       reg ? h->regp + 2 * h->reg_cap : nullptr);
-    HIP_TRY(hipGetLastError());
-  }
+  int regn_v = ADAM_GRID;
+  TRY(gen_update(h, nb, start, &regn_v));
   {  // parts = {sum sce(fake), sum (feat_f - feat_r)^2, sum U^2, sum V^2}
     MultiRed mr{};
     mr.out = parts;
@@ -753,7 +744,7 @@ int dis_g_step(ganmf_handle* h, const int* rows_dev, int nb, int start, int b_gl
     mr.count = 2;
     if (reg) {
       mr.e[2] = {h->regp + 2 * h->reg_cap, ADAM_GRID, 2, 0};
-      mr.e[3] = {h->regp + 3 * h->reg_cap, ADAM_GRID, 3, 0};
+      mr.e[3] = {h->regp + 3 * h->reg_cap, regn_v, 3, 0};
       mr.count = 4;
     }
     Scope s(h, T_MULTIRED, 0, 0);
