@@ -146,6 +146,7 @@ struct ganmf_handle {
   int reg_cap = 0;
   bool fuse_adam = true;  // single GPU: Adam runs in the epilogue of the weight-gradient GEMMs
   float *d_parts = nullptr, *g_parts = nullptr;  // [cap][4]
+  float *d_arena = nullptr, *g_arena = nullptr;  // [cap][4][reg_cap] per-step block partials (GANMF), reduced once per epoch
   int64_t parts_cap = 0;
   // scoring scratch
   float *sc_rows = nullptr, *sc_out = nullptr;
@@ -387,7 +388,9 @@ int step_front(ganmf_handle* h, const int* rows_dev, int nb, int which) {
 }
 
 // One discriminator update on local rows rows_dev[0..nb) (GANMF.py:131-132,138,186-187).
-int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* parts) {
+int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* parts, float* arena) {
+  float* regWe = arena + 2 * (size_t)h->reg_cap;   // this step's arena slot: seg2 = sum We_ext^2, seg3 = sum Wd_ext^2
+  float* regWd = arena + 3 * (size_t)h->reg_cap;
   const int N = h->N, e = h->e;
   const bool dist = h->has_comm;
   const float inv_bn = 1.0f / ((float)b_global * (float)N);
@@ -453,7 +456,7 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
       if (fused) {
         g.epi.kind = EPI_ADAM; g.epi.adam_theta = h->Wd.p; g.epi.adam_m = h->Wd.m; g.epi.adam_v = h->Wd.v;
         g.epi.adam_alpha = h->scal + S_ALPHA_D; g.epi.adam_reg = h->cfg.d_reg;
-        g.epi.sq_partials = regD ? h->regp + h->reg_cap : nullptr;
+        g.epi.sq_partials = regD ? regWd : nullptr;
       }
       TRY(run_gemm(h, T_GEMM_GWD, T_RED_GWD, g, true, true, &regn[1], fused ? 24.0 * h->Wd.count() : 0, 0, fused ? &ft : nullptr));
     }
@@ -464,7 +467,7 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
       if (fused) {
         g.epi.kind = EPI_ADAM; g.epi.adam_theta = h->We.p; g.epi.adam_m = h->We.m; g.epi.adam_v = h->We.v;
         g.epi.adam_alpha = h->scal + S_ALPHA_D; g.epi.adam_reg = h->cfg.d_reg;
-        g.epi.sq_partials = regD ? h->regp : nullptr;
+        g.epi.sq_partials = regD ? regWe : nullptr;
       }
       TRY(run_gemm(h, T_GEMM_GWE, T_RED_GWE, g, true, true, &regn[0], fused ? 24.0 * h->We.count() : 0, 0, fused ? &ft : nullptr));
     }
@@ -474,25 +477,17 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
   const bool reg = h->cfg.d_reg != 0.f;
   if (!fused) {
     TRY(allreduce(h, h->gD, h->gD_elems));
-    TRY(adam_dense(h, T_ADAM_D, h->We, h->We.g, S_ALPHA_D, h->cfg.d_reg, reg ? h->regp : nullptr));
-    TRY(adam_dense(h, T_ADAM_D, h->Wd, h->Wd.g, S_ALPHA_D, h->cfg.d_reg, reg ? h->regp + h->reg_cap : nullptr));
-    regn[0] = regn[1] = ADAM_GRID;
+    TRY(adam_dense(h, T_ADAM_D, h->We, h->We.g, S_ALPHA_D, h->cfg.d_reg, reg ? regWe : nullptr));
+    TRY(adam_dense(h, T_ADAM_D, h->Wd, h->Wd.g, S_ALPHA_D, h->cfg.d_reg, reg ? regWd : nullptr));
   }
-  if (reg) {
-    MultiRed mr{};
-    mr.count = 2; mr.out = parts;
-    for (int i = 0; i < 2; ++i) mr.e[i] = {h->regp + i * h->reg_cap, regn[i], 2, i ? 1 : 0};
-    Scope s(h, T_MULTIRED, 0, 0);
-    hipLaunchKernelGGL(multi_reduce_kernel, dim3(1), dim3(256), 0, h->st, mr);
-    HIP_TRY(hipGetLastError());
-  }
-  return 0;
+  (void)regn; (void)parts;
+  return 0;   // the sum(theta^2) partials are reduced once per epoch (finish_parts_kernel)
 }
 
 // Generator parameter update shared by GANMF and DisGANMF: gUb = dF.V (reads the OLD V), gV = dF^T.Ub,
 // Adam on V (fused into the gV GEMM epilogue on a single GPU) and the all-rows Adam on U.
 // *regn_v = number of sum(V^2) partials written (when g_reg != 0).
-int gen_update(ganmf_handle* h, int nb, int start, int* regn_v) {
+int gen_update(ganmf_handle* h, int nb, int start, int* regn_v, float* reg_u, float* reg_v) {
   const int N = h->N, k = h->k;
   const bool reg = h->cfg.g_reg != 0.f;
   const bool fused = h->fuse_adam && !h->has_comm && nb > 0;
@@ -511,7 +506,7 @@ int gen_update(ganmf_handle* h, int nb, int start, int* regn_v) {
       if (fused) {
         g.epi.kind = EPI_ADAM; g.epi.adam_theta = h->V.p; g.epi.adam_m = h->V.m; g.epi.adam_v = h->V.v;
         g.epi.adam_alpha = h->scal + S_ALPHA_G; g.epi.adam_reg = h->cfg.g_reg;
-        g.epi.sq_partials = reg ? h->regp + 3 * h->reg_cap : nullptr;
+        g.epi.sq_partials = reg ? reg_v : nullptr;
       }
       TRY(run_gemm(h, T_GEMM_GV, T_RED_GV, g, true, true, regn_v, fused ? 24.0 * h->V.count() : 0));
       if (!fused) *regn_v = ADAM_GRID;
@@ -521,13 +516,13 @@ int gen_update(ganmf_handle* h, int nb, int start, int* regn_v) {
   }
   if (!fused) {
     TRY(allreduce(h, h->V.g, h->V.padded()));
-    TRY(adam_dense(h, T_ADAM_V, h->V, h->V.g, S_ALPHA_G, h->cfg.g_reg, reg ? h->regp + 3 * h->reg_cap : nullptr));
+    TRY(adam_dense(h, T_ADAM_V, h->V, h->V.g, S_ALPHA_G, h->cfg.g_reg, reg ? reg_v : nullptr));
   }
   {
     Scope s(h, T_ADAM_U, 0, 24.0 * h->Ue.count());
     hipLaunchKernelGGL(adam_rows_kernel, dim3(ADAM_GRID), dim3(256), 0, h->st, h->Ue.p, h->Ue.m, h->Ue.v, h->gUb,
                        h->pos, start, nb, h->U, h->ldk, h->scal, S_ALPHA_G, h->cfg.g_reg,
-                       reg ? h->regp + 2 * h->reg_cap : nullptr);
+                       reg ? reg_u : nullptr);
     HIP_TRY(hipGetLastError());
   }
   return 0;
@@ -535,7 +530,9 @@ int gen_update(ganmf_handle* h, int nb, int start, int* regn_v) {
 
 // One generator update (GANMF.py:133-135,139,200-201).  `start` = position of the batch in the
 // epoch permutation (adam_rows_kernel finds batch rows through pos[]).
-int g_step(ganmf_handle* h, const int* rows_dev, int nb, int start, int b_global, float* parts) {
+int g_step(ganmf_handle* h, const int* rows_dev, int nb, int start, int b_global, float* parts, float* arena) {
+  // this step's arena slot: seg0 = sum Delta_f^2, seg1 = sum (Ef-Er)^2, seg2 = sum U^2, seg3 = sum V^2 partials
+  const size_t cap = h->reg_cap;
   const int N = h->N, e = h->e, k = h->k;
   const float alpha = h->cfg.recon_coefficient;
   const float inv_bn = 1.0f / ((float)b_global * (float)N);
@@ -547,7 +544,7 @@ int g_step(ganmf_handle* h, const int* rows_dev, int nb, int start, int b_global
       g.A = h->E + (size_t)nb * h->lde; g.lda = h->lde; g.B = h->Wd.p; g.ldb = h->ldN;
       g.C = h->Dl; g.ldc = h->ldN; g.M = nb; g.N = N; g.K = e + 1;
       g.epi.kind = EPI_SUB_AUX_SQ; g.epi.aux = h->XF + (size_t)nb * h->ldN; g.epi.ldaux = h->ldN;
-      g.epi.sq_partials = h->sqp;
+      g.epi.sq_partials = arena;
       TRY(run_gemm(h, T_GEMM_DEC, T_RED_DEC, g, false, true, &sqn, 4.0 * nb * N));
     }
     // host constants: rsG = (1-alpha)*2/(B*N) ; cfm = alpha*2/(B*e)
@@ -558,7 +555,7 @@ int g_step(ganmf_handle* h, const int* rows_dev, int nb, int start, int b_global
       g.A = h->Dl; g.lda = h->ldN; g.B = h->Wd.p; g.ldb = h->ldN;
       g.C = h->dE; g.ldc = h->lde; g.M = nb; g.N = e; g.K = N;
       g.epi.kind = EPI_G_DE; g.epi.c = rsv; g.epi.cfm = cfm;
-      g.epi.er = h->E; g.epi.ef = h->E + (size_t)nb * h->lde; g.epi.sq_partials = h->fmp;
+      g.epi.er = h->E; g.epi.ef = h->E + (size_t)nb * h->lde; g.epi.sq_partials = arena + cap;
       TRY(run_gemm(h, T_GEMM_DE, T_RED_DE, g, false, false, &fmn));
     }
     {  // dF = dE . We^T - rsG*Delta_f      (MSE gradient reaches F through both arguments)
@@ -574,22 +571,8 @@ int g_step(ganmf_handle* h, const int* rows_dev, int nb, int start, int b_global
   }
   const bool reg = h->cfg.g_reg != 0.f;
   int regn_v = ADAM_GRID;
-  TRY(gen_update(h, nb, start, &regn_v));
-  {  // parts = {sum Delta_f^2, sum (Ef-Er)^2, sum U^2, sum V^2}
-    MultiRed mr{};
-    mr.out = parts;
-    mr.e[0] = {h->sqp, sqn, 0, 0};
-    mr.e[1] = {h->fmp, fmn, 1, 0};
-    mr.count = 2;
-    if (reg) {
-      mr.e[2] = {h->regp + 2 * h->reg_cap, ADAM_GRID, 2, 0};
-      mr.e[3] = {h->regp + 3 * h->reg_cap, regn_v, 3, 0};
-      mr.count = 4;
-    }
-    Scope s(h, T_MULTIRED, 0, 0);
-    hipLaunchKernelGGL(multi_reduce_kernel, dim3(1), dim3(256), 0, h->st, mr);
-    HIP_TRY(hipGetLastError());
-  }
+  TRY(gen_update(h, nb, start, &regn_v, arena + 2 * cap, arena + 3 * cap));
+  (void)parts; (void)reg; (void)sqn; (void)fmn;
   return 0;
 }
 
@@ -735,7 +718,7 @@ int dis_g_step(ganmf_handle* h, const int* rows_dev, int nb, int start, int b_gl
   }
   const bool reg = h->cfg.g_reg != 0.f;
   int regn_v = ADAM_GRID;
-  TRY(gen_update(h, nb, start, &regn_v));
+  TRY(gen_update(h, nb, start, &regn_v, h->regp + 2 * h->reg_cap, h->regp + 3 * h->reg_cap));
   {  // parts = {sum sce(fake), sum (feat_f - feat_r)^2, sum U^2, sum V^2}
     MultiRed mr{};
     mr.out = parts;
@@ -755,21 +738,47 @@ int dis_g_step(ganmf_handle* h, const int* rows_dev, int nb, int start, int b_gl
 }
 
 // model dispatch
-int any_d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* parts) {
-  return h->cfg.model == GANMF_MODEL_GANMF ? d_step(h, rows_dev, nb, b_global, parts) : dis_d_step(h, rows_dev, nb, b_global, parts);
+int any_d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, int64_t idx) {
+  float* parts = h->d_parts + 4 * idx;
+  return h->cfg.model == GANMF_MODEL_GANMF ? d_step(h, rows_dev, nb, b_global, parts, h->d_arena + (size_t)idx * 4 * h->reg_cap)
+                                           : dis_d_step(h, rows_dev, nb, b_global, parts);
 }
-int any_g_step(ganmf_handle* h, const int* rows_dev, int nb, int start, int b_global, float* parts) {
-  return h->cfg.model == GANMF_MODEL_GANMF ? g_step(h, rows_dev, nb, start, b_global, parts)
+int any_g_step(ganmf_handle* h, const int* rows_dev, int nb, int start, int b_global, int64_t idx) {
+  float* parts = h->g_parts + 4 * idx;
+  return h->cfg.model == GANMF_MODEL_GANMF ? g_step(h, rows_dev, nb, start, b_global, parts, h->g_arena + (size_t)idx * 4 * h->reg_cap)
                                            : dis_g_step(h, rows_dev, nb, start, b_global, parts);
+}
+
+// zero the per-step arenas before a pass / reduce them into the loss parts after it (GANMF)
+int arenas_begin(ganmf_handle* h, int64_t nd, int64_t ng) {
+  if (h->cfg.model != GANMF_MODEL_GANMF) return 0;
+  if (nd > 0) HIP_TRY(hipMemsetAsync(h->d_arena, 0, (size_t)nd * 4 * h->reg_cap * sizeof(float), h->st));
+  if (ng > 0) HIP_TRY(hipMemsetAsync(h->g_arena, 0, (size_t)ng * 4 * h->reg_cap * sizeof(float), h->st));
+  return 0;
+}
+int arenas_finish(ganmf_handle* h, int64_t nd, int64_t ng) {
+  if (h->cfg.model != GANMF_MODEL_GANMF) return 0;
+  Scope s(h, T_MULTIRED, 0, 4.0 * (nd + ng) * 4 * h->reg_cap);
+  if (nd > 0) hipLaunchKernelGGL(finish_parts_kernel, dim3((int)nd), dim3(256), 0, h->st, h->d_arena, h->reg_cap, 0, h->d_parts);
+  if (ng > 0) hipLaunchKernelGGL(finish_parts_kernel, dim3((int)ng), dim3(256), 0, h->st, h->g_arena, h->reg_cap, 1, h->g_parts);
+  HIP_TRY(hipGetLastError());
+  return 0;
 }
 
 int ensure_parts(ganmf_handle* h, int64_t steps) {
   if (steps <= h->parts_cap) return 0;
+  HIP_TRY(hipStreamSynchronize(h->st));
   if (h->d_parts) hipFree(h->d_parts);
   if (h->g_parts) hipFree(h->g_parts);
   h->parts_cap = steps + 64;
   TRY(dalloc(&h->d_parts, (size_t)h->parts_cap * 4));
   TRY(dalloc(&h->g_parts, (size_t)h->parts_cap * 4));
+  if (h->cfg.model == GANMF_MODEL_GANMF) {
+    if (h->d_arena) hipFree(h->d_arena);
+    if (h->g_arena) hipFree(h->g_arena);
+    TRY(dalloc(&h->d_arena, (size_t)h->parts_cap * 4 * h->reg_cap));
+    TRY(dalloc(&h->g_arena, (size_t)h->parts_cap * 4 * h->reg_cap));
+  }
   return 0;
 }
 
@@ -917,8 +926,11 @@ int ganmf_create(const ganmf_cfg* cfg, ganmf_handle** out) {
   TRY(dalloc(&h->sqp, (size_t)2 * std::max(GEMM_RED_GRID, ((B + 63) / 64) * ((N + 63) / 64)) + 16));
   // FM partials: one per tile of the [B, e] dE output or per reduce block
   TRY(dalloc(&h->fmp, std::max(RED_GRID, ((B + 63) / 64) * ((e + 63) / 64) + (e + 64) / 64 + 1)));
-  h->reg_cap = std::max(ADAM_GRID, ((std::max(N, e) + 1 + 63) / 64) * ((std::max(N, e) + 63) / 64 + 1));
-  h->reg_cap = std::min(h->reg_cap, 1 << 20);
+  {
+    auto t64 = [](int a, int b) { return ((a + 63) / 64) * ((b + 63) / 64); };
+    h->reg_cap = std::max({ADAM_GRID, (int)GEMM_RED_GRID, t64(N + 2, e), t64(e + 1, N), t64(N, k), t64(B, N), t64(B, e)});
+    h->reg_cap = round_up(h->reg_cap, 64);
+  }
   TRY(dalloc(&h->regp, (size_t)(4 + 17 + 1) * h->reg_cap));
   const float pw[4] = {ADAM_B1, ADAM_B2, ADAM_B1, ADAM_B2};
   HIP_TRY(hipMemcpy(h->scal, pw, sizeof pw, hipMemcpyHostToDevice));
@@ -941,7 +953,7 @@ int ganmf_destroy(ganmf_handle* h) {
   hipFree(h->gD); hipFree(h->indptr); hipFree(h->indices); hipFree(h->data); hipFree(h->perm); hipFree(h->pos);
   hipFree(h->XF); hipFree(h->Ub); hipFree(h->E); hipFree(h->Dl); hipFree(h->dE); hipFree(h->dF); hipFree(h->gUb);
   hipFree(h->slab); hipFree(h->rs); hipFree(h->scal); hipFree(h->sqp); hipFree(h->fmp);
-  hipFree(h->regp); hipFree(h->d_parts); hipFree(h->g_parts); hipFree(h->sc_rows); hipFree(h->sc_out);
+  hipFree(h->regp); hipFree(h->d_parts); hipFree(h->g_parts); hipFree(h->d_arena); hipFree(h->g_arena); hipFree(h->sc_rows); hipFree(h->sc_out);
   for (auto& r : h->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
   hipStreamSynchronize(h->st2);
   hipEventDestroy(h->ev_fork); hipEventDestroy(h->ev_join); hipEventDestroy(h->ev_mid);
@@ -1081,20 +1093,22 @@ int ganmf_train_epoch(ganmf_handle* h, const int32_t* perm, int64_t n, int32_t d
   TRY(ensure_parts(h, std::max(nd, ng)));
   HIP_TRY(hipMemsetAsync(h->d_parts, 0, (size_t)std::max<int64_t>(nd, 1) * 4 * sizeof(float), h->st));
   HIP_TRY(hipMemsetAsync(h->g_parts, 0, (size_t)std::max<int64_t>(ng, 1) * 4 * sizeof(float), h->st));
+  TRY(arenas_begin(h, nd, ng));
   int64_t idx = 0;
   for (int p = 0; p < d_steps; ++p)
     for (int64_t i = 0; i < per_pass; ++i, ++idx) {
       const int64_t a = i * B;
       const int nb = (int)std::max<int64_t>(0, std::min<int64_t>(B, n - a));
-      TRY(any_d_step(h, h->perm + std::min<int64_t>(a, std::max<int64_t>(n - 1, 0)), nb, bglob[i], h->d_parts + 4 * idx));
+      TRY(any_d_step(h, h->perm + std::min<int64_t>(a, std::max<int64_t>(n - 1, 0)), nb, bglob[i], idx));
     }
   idx = 0;
   for (int p = 0; p < g_steps; ++p)
     for (int64_t i = 0; i < per_pass; ++i, ++idx) {
       const int64_t a = i * B;
       const int nb = (int)std::max<int64_t>(0, std::min<int64_t>(B, n - a));
-      TRY(any_g_step(h, h->perm + std::min<int64_t>(a, std::max<int64_t>(n - 1, 0)), nb, (int)a, bglob[i], h->g_parts + 4 * idx));
+      TRY(any_g_step(h, h->perm + std::min<int64_t>(a, std::max<int64_t>(n - 1, 0)), nb, (int)a, bglob[i], idx));
     }
+  TRY(arenas_finish(h, nd, ng));
   if (dist && ng > 0) TRY(allreduce(h, h->g_parts, (size_t)ng * 4));
   std::vector<float> dp((size_t)std::max<int64_t>(nd, 1) * 4), gp((size_t)std::max<int64_t>(ng, 1) * 4);
   HIP_TRY(hipMemcpyAsync(dp.data(), h->d_parts, dp.size() * sizeof(float), hipMemcpyDeviceToHost, h->st));
@@ -1122,8 +1136,10 @@ int ganmf_train_step(ganmf_handle* h, int kind, const int32_t* uids, int32_t n, 
   HIP_TRY(hipMemcpyAsync(h->pos, pos.data(), (size_t)h->U * sizeof(int), hipMemcpyHostToDevice, h->st));
   HIP_TRY(hipMemsetAsync(h->d_parts, 0, 4 * sizeof(float), h->st));
   HIP_TRY(hipMemsetAsync(h->g_parts, 0, 4 * sizeof(float), h->st));
-  if (kind == 0) TRY(any_d_step(h, h->perm, n, n, h->d_parts));
-  else TRY(any_g_step(h, h->perm, n, 0, n, h->g_parts));
+  TRY(arenas_begin(h, kind == 0, kind == 1));
+  if (kind == 0) TRY(any_d_step(h, h->perm, n, n, 0));
+  else TRY(any_g_step(h, h->perm, n, 0, n, 0));
+  TRY(arenas_finish(h, kind == 0, kind == 1));
   std::vector<float> dp(4), gp(4);
   HIP_TRY(hipMemcpyAsync(dp.data(), h->d_parts, 4 * sizeof(float), hipMemcpyDeviceToHost, h->st));
   HIP_TRY(hipMemcpyAsync(gp.data(), h->g_parts, 4 * sizeof(float), hipMemcpyDeviceToHost, h->st));

@@ -117,6 +117,27 @@ __global__ __launch_bounds__(256) void multi_reduce_kernel(const MultiRed mr) {
   }
 }
 
+// Per-step loss parts, once per epoch: block i sums the four partial segments (cap floats each, unused
+// entries zero) that step i's kernels left in its arena slot.  mode 0 (D): parts[i][2] = seg2 + seg3
+// (sum theta_D^2 of the two folded tensors); mode 1 (G): parts[i][s] = seg_s, s = 0..3.
+__global__ __launch_bounds__(256) void finish_parts_kernel(const float* __restrict__ arena, int cap, int mode,
+                                                           float* __restrict__ parts) {
+  __shared__ float red[4];
+  const float* a = arena + (size_t)blockIdx.x * 4 * cap;
+  float tot[4];
+  for (int sgm = 0; sgm < 4; ++sgm) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < cap; i += 256) s += a[(size_t)sgm * cap + i];
+    tot[sgm] = block_sum_256(s, red);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    float* p = parts + (size_t)blockIdx.x * 4;
+    if (mode == 0) p[2] = tot[2] + tot[3];
+    else { p[0] = tot[0]; p[1] = tot[1]; p[2] = tot[2]; p[3] = tot[3]; }
+  }
+}
+
 // Discriminator scalars (GANMF.py:131-132): Lr, Lf, hinge and the backward row scales
 // rs[r] = c_path * 2/(B*N) with c_real = 1 + m*[h>0], c_fake = -[h>0]; loss_parts[0] = Lr + max(0,h).
 // Every block recomputes the two sums from the partials in the same fixed order (identical result
