@@ -117,6 +117,8 @@ def main():
     except Exception:
         if world > 1:
             raise
+    if torch is not None and torch.cuda.is_available():
+        torch.cuda.set_device(local_rank)      # torch.cuda.synchronize() below must target this rank's GPU
     if world > 1:
         os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         dist.init_process_group("gloo", rank=rank, world_size=world)   # control plane only
