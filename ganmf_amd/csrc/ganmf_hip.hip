@@ -260,10 +260,11 @@ float* slot_ptr(Tensor* t, int slot) {
 inline double gemm_flops(double M, double N, double K) { return 2.0 * M * N * K; }
 inline double gemm_bytes(double M, double N, double K) { return 4.0 * (M * K + N * K + M * N); }
 
-int allreduce(ganmf_handle* h, float* buf, size_t count) {
+int allreduce(ganmf_handle* h, float* buf, size_t count, int lane = 0) {
   if (!h->has_comm) return 0;
-  Scope s(h, T_ALLREDUCE, 0, 4.0 * count);
-  NCCL_TRY(ncclAllReduce(buf, buf, count, ncclFloat, ncclSum, h->comm, h->st));
+  hipStream_t st = lane ? h->st2 : h->st;
+  Scope s(h, T_ALLREDUCE, 0, 4.0 * count, st);
+  NCCL_TRY(ncclAllReduce(buf, buf, count, ncclFloat, ncclSum, h->comm, st));
   return 0;
 }
 
@@ -436,20 +437,9 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
   if (nb > 0) {
     const bool regD = h->cfg.d_reg != 0.f;
     fused = h->fuse_adam && !dist;
-    {  // dE = rs * (Delta . Wd^T)          (bias row e of Wd_ext is not part of this product; reads the OLD Wd)
-      GemmP g{};
-      g.A = h->Dl; g.lda = h->ldN; g.B = h->Wd.p; g.ldb = h->ldN;
-      g.C = h->dE; g.ldc = h->lde; g.M = 2 * nb; g.N = e; g.K = N;
-      g.epi.kind = EPI_ROWSCALE; g.epi.rowscale = h->rs;
-      TRY(run_gemm(h, T_GEMM_DE, T_RED_DE, g, false, false));
-    }
-    // Weight-gradient GEMMs.  Single GPU: the gradient tile never leaves the CU -- the epilogue
-    // applies TF-Adam to theta/m/v in place (64x64 tiles, two workgroups per CU, so one
-    // workgroup's HBM-bound Adam phase overlaps its neighbour's MFMA phase).  Data-parallel: the
-    // gradients are stored, all-reduced and a separate Adam kernel follows.
     GemmTune ft;
     ft.tile = 64; ft.ring = 2; ft.nsplit = 1;
-    {  // gWd_ext = (rs*[E|1])^T . Delta   -> rows 0..e-1 = gWd, row e = gbd
+    auto gemm_gWd = [&]() -> int {  // gWd_ext = (rs*[E|1])^T . Delta   -> rows 0..e-1 = gWd, row e = gbd
       GemmP g{};
       g.A = h->Es; g.lda = h->lde; g.B = h->Dl; g.ldb = h->ldN;
       g.C = h->Wd.g; g.ldc = h->ldN; g.M = e + 1; g.N = N; g.K = 2 * nb; g.epi.kind = EPI_STORE;
@@ -458,8 +448,26 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
         g.epi.adam_alpha = h->scal + S_ALPHA_D; g.epi.adam_reg = h->cfg.d_reg;
         g.epi.sq_partials = regD ? regWd : nullptr;
       }
-      TRY(run_gemm(h, T_GEMM_GWD, T_RED_GWD, g, true, true, &regn[1], fused ? 24.0 * h->Wd.count() : 0, 0, fused ? &ft : nullptr));
+      return run_gemm(h, T_GEMM_GWD, T_RED_GWD, g, true, true, &regn[1], fused ? 24.0 * h->Wd.count() : 0, 0, fused ? &ft : nullptr);
+    };
+    // Data-parallel: the decoder gradient is produced first and its all-reduce runs on the side
+    // lane under the dE and gWe_ext GEMMs (xGMI transfer hidden behind MFMA work).
+    if (dist) {
+      TRY(gemm_gWd());
+      TRY(lane_fork(h));
+      TRY(allreduce(h, h->Wd.g, h->Wd.padded(), 1));
     }
+    {  // dE = rs * (Delta . Wd^T)          (bias row e of Wd_ext is not part of this product; reads the OLD Wd)
+      GemmP g{};
+      g.A = h->Dl; g.lda = h->ldN; g.B = h->Wd.p; g.ldb = h->ldN;
+      g.C = h->dE; g.ldc = h->lde; g.M = 2 * nb; g.N = e; g.K = N;
+      g.epi.kind = EPI_ROWSCALE; g.epi.rowscale = h->rs;
+      TRY(run_gemm(h, T_GEMM_DE, T_RED_DE, g, false, false));
+    }
+    // Weight-gradient GEMMs.  Single GPU: the gradient tile never leaves the CU -- the epilogue
+    // applies TF-Adam to theta/m/v in place (after dE, which reads the old decoder).
+    // Data-parallel: the gradients are stored, all-reduced and a separate Adam kernel follows.
+    if (!dist) TRY(gemm_gWd());
     {  // gWe_ext = [X;F | 1]^T . dE       -> rows 0..N-1 = gWe, row N = gbe
       GemmP g{};
       g.A = h->XF; g.lda = h->ldN; g.B = h->dE; g.ldb = h->lde;
@@ -473,11 +481,16 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
     }
   } else {
     HIP_TRY(hipMemsetAsync(h->gD, 0, h->gD_elems * sizeof(float), h->st));
+    if (dist) {   // same collective order as the ranks that have rows
+      TRY(lane_fork(h));
+      TRY(allreduce(h, h->Wd.g, h->Wd.padded(), 1));
+    }
   }
   const bool reg = h->cfg.d_reg != 0.f;
   if (!fused) {
-    TRY(allreduce(h, h->gD, h->gD_elems));
+    if (dist) TRY(allreduce(h, h->We.g, h->We.padded()));
     TRY(adam_dense(h, T_ADAM_D, h->We, h->We.g, S_ALPHA_D, h->cfg.d_reg, reg ? regWe : nullptr));
+    if (dist) TRY(lane_join(h));
     TRY(adam_dense(h, T_ADAM_D, h->Wd, h->Wd.g, S_ALPHA_D, h->cfg.d_reg, reg ? regWd : nullptr));
   }
   (void)regn; (void)parts;
@@ -490,33 +503,40 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
 int gen_update(ganmf_handle* h, int nb, int start, int* regn_v, float* reg_u, float* reg_v) {
   const int N = h->N, k = h->k;
   const bool reg = h->cfg.g_reg != 0.f;
-  const bool fused = h->fuse_adam && !h->has_comm && nb > 0;
+  const bool dist = h->has_comm;
+  const bool fused = h->fuse_adam && !dist && nb > 0;
   *regn_v = ADAM_GRID;
-  if (nb > 0) {
-    {  // gUb = dF . V
-      GemmP g{};
-      g.A = h->dF; g.lda = h->ldN; g.B = h->V.p; g.ldb = h->ldk;
-      g.C = h->gUb; g.ldc = h->ldk; g.M = nb; g.N = k; g.K = N; g.epi.kind = EPI_STORE;
-      TRY(run_gemm(h, T_GEMM_GUB, T_RED_GUB, g, false, true));
+  auto gemm_gUb = [&]() -> int {  // gUb = dF . V     (reads the OLD V)
+    GemmP g{};
+    g.A = h->dF; g.lda = h->ldN; g.B = h->V.p; g.ldb = h->ldk;
+    g.C = h->gUb; g.ldc = h->ldk; g.M = nb; g.N = k; g.K = N; g.epi.kind = EPI_STORE;
+    return run_gemm(h, T_GEMM_GUB, T_RED_GUB, g, false, true);
+  };
+  auto gemm_gV = [&]() -> int {   // gV = dF^T . Ub
+    GemmP g{};
+    g.A = h->dF; g.lda = h->ldN; g.B = h->Ub; g.ldb = h->ldk;
+    g.C = h->V.g; g.ldc = h->ldk; g.M = N; g.N = k; g.K = nb; g.epi.kind = EPI_STORE;
+    if (fused) {
+      g.epi.kind = EPI_ADAM; g.epi.adam_theta = h->V.p; g.epi.adam_m = h->V.m; g.epi.adam_v = h->V.v;
+      g.epi.adam_alpha = h->scal + S_ALPHA_G; g.epi.adam_reg = h->cfg.g_reg;
+      g.epi.sq_partials = reg ? reg_v : nullptr;
     }
-    {  // gV = dF^T . Ub
-      GemmP g{};
-      g.A = h->dF; g.lda = h->ldN; g.B = h->Ub; g.ldb = h->ldk;
-      g.C = h->V.g; g.ldc = h->ldk; g.M = N; g.N = k; g.K = nb; g.epi.kind = EPI_STORE;
-      if (fused) {
-        g.epi.kind = EPI_ADAM; g.epi.adam_theta = h->V.p; g.epi.adam_m = h->V.m; g.epi.adam_v = h->V.v;
-        g.epi.adam_alpha = h->scal + S_ALPHA_G; g.epi.adam_reg = h->cfg.g_reg;
-        g.epi.sq_partials = reg ? reg_v : nullptr;
-      }
-      TRY(run_gemm(h, T_GEMM_GV, T_RED_GV, g, true, true, regn_v, fused ? 24.0 * h->V.count() : 0));
-      if (!fused) *regn_v = ADAM_GRID;
-    }
+    TRY(run_gemm(h, T_GEMM_GV, T_RED_GV, g, true, true, regn_v, fused ? 24.0 * h->V.count() : 0));
+    if (!fused) *regn_v = ADAM_GRID;
+    return 0;
+  };
+  if (dist) {
+    // data-parallel: gV first, its all-reduce runs on the side lane under gUb and the Adam pass over U
+    if (nb > 0) TRY(gemm_gV());
+    else HIP_TRY(hipMemsetAsync(h->V.g, 0, h->V.padded() * sizeof(float), h->st));
+    TRY(lane_fork(h));
+    TRY(allreduce(h, h->V.g, h->V.padded(), 1));
+    if (nb > 0) TRY(gemm_gUb());
+  } else if (nb > 0) {
+    TRY(gemm_gUb());
+    TRY(gemm_gV());      // fused: Adam(V) in the epilogue, after gUb has read the old V
   } else {
     HIP_TRY(hipMemsetAsync(h->V.g, 0, h->V.padded() * sizeof(float), h->st));
-  }
-  if (!fused) {
-    TRY(allreduce(h, h->V.g, h->V.padded()));
-    TRY(adam_dense(h, T_ADAM_V, h->V, h->V.g, S_ALPHA_G, h->cfg.g_reg, reg ? reg_v : nullptr));
   }
   {
     Scope s(h, T_ADAM_U, 0, 24.0 * h->Ue.count());
@@ -524,6 +544,10 @@ int gen_update(ganmf_handle* h, int nb, int start, int* regn_v, float* reg_u, fl
                        h->pos, start, nb, h->U, h->ldk, h->scal, S_ALPHA_G, h->cfg.g_reg,
                        reg ? reg_u : nullptr);
     HIP_TRY(hipGetLastError());
+  }
+  if (!fused) {
+    if (dist) TRY(lane_join(h));
+    TRY(adam_dense(h, T_ADAM_V, h->V, h->V.g, S_ALPHA_G, h->cfg.g_reg, reg ? reg_v : nullptr));
   }
   return 0;
 }
