@@ -918,7 +918,7 @@ int ganmf_create(const ganmf_cfg* cfg, ganmf_handle** out) {
     for (int l = 0; l < h->L; ++l) { h->Wl[l].g = gp; gp += h->Wl[l].padded(); }
     h->Wo.g = gp;
   }
-  TRY(dalloc(&h->zero_page, 64));
+  TRY(dalloc(&h->zero_page, 1024 + 64));   // 4 KiB: one 16-byte line per lane of a workgroup
   TRY(dalloc((float**)&h->perm, U));
   TRY(dalloc((float**)&h->pos, U));
   TRY(dalloc(&h->XF, (size_t)2 * B * h->ldN));
@@ -1318,7 +1318,7 @@ int ganmf_gemm_f32(int device, const float* A, const float* B, float* C, int64_t
   const int br = b_kmajor ? K : N, bc = b_kmajor ? N : K;
   const int lda = round_up(ac, LD_ALIGN), ldb = round_up(bc, LD_ALIGN), ldc = round_up((int)N, LD_ALIGN);
   float *dA = nullptr, *dB = nullptr, *dC = nullptr, *slab = nullptr, *zp = nullptr;
-  TRY(dalloc(&zp, 64));
+  TRY(dalloc(&zp, 1024 + 64));
   TRY(dalloc(&dA, (size_t)ar * lda)); TRY(dalloc(&dB, (size_t)br * ldb)); TRY(dalloc(&dC, (size_t)M * ldc));
   HIP_TRY(hipMemcpy2D(dA, (size_t)lda * 4, A, (size_t)ac * 4, (size_t)ac * 4, ar, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy2D(dB, (size_t)ldb * 4, B, (size_t)bc * 4, (size_t)bc * 4, br, hipMemcpyHostToDevice));

@@ -139,7 +139,7 @@ struct GemmP {
   float* C;
   int lda, ldb, ldc;
   int M, N, K;
-  const float* zero_page;  // >= 16 bytes of zeros in device memory
+  const float* zero_page;  // >= 4 KiB of zeros in device memory (out-of-range lanes read zero_page + 16 B * (tid & 255))
   int nsplit;              // >= 1; > 1: C is the slab, epilogue deferred to splitk_reduce_kernel
   int k_per_split;         // multiple of BK
   long long c_split_stride;
@@ -170,11 +170,14 @@ struct Stage {
   // rows that share a 64-dword LDS bank row differ in bit 0 (BK=32) or not at all (BK=64)
   __device__ static inline int swz(int row) { return (row / (64 / BK)) & (S - 1); }
 
+  const float* zp;        // this lane's own line of the zero page
   const float* ptr[NP];   // per-lane source address of the next tile (KM: before validity select)
   int aux[NP];            // !KM: pointer increment per tile (0 for zero-page lanes); KM: k-row or -1
 
   __device__ inline void init(const float* __restrict__ base, int ld, int r0, int rlimit, int kbeg,
-                              const float* __restrict__ zero, int tid) {
+                              const float* zero, int tid) {
+    zero += (tid & 255) * 4;   // distinct lines per lane: no single-line hot spot
+    zp = zero;
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
       const int pos = j * 256 + tid;
@@ -199,10 +202,10 @@ struct Stage {
     for (int j = 0; j < NP; ++j) {
       const float* src;
       if constexpr (!KM) {
-        src = kleft > 0 ? ptr[j] : zero;
+        src = kleft > 0 ? ptr[j] : zp;
         ptr[j] += aux[j];
       } else {
-        src = (aux[j] >= 0 && aux[j] < kleft) ? ptr[j] : zero;
+        src = (aux[j] >= 0 && aux[j] < kleft) ? ptr[j] : zp;
         ptr[j] += (size_t)BK * ld;
       }
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -291,17 +294,21 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const GemmP p) {
       }
   };
 
-  // prologue: tiles 0 .. NS-1 in flight (tiles past the K range come from the zero page so that
-  // the vmcnt bookkeeping below stays a compile-time constant)
+  // prologue: tiles 0 .. min(NS, nt)-1 in flight.  No loads are issued past the K range (a dummy tile
+  // makes every lane of every workgroup read the same zero-page line: an L2 hot spot that cost
+  // 20-40 us on the short-K GEMMs); the tail therefore waits with vmcnt(0) instead of the counted wait.
   int kleft = kend - kbeg;   // k's remaining from the next tile to issue
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
-    la.issue(smem + s * BUF, p.lda, kleft, p.zero_page, wave);
-    lb.issue(smem + s * BUF + SA::SZ, p.ldb, kleft, p.zero_page, wave);
+    if (kleft > 0) {
+      la.issue(smem + s * BUF, p.lda, kleft, p.zero_page, wave);
+      lb.issue(smem + s * BUF + SA::SZ, p.ldb, kleft, p.zero_page, wave);
+    }
     kleft -= BK;
   }
-  GANMF_WAIT_VMCNT((NS - 1) * LOADS);   // tile 0 of this wave has landed ...
-  __builtin_amdgcn_s_barrier();         // ... and of every other wave
+  if (nt >= NS) GANMF_WAIT_VMCNT((NS - 1) * LOADS);   // tile 0 of this wave has landed ...
+  else GANMF_WAIT_VMCNT(0);
+  __builtin_amdgcn_s_barrier();                        // ... and of every other wave
   load_frags(0, smem, 0);
 
   int slot = 0;   // ring slot of tile `it`
@@ -315,13 +322,18 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const GemmP p) {
         __builtin_amdgcn_sched_barrier(0);       // keep the reads ahead of the MFMAs (hipcc sinks them)
       } else {
         // Last chunk: its fragments are in registers once lgkmcnt drains, so this wave no longer
-        // reads slot `slot`.  Tile it+1 has landed when at most NS-2 younger tiles are outstanding;
-        // after the barrier that holds for every wave and slot `slot` is free for tile it+NS.
+        // reads slot `slot`.  Tile it+1 has landed when at most NS-2 younger tiles are outstanding
+        // (tiles it+2 .. it+NS-1 exist only while it+NS-1 < nt; in the tail nothing younger is in
+        // flight and the wait is vmcnt(0)); after the barrier that holds for every wave and slot
+        // `slot` is free for tile it+NS.
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        GANMF_WAIT_VMCNT((NS - 2) * LOADS);
+        if (it + NS - 1 < nt) GANMF_WAIT_VMCNT((NS - 2) * LOADS);
+        else GANMF_WAIT_VMCNT(0);
         __builtin_amdgcn_s_barrier();
-        la.issue(smem + slot * BUF, p.lda, kleft, p.zero_page, wave);
-        lb.issue(smem + slot * BUF + SA::SZ, p.ldb, kleft, p.zero_page, wave);
+        if (kleft > 0) {
+          la.issue(smem + slot * BUF, p.lda, kleft, p.zero_page, wave);
+          lb.issue(smem + slot * BUF + SA::SZ, p.ldb, kleft, p.zero_page, wave);
+        }
         kleft -= BK;
         load_frags(0, smem + nslot * BUF, 0);    // first fragments of tile it+1 under the last MFMAs
         __builtin_amdgcn_sched_barrier(0);
@@ -330,7 +342,7 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const GemmP p) {
     }
     slot = nslot;
   }
-  // drain the (zero-page) tiles still in flight before LDS is reused / the block exits
+  // nothing is in flight any more; LDS reads must be done before the ring is reused as C staging
   GANMF_WAIT_VMCNT(0);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
