@@ -31,6 +31,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <type_traits>
 
 namespace ganmf {
 
@@ -197,21 +198,30 @@ struct Stage {
   }
 
   // issue the glds of one tile into LDS at `s`; kleft = kend - k0 of this tile (<= 0: dummy tile)
-  __device__ inline void issue(float* s, int ld, int kleft, const float* __restrict__ zero, int wave) {
-#pragma unroll
-    for (int j = 0; j < NP; ++j) {
-      const float* src;
-      if constexpr (!KM) {
-        src = kleft > 0 ? ptr[j] : zp;
-        ptr[j] += aux[j];
-      } else {
-        src = (aux[j] >= 0 && aux[j] < kleft) ? ptr[j] : zp;
-        ptr[j] += (size_t)BK * ld;
-      }
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(s + (j * 256 + wave * 64) * 4),
-                                       16, 0, 0);
+  // one glds piece (1 KiB per wave) of the tile that starts kleft k's before the end of the K range
+  template <int J>
+  __device__ inline void issue_piece(float* s, int ld, int kleft, int wave) {
+    const float* src;
+    if constexpr (!KM) {
+      src = kleft > 0 ? ptr[J] : zp;
+      ptr[J] += aux[J];
+    } else {
+      src = (aux[J] >= 0 && aux[J] < kleft) ? ptr[J] : zp;
+      ptr[J] += (size_t)BK * ld;
     }
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(s + (J * 256 + wave * 64) * 4),
+                                     16, 0, 0);
+  }
+  template <int J0, int J1>
+  __device__ inline void issue_range(float* s, int ld, int kleft, int wave) {
+    if constexpr (J0 < J1) {
+      issue_piece<J0>(s, ld, kleft, wave);
+      issue_range<J0 + 1, J1>(s, ld, kleft, wave);
+    }
+  }
+  __device__ inline void issue(float* s, int ld, int kleft, const float* __restrict__ zero, int wave) {
+    issue_range<0, NP>(s, ld, kleft, wave);
   }
 
   // fragment for the 32-row MFMA block starting at tile row `rb`, chunk c (8 k's), lane (i, h):
@@ -311,7 +321,27 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const GemmP p) {
   __builtin_amdgcn_s_barrier();                        // ... and of every other wave
   load_frags(0, smem, 0);
 
-  int slot = 0;   // ring slot of tile `it`
+  // The refill of a freed ring slot is spread over the chunks of the FOLLOWING tile, LOADS / NC glds per
+  // chunk: a single wave per SIMD issues in order, so the ~60 address/issue instructions of a whole
+  // tile in one block stall the MFMA pipe at every tile boundary; one or two pieces per chunk hide in
+  // the MFMA gaps.  (All pieces of a tile are still issued between two boundary waits, so the counted
+  // vmcnt bookkeeping is unchanged.)
+  constexpr int PPC = (LOADS + NC - 1) / NC;      // pieces per chunk
+  int slot = 0;         // ring slot of tile `it`
+  int pend_slot = 0;    // slot being refilled during this tile (freed at the previous boundary)
+  int pend_kleft = 0;   // <= 0: nothing to refill
+  auto refill_chunk = [&](auto cc) {
+    constexpr int c = decltype(cc)::value;
+    if (pend_kleft > 0) {
+      float* base = smem + pend_slot * BUF;
+      constexpr int q0 = c * PPC, q1 = (c + 1) * PPC < LOADS ? (c + 1) * PPC : LOADS;
+      // pieces [0, NP_A) belong to A, [NP_A, LOADS) to B
+      constexpr int a0 = q0 < SA::NP ? q0 : SA::NP, a1 = q1 < SA::NP ? q1 : SA::NP;
+      constexpr int b0 = q0 > SA::NP ? q0 - SA::NP : 0, b1 = q1 > SA::NP ? q1 - SA::NP : 0;
+      la.template issue_range<a0, a1>(base, p.lda, pend_kleft, wave);
+      lb.template issue_range<b0, b1>(base + SA::SZ, p.ldb, pend_kleft, wave);
+    }
+  };
   for (int it = 0; it < nt; ++it) {
     const float* __restrict__ cur = smem + slot * BUF;
     const int nslot = (slot + 1 == NS) ? 0 : slot + 1;
@@ -319,21 +349,30 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const GemmP p) {
     for (int c = 0; c < NC; ++c) {
       if (c + 1 < NC) {
         load_frags((c + 1) & 1, cur, c + 1);     // next chunk's fragments under this chunk's MFMAs
+        if (c == 0) refill_chunk(std::integral_constant<int, 0>{});
+        else if (c == 1) refill_chunk(std::integral_constant<int, 1>{});
+        else if (c == 2) refill_chunk(std::integral_constant<int, 2>{});
+        else if (c == 3) refill_chunk(std::integral_constant<int, 3>{});
+        else if (c == 4) refill_chunk(std::integral_constant<int, 4>{});
+        else if (c == 5) refill_chunk(std::integral_constant<int, 5>{});
+        else if (c == 6) refill_chunk(std::integral_constant<int, 6>{});
         __builtin_amdgcn_sched_barrier(0);       // keep the reads ahead of the MFMAs (hipcc sinks them)
       } else {
         // Last chunk: its fragments are in registers once lgkmcnt drains, so this wave no longer
         // reads slot `slot`.  Tile it+1 has landed when at most NS-2 younger tiles are outstanding
         // (tiles it+2 .. it+NS-1 exist only while it+NS-1 < nt; in the tail nothing younger is in
         // flight and the wait is vmcnt(0)); after the barrier that holds for every wave and slot
-        // `slot` is free for tile it+NS.
+        // `slot` is free: tile it+NS is refilled into it during the next tile.
+        if (c == NC - 1) {
+          if constexpr (NC == 4) refill_chunk(std::integral_constant<int, 3>{});
+          else refill_chunk(std::integral_constant<int, 7>{});
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (it + NS - 1 < nt) GANMF_WAIT_VMCNT((NS - 2) * LOADS);
         else GANMF_WAIT_VMCNT(0);
         __builtin_amdgcn_s_barrier();
-        if (kleft > 0) {
-          la.issue(smem + slot * BUF, p.lda, kleft, p.zero_page, wave);
-          lb.issue(smem + slot * BUF + SA::SZ, p.ldb, kleft, p.zero_page, wave);
-        }
+        pend_slot = slot;
+        pend_kleft = kleft;
         kleft -= BK;
         load_frags(0, smem + nslot * BUF, 0);    // first fragments of tile it+1 under the last MFMAs
         __builtin_amdgcn_sched_barrier(0);
