@@ -323,8 +323,7 @@ int run_gemm(ganmf_handle* h, int tag_gemm, int tag_red, GemmP g, bool akm, bool
     q.tiles_m = pl.tiles_m; q.tiles_n = pl.tiles_n; q.nsplit = pl.nsplit; q.k_per_split = pl.kps; q.counters = nullptr;
     q.C = slab; q.c_split_stride = (long long)g.nbatch * g.M * g.ldc; q.c_batch_stride = (long long)g.M * g.ldc;
     hipError_t e;
-    if (pl.tile == 128) e = pl.ring == 3 ? gemm_launch_t<128, 128, 32, 3>(st, q, akm, bkm) : gemm_launch_t<128, 128, 32, 2>(st, q, akm, bkm);
-    else e = pl.ring == 3 ? gemm_launch_t<64, 64, 64, 3>(st, q, akm, bkm) : gemm_launch_t<64, 64, 64, 2>(st, q, akm, bkm);
+    e = gemm_dispatch(st, q, akm, bkm, pl);
     HIP_TRY(e);
   }
   {
@@ -873,7 +872,7 @@ int ganmf_create(const ganmf_cfg* cfg, ganmf_handle** out) {
   h->tune.tile = env_int("GANMF_TILE", 0);
   if (h->tune.tile != 0 && h->tune.tile != 64 && h->tune.tile != 128) h->tune.tile = 0;
   h->tune.ring = env_int("GANMF_RING", 0);
-  if (h->tune.ring != 0 && h->tune.ring != 2 && h->tune.ring != 3) h->tune.ring = 0;
+  if (h->tune.ring != 0 && h->tune.ring != 2 && h->tune.ring != 3 && h->tune.ring != 4) h->tune.ring = 0;
   h->tune.nsplit = std::max(0, env_int("GANMF_NSPLIT", 0));
   h->debug_plan = env_int("GANMF_DEBUG_PLAN", 0) != 0;
   HIP_TRY(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
@@ -1328,7 +1327,7 @@ int ganmf_gemm_f32(int device, const float* A, const float* B, float* C, int64_t
   GemmTune tune;
   tune.tile = tile; tune.nsplit = nsplit;
   tune.ring = env_int("GANMF_RING", 0);
-  if (tune.ring != 0 && tune.ring != 2 && tune.ring != 3) tune.ring = 0;
+  if (tune.ring != 0 && tune.ring != 2 && tune.ring != 3 && tune.ring != 4) tune.ring = 0;
   const GemmPlan pl = gemm_plan(g.M, g.N, g.K, 1, false, tune);
   const size_t slab_elems = gemm_slab_elems(pl, g.M, ldc, 1);
   if (slab_elems) TRY(dalloc(&slab, slab_elems));

@@ -653,6 +653,9 @@ inline hipError_t gemm_launch_t(hipStream_t st, const GemmP& p, bool akm, bool b
   return hipGetLastError();
 }
 
+struct GemmPlan;
+inline hipError_t gemm_dispatch(hipStream_t st, const GemmP& p, bool akm, bool bkm, const GemmPlan& pl);
+
 // Logical GEMM: C[bz] = epi(op(A[bz]) . op(B)).  `p` carries the operands, shapes, batch strides
 // and the epilogue; C/ldc/c_batch_stride describe the FINAL output.  slab: workspace for split-K.
 inline hipError_t gemm_run(hipStream_t st, GemmP p, bool akm, bool bkm, const GemmPlan& pl, float* slab,
@@ -677,11 +680,16 @@ inline hipError_t gemm_run(hipStream_t st, GemmP p, bool akm, bool bkm, const Ge
     p.C = slab; p.c_split_stride = r.split_stride; p.c_batch_stride = (long long)p.M * p.ldc;
   }
   hipError_t e;
-  if (pl.tile == 128) e = pl.ring == 3 ? gemm_launch_t<128, 128, 32, 3>(st, p, akm, bkm) : gemm_launch_t<128, 128, 32, 2>(st, p, akm, bkm);
-  else e = pl.ring == 3 ? gemm_launch_t<64, 64, 64, 3>(st, p, akm, bkm) : gemm_launch_t<64, 64, 64, 2>(st, p, akm, bkm);
+  e = gemm_dispatch(st, p, akm, bkm, pl);
   if (e != hipSuccess || pl.nsplit == 1 || in_launch) return e;
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(GEMM_RED_GRID, p.nbatch), dim3(256), 0, st, r);
   return hipGetLastError();
+}
+
+inline hipError_t gemm_dispatch(hipStream_t st, const GemmP& p, bool akm, bool bkm, const GemmPlan& pl) {
+  if (pl.tile == 128) return pl.ring >= 3 ? gemm_launch_t<128, 128, 32, 3>(st, p, akm, bkm) : gemm_launch_t<128, 128, 32, 2>(st, p, akm, bkm);
+  if (pl.ring == 4) return gemm_launch_t<64, 64, 64, 4>(st, p, akm, bkm);   // 128 KiB ring: three K-tiles (96 KiB) in flight
+  return pl.ring == 3 ? gemm_launch_t<64, 64, 64, 3>(st, p, akm, bkm) : gemm_launch_t<64, 64, 64, 2>(st, p, akm, bkm);
 }
 
 }  // namespace ganmf
