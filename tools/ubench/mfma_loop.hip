@@ -114,6 +114,52 @@ __global__ __launch_bounds__(512) void loop_pc(const float* __restrict__ src, fl
   out[blockIdx.x * 256 + (tid & 255)] = s;
 }
 
+// bytes-per-tile sweep: PIECES glds (1 KiB each per wave) per tile per wave, issued one tile ahead
+template <int PIECES>
+__global__ __launch_bounds__(256) void loop_bytes(const float* __restrict__ src, float* out, unsigned long long* cyc, int ntiles) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * PIECES * 1024];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  f32x16 acc[4];
+  for (int a = 0; a < 4; ++a) for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+  float4 fa = make_float4(1, 2, 3, 4), fb = make_float4(4, 3, 2, 1);
+  const float* g = src + (size_t)blockIdx.x * 8192 + tid * 4;
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int t = 0; t < ntiles; ++t) {
+    float* buf = smem + (t & 1) * PIECES * 1024;
+#pragma unroll
+    for (int j = 0; j < PIECES; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + (j & 7) * 1024),
+                                       (__attribute__((address_space(3))) void*)(buf + (j * 256 + wave * 64) * 4), 16, 0, 0);
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb.x, acc[a], 0, 0, 0);
+        acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb.y, acc[a], 0, 0, 0);
+        acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb.z, acc[a], 0, 0, 0);
+        acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb.w, acc[a], 0, 0, 0);
+      }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  if (lane == 0) cyc[blockIdx.x * 4 + wave] = t1 - t0;
+  float s = 0;
+  for (int a = 0; a < 4; ++a) for (int r = 0; r < 16; ++r) s += acc[a][r];
+  out[blockIdx.x * 256 + tid] = s + smem[tid];
+}
+template <int PIECES>
+void run_bytes(const float* src, float* out, unsigned long long* cyc, int ntiles) {
+  hipLaunchKernelGGL((loop_bytes<PIECES>), dim3(256), dim3(256), 0, 0, src, out, cyc, ntiles);
+  hipLaunchKernelGGL((loop_bytes<PIECES>), dim3(256), dim3(256), 0, 0, src, out, cyc, ntiles);
+  hipDeviceSynchronize();
+  std::vector<unsigned long long> h(1024);
+  hipMemcpy(h.data(), cyc, 8192, hipMemcpyDeviceToHost);
+  std::sort(h.begin(), h.end());
+  const double c = (double)h[512] / ntiles;
+  printf("glds %2d KiB per tile per CU + 64 MFMAs/wave : %7.1f cycles per tile  (%.1f B/clk/CU)\n", PIECES * 4, c, PIECES * 4096.0 / c);
+}
+
 template <int NACC, int LW>
 void run_pc(const char* name, const float* src, float* out, unsigned long long* cyc, int ntiles) {
   hipLaunchKernelGGL((loop_pc<NACC, LW>), dim3(256), dim3(512), 0, 0, src, out, cyc, ntiles);
@@ -155,6 +201,11 @@ int main() {
   run<8 | 2, 4>("MFMA + 8 global_load + 8 ds_write + barrier", src, out, cyc, nt);
   run<8 | 2 | 1, 4>("MFMA + frags + regstage + barrier", src, out, cyc, nt);
   run<8 | 2 | 1, 1>("MFMA + frags + regstage + barrier", src, out, cyc, nt);
+  run_bytes<2>(src, out, cyc, nt);
+  run_bytes<4>(src, out, cyc, nt);
+  run_bytes<8>(src, out, cyc, nt);
+  run_bytes<12>(src, out, cyc, nt);
+  run_bytes<16>(src, out, cyc, nt);
   run_pc<4, 4>("producer/consumer, 32 KiB per tile", src, out, cyc, nt);
   run_pc<4, 2>("producer/consumer, 32 KiB per tile", src, out, cyc, nt);
   run_pc<4, 1>("producer/consumer, 32 KiB per tile", src, out, cyc, nt);
