@@ -105,6 +105,7 @@ class GANMF(BaseRecommender):
             self.engine.close()
         self.engine = Engine(self.num_users, self.num_items, num_factors, emb_dim, batch_size, device=self.device, **hp)
         self.engine.set_urm(self._URM_fit)
+        self.engine.set_seen(self._URM_eval)            # for device-side recommend()
         self.params = {'D': [_TensorRef(t, n) for t, n in self._D_TENSORS],
                        'G': [_TensorRef(t, n) for t, n in self._G_TENSORS]}
         self.sess = _SessionShim(self)
@@ -217,6 +218,38 @@ class GANMF(BaseRecommender):
         self._require_engine()
         ids = np.asarray(user_id_array).reshape(-1)
         return self.engine.scores(ids, transposed=(self.mode == 'item'))
+
+    # ---- recommend (Base/BaseRecommender.py:155-247) ---------------------------------------------
+    _DEVICE_TOPK_MAX = 256   # above this the k-round device selection loses to numpy's argpartition
+
+    def recommend_topk(self, user_id_array, cutoff, remove_seen_flag=True):
+        """Top-`cutoff` item ids per user as an [n, cutoff] int32 array, -1 padded where a user has fewer
+        finite scores; scores, seen-item mask and selection all stay on the device (ganmf_recommend)."""
+        self._require_engine()
+        ids = np.atleast_1d(np.asarray(user_id_array)).reshape(-1)
+        items, _ = self.engine.recommend(ids, cutoff, transposed=(self.mode == 'item'), remove_seen=remove_seen_flag)
+        return items
+
+    def recommend(self, user_id_array, cutoff=None, remove_seen_flag=True, items_to_compute=None,
+                  remove_top_pop_flag=False, remove_CustomItems_flag=False, return_scores=False):
+        device_ok = (not return_scores and items_to_compute is None and not remove_top_pop_flag
+                     and not remove_CustomItems_flag and cutoff is not None and 1 <= cutoff <= self._DEVICE_TOPK_MAX
+                     and cutoff <= self.n_items)
+        if not device_ok:   # full score matrix needed on the host: the reference's own route
+            saved = self.URM_train
+            self.URM_train = self._URM_eval
+            try:
+                return super(GANMF, self).recommend(user_id_array, cutoff=cutoff, remove_seen_flag=remove_seen_flag,
+                                                    items_to_compute=items_to_compute,
+                                                    remove_top_pop_flag=remove_top_pop_flag,
+                                                    remove_CustomItems_flag=remove_CustomItems_flag,
+                                                    return_scores=return_scores)
+            finally:
+                self.URM_train = saved
+        single = np.isscalar(user_id_array)
+        items = self.recommend_topk(user_id_array, cutoff, remove_seen_flag)
+        lists = [row[row >= 0].tolist() for row in items]
+        return lists[0] if single else lists
 
     def _require_engine(self):
         if self.engine is None:

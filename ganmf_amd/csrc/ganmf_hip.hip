@@ -148,6 +148,13 @@ struct ganmf_handle {
   float *d_parts = nullptr, *g_parts = nullptr;  // [cap][4]
   float *d_arena = nullptr, *g_arena = nullptr;  // [cap][4][reg_cap] per-step block partials (GANMF), reduced once per epoch
   int64_t parts_cap = 0;
+  // recommend(): URM_train in evaluation orientation for the seen-item mask, top-k outputs
+  long long* seen_indptr = nullptr;
+  int* seen_indices = nullptr;
+  int64_t seen_rows = 0, seen_cols = 0;
+  int* topk_items = nullptr;
+  float* topk_vals = nullptr;
+  size_t topk_cap = 0;
   // scoring scratch
   float *sc_rows = nullptr, *sc_out = nullptr;
   size_t sc_rows_cap = 0, sc_out_cap = 0;
@@ -976,6 +983,7 @@ int ganmf_destroy(ganmf_handle* h) {
   hipFree(h->gD); hipFree(h->indptr); hipFree(h->indices); hipFree(h->data); hipFree(h->perm); hipFree(h->pos);
   hipFree(h->XF); hipFree(h->Ub); hipFree(h->E); hipFree(h->Dl); hipFree(h->dE); hipFree(h->dF); hipFree(h->gUb);
   hipFree(h->slab); hipFree(h->rs); hipFree(h->scal); hipFree(h->sqp); hipFree(h->fmp);
+  hipFree(h->seen_indptr); hipFree(h->seen_indices); hipFree(h->topk_items); hipFree(h->topk_vals);
   hipFree(h->regp); hipFree(h->d_parts); hipFree(h->g_parts); hipFree(h->d_arena); hipFree(h->g_arena); hipFree(h->sc_rows); hipFree(h->sc_out);
   for (auto& r : h->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
   hipStreamSynchronize(h->st2);
@@ -1216,6 +1224,68 @@ int ganmf_scores(ganmf_handle* h, const int32_t* ids, int64_t n, int transposed,
     hipError_t e = hipMemcpy2DAsync(out, (size_t)W * 4, od, (size_t)ldw * 4, (size_t)W * 4, n, hipMemcpyDeviceToHost, h->st);
     if (e == hipSuccess) e = hipStreamSynchronize(h->st);
     if (e != hipSuccess) rc = fail(-2, "ganmf_scores: copy back failed: %s", hipGetErrorString(e));
+  }
+  hipStreamSynchronize(h->st);
+  hipFree(ids_dev);
+  return rc;
+}
+
+int ganmf_set_seen_csr(ganmf_handle* h, const int64_t* indptr, const int32_t* indices, int64_t n_rows, int64_t n_cols) {
+  if (!h || !indptr) return fail(-1, "ganmf_set_seen_csr: null argument");
+  const int64_t nnz = indptr[n_rows];
+  if (indptr[0] != 0 || nnz < 0 || (nnz > 0 && !indices)) return fail(-1, "ganmf_set_seen_csr: bad indptr");
+  for (int64_t r = 0; r < n_rows; ++r)
+    if (indptr[r + 1] < indptr[r]) return fail(-1, "ganmf_set_seen_csr: indptr not monotone at row %lld", (long long)r);
+  for (int64_t j = 0; j < nnz; ++j)
+    if (indices[j] < 0 || indices[j] >= n_cols) return fail(-1, "ganmf_set_seen_csr: column index %d out of range", indices[j]);
+  HIP_TRY(hipSetDevice(h->dev));
+  HIP_TRY(hipStreamSynchronize(h->st));
+  if (h->seen_indptr) { hipFree(h->seen_indptr); hipFree(h->seen_indices); h->seen_indptr = nullptr; h->seen_indices = nullptr; }
+  HIP_TRY(hipMalloc((void**)&h->seen_indptr, (n_rows + 1) * sizeof(long long)));
+  HIP_TRY(hipMalloc((void**)&h->seen_indices, std::max<int64_t>(nnz, 1) * sizeof(int)));
+  HIP_TRY(hipMemcpy(h->seen_indptr, indptr, (n_rows + 1) * sizeof(long long), hipMemcpyHostToDevice));
+  if (nnz) HIP_TRY(hipMemcpy(h->seen_indices, indices, nnz * sizeof(int), hipMemcpyHostToDevice));
+  h->seen_rows = n_rows; h->seen_cols = n_cols;
+  return 0;
+}
+
+int ganmf_recommend(ganmf_handle* h, const int32_t* ids, int64_t n, int transposed, int32_t cutoff, int remove_seen,
+                    int32_t* out_items, float* out_scores) {
+  if (!h || !ids || !out_items) return fail(-1, "ganmf_recommend: null argument");
+  if (n < 1 || n > (1 << 30)) return fail(-1, "ganmf_recommend: n out of range");
+  const int limit = transposed ? h->N : h->U, W = transposed ? h->U : h->N;
+  if (cutoff < 1 || cutoff > W) return fail(-1, "ganmf_recommend: cutoff %d out of range [1,%d]", cutoff, W);
+  for (int64_t i = 0; i < n; ++i)
+    if (ids[i] < 0 || ids[i] >= limit) return fail(-1, "ganmf_recommend: id %d out of range [0,%d)", ids[i], limit);
+  if (remove_seen && (!h->seen_indptr || h->seen_rows != limit || h->seen_cols != W))
+    return fail(-1, "ganmf_recommend: remove_seen needs ganmf_set_seen_csr with a %d x %d matrix", limit, W);
+  HIP_TRY(hipSetDevice(h->dev));
+  int* ids_dev = nullptr;
+  HIP_TRY(hipMalloc((void**)&ids_dev, n * sizeof(int)));
+  HIP_TRY(hipMemcpyAsync(ids_dev, ids, n * sizeof(int), hipMemcpyHostToDevice, h->st));
+  const size_t need = (size_t)n * cutoff;
+  if (need > h->topk_cap) {
+    HIP_TRY(hipStreamSynchronize(h->st));
+    if (h->topk_items) { hipFree(h->topk_items); hipFree(h->topk_vals); }
+    HIP_TRY(hipMalloc((void**)&h->topk_items, need * sizeof(int)));
+    HIP_TRY(hipMalloc((void**)&h->topk_vals, need * sizeof(float)));
+    h->topk_cap = need;
+  }
+  float* od = nullptr; int Wd = 0, ldw = 0;
+  int rc = scores_device(h, ids_dev, n, transposed, &od, &Wd, &ldw);
+  if (rc == 0) {
+    const int lds_cap = 32768;   // floats: 128 KiB of the CU's 160 KiB
+    const size_t shmem = Wd <= lds_cap ? (size_t)Wd * sizeof(float) : 0;
+    if (shmem > 48 * 1024)
+      hipFuncSetAttribute(reinterpret_cast<const void*>(mask_topk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    hipLaunchKernelGGL(mask_topk_kernel, dim3((int)n), dim3(256), shmem, h->st, od, ldw, Wd, ids_dev,
+                       remove_seen ? h->seen_indptr : (const long long*)nullptr, h->seen_indices, (int)cutoff, lds_cap,
+                       h->topk_items, h->topk_vals);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(out_items, h->topk_items, need * sizeof(int), hipMemcpyDeviceToHost, h->st);
+    if (e == hipSuccess && out_scores) e = hipMemcpyAsync(out_scores, h->topk_vals, need * sizeof(float), hipMemcpyDeviceToHost, h->st);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->st);
+    if (e != hipSuccess) rc = fail(-2, "ganmf_recommend: %s", hipGetErrorString(e));
   }
   hipStreamSynchronize(h->st);
   hipFree(ids_dev);

@@ -330,6 +330,59 @@ __global__ __launch_bounds__(256) void dis_dz_top_kernel(const float* __restrict
   }
 }
 
+// ---- recommend(): seen items -> -inf, then top-k by score (Base/BaseRecommender.py:189-234) ---------
+// One workgroup per score row.  The row is staged in LDS when it fits (lds_cap floats), otherwise the
+// selection works in place on the (private) score buffer.  k rounds of a block-wide arg-max with
+// removal; ties go to the smaller item id; exhausted rows (everything -inf) yield -1.
+__global__ __launch_bounds__(256) void mask_topk_kernel(float* __restrict__ scores, int ld, int W,
+                                                        const int* __restrict__ row_ids,
+                                                        const long long* __restrict__ seen_indptr,
+                                                        const int* __restrict__ seen_indices, int k, int lds_cap,
+                                                        int* __restrict__ out_items, float* __restrict__ out_vals) {
+  extern __shared__ __attribute__((aligned(16))) float srow[];
+  __shared__ float wv[4];
+  __shared__ int wi[4];
+  const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* g = scores + (size_t)r * ld;
+  const bool in_lds = W <= lds_cap;
+  float* row = in_lds ? srow : g;
+  if (in_lds)
+    for (int i = tid; i < W; i += 256) srow[i] = g[i];
+  __syncthreads();
+  if (seen_indptr) {
+    const int u = row_ids[r];
+    const long long s = seen_indptr[u], e = seen_indptr[u + 1];
+    for (long long j = s + tid; j < e; j += 256) row[seen_indices[j]] = -INFINITY;
+  }
+  __syncthreads();
+  for (int t = 0; t < k; ++t) {
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = tid; i < W; i += 256) {
+      const float v = row[i];
+      if (v > bv) { bv = v; bi = i; }       // strided scan visits ids in increasing order: first max wins
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o);
+      const int oi = __shfl_xor(bi, o);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) { wv[wave] = bv; wi[wave] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+      float v = wv[0]; int i = wi[0];
+      for (int w = 1; w < 4; ++w)
+        if (wv[w] > v || (wv[w] == v && wi[w] < i)) { v = wv[w]; i = wi[w]; }
+      const bool ok = v > -INFINITY && i != 0x7fffffff;
+      out_items[(size_t)r * k + t] = ok ? i : -1;
+      out_vals[(size_t)r * k + t] = ok ? v : -INFINITY;
+      if (ok) row[i] = -INFINITY;
+    }
+    __syncthreads();
+  }
+}
+
 __global__ void fill_kernel(float* __restrict__ p, float v, long long n) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (long long)gridDim.x * blockDim.x)

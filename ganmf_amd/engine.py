@@ -108,6 +108,25 @@ class Engine:
             L.check(self.lib.ganmf_scores(self.h, _i32p(ids), ids.size, int(transposed), _f32p(out)), "ganmf_scores")
         return out
 
+    def set_seen(self, urm_eval_csr):
+        """URM_train in evaluation orientation (rows = users the evaluator asks about)."""
+        urm = urm_eval_csr.tocsr()
+        urm.sort_indices()
+        indptr = np.ascontiguousarray(urm.indptr, dtype=np.int64)
+        indices = np.ascontiguousarray(urm.indices, dtype=np.int32)
+        L.check(self.lib.ganmf_set_seen_csr(self.h, indptr.ctypes.data_as(C.POINTER(C.c_int64)), _i32p(indices),
+                                            urm.shape[0], urm.shape[1]), "ganmf_set_seen_csr")
+
+    def recommend(self, ids, cutoff, transposed=False, remove_seen=True):
+        """device top-k: returns (items [n, cutoff] int32 with -1 padding, scores [n, cutoff])"""
+        ids = np.ascontiguousarray(ids, dtype=np.int32).ravel()
+        items = np.empty((ids.size, cutoff), dtype=np.int32)
+        vals = np.empty((ids.size, cutoff), dtype=np.float32)
+        if ids.size:
+            L.check(self.lib.ganmf_recommend(self.h, _i32p(ids), ids.size, int(transposed), int(cutoff), int(remove_seen),
+                                             _i32p(items), _f32p(vals)), "ganmf_recommend")
+        return items, vals
+
     def snapshot_best(self):
         L.check(self.lib.ganmf_snapshot_best(self.h), "ganmf_snapshot_best")
 

@@ -160,3 +160,104 @@ class EvaluatorHoldout(object):
         else:
             print("WARNING: No users had a sufficient number of relevant items")
         return results, get_result_string(results)
+
+
+class EvaluatorHoldoutFast(EvaluatorHoldout):
+    """Same protocol and result dictionaries as EvaluatorHoldout (Evaluator.py:214-414), but consumes only the
+    top-`max_cutoff` ids of each user — `recommender.recommend_topk(...)` when the recommender has it (device
+    selection, include/ganmf_hip.h: ganmf_recommend), else `recommend(..., return_scores=False)` — and computes
+    the ranking metrics for a whole block of users at once.  Sums are float64 (the per-user functions above
+    follow the reference's float32 sums); the two agree to ~1e-6 relative.  RMSE needs every score of every
+    user and is reported as NaN here; SURVEY §8(f) row 1."""
+    EVALUATOR_NAME = "EvaluatorHoldoutFast"
+
+    def __init__(self, URM_test_list, cutoff_list, minRatingsPerUser=1, exclude_seen=True):
+        super().__init__(URM_test_list, cutoff_list, minRatingsPerUser=minRatingsPerUser, exclude_seen=exclude_seen)
+        K = self.max_cutoff
+        self._users = np.asarray(self.usersToEvaluate, dtype=np.int64)
+        self._n_test = np.ediff1d(self.URM_test.indptr)[self._users].astype(np.int64)
+        # relevance lookup: stored entries of URM_test are the relevant items (Evaluator.py:46-52), value = gain
+        self._rel = sps.csr_matrix((np.ones_like(self.URM_test.data, dtype=np.float64), self.URM_test.indices,
+                                    self.URM_test.indptr), shape=self.URM_test.shape)
+        self._gain = sps.csr_matrix((np.power(2.0, self.URM_test.data.astype(np.float32)).astype(np.float64) - 1.0,
+                                     self.URM_test.indices, self.URM_test.indptr), shape=self.URM_test.shape)
+        # ideal DCG prefix sums: ratings sorted descending, first K, discounted (metrics.py ndcg/dcg)
+        disc = 1.0 / np.log(np.arange(K, dtype=np.float32) + 2).astype(np.float64)
+        ideal = np.zeros((len(self._users), K))
+        for i, u in enumerate(self._users):
+            r = np.sort(self.get_user_test_ratings(u))[::-1][:K].astype(np.float32)
+            ideal[i, :len(r)] = (np.power(2.0, r).astype(np.float64) - 1.0) * disc[:len(r)]
+        self._ideal_cum = np.cumsum(ideal, axis=1)
+        self._disc = disc
+
+    def _topk(self, rec, batch):
+        K = self.max_cutoff
+        if hasattr(rec, "recommend_topk"):
+            return np.asarray(rec.recommend_topk(batch, K, remove_seen_flag=self.exclude_seen))
+        lists = rec.recommend(batch, remove_seen_flag=self.exclude_seen, cutoff=K, remove_top_pop_flag=False,
+                              remove_CustomItems_flag=False, return_scores=False)
+        out = np.full((len(batch), K), -1, dtype=np.int64)
+        for i, l in enumerate(lists):
+            out[i, :len(l)] = l
+        return out
+
+    def evaluateRecommender(self, recommender_object):
+        K = self.max_cutoff
+        block_size = max(1, min(4096, int(1e8 / self.n_items)))
+        names = [m for m in METRICS if m != "F1"]
+        sums = {c: {m: 0.0 for m in names} for c in self.cutoff_list}
+        n_eval = len(self._users)
+        inv_rank = 1.0 / np.arange(1, K + 1, dtype=np.float64)
+        for start in range(0, n_eval, block_size):
+            sl = slice(start, min(start + block_size, n_eval))
+            batch = self._users[sl]
+            items = self._topk(recommender_object, batch)
+            assert items.shape == (len(batch), K)
+            valid = items >= 0
+            safe = np.where(valid, items, 0)
+            rows = np.repeat(np.arange(len(batch)), K)
+            rel_block, gain_block = self._rel[batch], self._gain[batch]
+            is_rel = np.asarray(rel_block[rows, safe.ravel()]).reshape(len(batch), K) > 0
+            is_rel &= valid
+            gain = np.asarray(gain_block[rows, safe.ravel()]).reshape(len(batch), K) * is_rel
+            n_test = self._n_test[sl].astype(np.float64)
+            length = valid.sum(axis=1)
+            for c in self.cutoff_list:
+                r = sums[c]
+                rel = is_rel[:, :c].astype(np.float64)
+                neg = (valid[:, :c] & ~is_rel[:, :c]).astype(np.float64)
+                len_c = np.minimum(length, c).astype(np.float64)
+                hits = rel.sum(axis=1)
+                nneg = neg.sum(axis=1)
+                # AUC over the list: for each hit, the negatives ranked after it (metrics.py roc_auc)
+                neg_after = nneg[:, None] - np.cumsum(neg, axis=1)
+                pairs = (rel * neg_after).sum(axis=1)
+                auc = np.where(nneg == 0, 1.0, np.where(hits > 0, pairs / np.maximum(hits * nneg, 1.0), 0.0))
+                nz = np.maximum(len_c, 1.0)
+                r["ROC_AUC"] += auc.sum()
+                r["PRECISION"] += np.where(len_c > 0, hits / nz, 0.0).sum()
+                r["PRECISION_RECALL_MIN_DEN"] += np.where(len_c > 0, hits / np.maximum(np.minimum(n_test, len_c), 1.0), 0.0).sum()
+                r["RECALL"] += (hits / n_test).sum()
+                dcg_rank = (gain[:, :c] * self._disc[:c]).sum(axis=1)
+                li = np.maximum(len_c.astype(np.int64) - 1, 0)
+                ideal = self._ideal_cum[sl][np.arange(len(batch)), li]
+                r["NDCG"] += np.where(dcg_rank > 0, dcg_rank / np.where(ideal > 0, ideal, 1.0), 0.0).sum()
+                r["HIT_RATE"] += hits.sum()
+                r["ARHR"] += (rel * inv_rank[:c]).sum()
+                first = np.argmax(rel > 0, axis=1)
+                r["MRR"] += np.where(hits > 0, inv_rank[first], 0.0).sum()
+                p_at_k = rel * np.cumsum(rel, axis=1) * inv_rank[:c]
+                r["MAP"] += np.where(len_c > 0, p_at_k.sum(axis=1) / np.maximum(np.minimum(n_test, len_c), 1.0), 0.0).sum()
+        results = {c: {} for c in self.cutoff_list}
+        if n_eval > 0:
+            for c in self.cutoff_list:
+                for m in names:
+                    results[c][m] = float(sums[c][m] / n_eval)
+                results[c]["RMSE"] = float("nan")
+                p, rc = results[c]["PRECISION"], results[c]["RECALL"]
+                if p + rc != 0:
+                    results[c]["F1"] = 2 * (p * rc) / (p + rc)
+        else:
+            results = {c: {m: 0.0 for m in names} for c in self.cutoff_list}
+            print("WARNING: No users had a sufficient number of relevant items")
+        return results, get_result_string(results)

@@ -119,6 +119,16 @@ int ganmf_train_step(ganmf_handle* h, int kind, const int32_t* uids, int32_t n, 
  * (the item-mode product is formed directly; the full matrix is never materialised). */
 int ganmf_scores(ganmf_handle* h, const int32_t* ids, int64_t n, int transposed, float* out);
 
+/* Replaces the per-user part of BaseRecommender.recommend (Base/BaseRecommender.py:189-234): the scores
+ * of ganmf_scores stay on the device, already-seen items are set to -inf and the `cutoff` best items per
+ * row are selected there; only n*cutoff ids (and their scores) cross PCIe.  SURVEY §8(f) row 1.
+ * ganmf_set_seen_csr uploads URM_train in EVALUATION orientation (rows = users as evaluators see them,
+ * columns = items; n_rows/n_cols must match the id domain / score width of the chosen `transposed`).
+ * Ties go to the smaller item id; rows with fewer than `cutoff` finite scores are padded with -1. */
+int ganmf_set_seen_csr(ganmf_handle* h, const int64_t* indptr, const int32_t* indices, int64_t n_rows, int64_t n_cols);
+int ganmf_recommend(ganmf_handle* h, const int32_t* ids, int64_t n, int transposed, int32_t cutoff, int remove_seen,
+                    int32_t* out_items, float* out_scores);
+
 /* Replaces save_current_model / load_model (GANMF.py:249-255, Utils_.py:292-294): device-side
  * copies of all trainable tensors to / from their `best` twins. */
 int ganmf_snapshot_best(ganmf_handle* h);

@@ -32,6 +32,48 @@ def test_evaluator_matches_reference_golden(golden_dir):
             assert abs(res[int(c)][k] - d[k]) <= 1e-9 + 2e-6 * abs(d[k]), (c, k, res[int(c)][k], d[k])
 
 
+def test_fast_evaluator_matches_reference_golden(golden_dir):
+    """EvaluatorHoldoutFast (block-vectorised, top-k ids only) against the same reference golden; RMSE is
+    not available without the full score rows and must be NaN.  The golden itself carries the reference's
+    float32 running sums over ~2100 users (a few 1e-6 relative); the fast path sums in float64, hence 2e-5."""
+    from ganmf_amd.evaluation import EvaluatorHoldoutFast
+    f = np.load(os.path.join(golden_dir, "evaluator_factors.npz"))
+    exp = json.load(open(os.path.join(golden_dir, "evaluator_expected.json")))
+    train = sps.load_npz(os.path.join(golden_dir, "hetrec2011_URM_train_small.npz")).tocsr()
+    val = sps.load_npz(os.path.join(golden_dir, "hetrec2011_URM_validation.npz")).tocsr()
+    res, text = EvaluatorHoldoutFast(val, [5, 10]).evaluateRecommender(_Factors(train, f["U"], f["V"]))
+    assert "CUTOFF: 10" in text
+    for c, d in exp.items():
+        for k in ("ROC_AUC", "PRECISION", "PRECISION_RECALL_MIN_DEN", "RECALL", "MAP", "MRR", "NDCG", "F1", "HIT_RATE",
+                  "ARHR"):
+            assert abs(res[int(c)][k] - d[k]) <= 1e-9 + 2e-5 * abs(d[k]), (c, k, res[int(c)][k], d[k])
+        assert np.isnan(res[int(c)]["RMSE"])
+
+
+def test_fast_evaluator_short_lists_and_ratings():
+    """Users whose recommendation list is shorter than the cutoff (everything else seen) and graded test
+    ratings: the two evaluators must agree metric by metric."""
+    from ganmf_amd.evaluation import EvaluatorHoldoutFast
+    rng = np.random.RandomState(5)
+    n_users, n_items = 40, 12
+    train = (rng.rand(n_users, n_items) < 0.5).astype(np.float32)
+    train[:6, :] = 1.0
+    train[:6, :3] = 0.0          # 3 unseen items < cutoff 5
+    train[6, :] = 1.0            # nothing left to recommend
+    test = ((rng.rand(n_users, n_items) < 0.3) & (train == 0)) * rng.randint(1, 6, size=(n_users, n_items))
+    test[6, 0] = 3               # relevant item that can never be recommended
+    U, V = rng.randn(n_users, 4).astype(np.float32), rng.randn(n_items, 4).astype(np.float32)
+    rec = _Factors(sps.csr_matrix(train), U, V)
+    test = sps.csr_matrix(test.astype(np.float32))
+    slow, _ = EvaluatorHoldout(test, [1, 5, 8]).evaluateRecommender(rec)
+    fast, _ = EvaluatorHoldoutFast(test, [1, 5, 8]).evaluateRecommender(rec)
+    for c in (1, 5, 8):
+        for k, v in slow[c].items():
+            if k == "RMSE":
+                continue
+            assert abs(fast[c][k] - v) <= 1e-9 + 2e-6 * abs(v), (c, k, fast[c][k], v)
+
+
 def test_kat1_ranking_on_cpu(golden_dir):
     """KAT-1 without a GPU: checkpoint tensors scored in numpy through the build's recommend()."""
     t = np.load(os.path.join(golden_dir, "kat1_checkpoint_tensors.npz"))

@@ -1,0 +1,122 @@
+"""Device-side recommend (ganmf_set_seen_csr / ganmf_recommend) against the host route of
+Base/BaseRecommender.py:155-247 (scores -> seen to -inf -> top-k) and the two evaluators on the same model."""
+import json
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sps
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(mode, n_users, n_items, k, seed, density=0.08):
+    from ganmf_amd.GANMF import GANMF
+    rng = np.random.RandomState(seed)
+    m = (rng.rand(n_users, n_items) < density).astype(np.float32)
+    m[np.arange(n_users), rng.randint(0, n_items, n_users)] = 1.0
+    urm = sps.csr_matrix(m)
+    model = GANMF(urm, mode=mode, is_experiment=True)
+    model._build(k, 16, 32)
+    nu, ni = model.num_users, model.num_items
+    model.engine.set_tensor(100, rng.randn(nu, k).astype(np.float32))
+    model.engine.set_tensor(101, rng.randn(ni, k).astype(np.float32))
+    model.URM_train = model._URM_eval
+    return model, urm, rng
+
+
+def _host_topk(model, users, cutoff, remove_seen):
+    """the reference's own steps on the full score rows, ties to the smaller id"""
+    scores = model._compute_item_score(users).astype(np.float32)
+    if remove_seen:
+        urm = model._URM_eval
+        for i, u in enumerate(users):
+            scores[i, urm.indices[urm.indptr[u]:urm.indptr[u + 1]]] = -np.inf
+    order = np.lexsort((np.arange(scores.shape[1])[None, :].repeat(len(users), 0), -scores), axis=1)[:, :cutoff]
+    vals = np.take_along_axis(scores, order, axis=1)
+    return np.where(np.isfinite(vals), order, -1), vals
+
+
+@pytest.mark.parametrize("mode", ["user", "item"])
+@pytest.mark.parametrize("remove_seen", [True, False])
+@pytest.mark.parametrize("cutoff", [1, 5, 50])
+def test_device_topk_equals_host(mode, remove_seen, cutoff):
+    model, urm, rng = _model(mode, 211, 333, 9, 3)
+    users = rng.permutation(211)[:97]
+    items, vals = model.engine.recommend(users, cutoff, transposed=(mode == "item"), remove_seen=remove_seen)
+    ref_items, ref_vals = _host_topk(model, users, cutoff, remove_seen)
+    assert np.array_equal(items, ref_items)
+    assert np.array_equal(vals, ref_vals)          # same GEMM, same bits
+    lists = model.recommend(users, cutoff=cutoff, remove_seen_flag=remove_seen)
+    assert lists == [r[r >= 0].tolist() for r in ref_items]
+    assert model.recommend(int(users[0]), cutoff=cutoff, remove_seen_flag=remove_seen) == lists[0]
+
+
+def test_short_lists_padded_and_ties():
+    from ganmf_amd.GANMF import GANMF
+    n_users, n_items, k = 9, 70, 4
+    m = np.zeros((n_users, n_items), np.float32)
+    m[0, :] = 1.0                 # user 0 has seen everything
+    m[1, 3:] = 1.0                # user 1: three items left
+    m[2:, 0] = 1.0
+    model = GANMF(sps.csr_matrix(m), mode="user", is_experiment=True)
+    model._build(k, 8, 4)
+    U = np.ones((n_users, k), np.float32)
+    V = np.ones((n_items, k), np.float32)     # every score equal: ties resolve to increasing item id
+    model.engine.set_tensor(100, U)
+    model.engine.set_tensor(101, V)
+    items, vals = model.engine.recommend(np.arange(n_users), 5, remove_seen=True)
+    assert items[0].tolist() == [-1] * 5 and np.all(np.isneginf(vals[0]))
+    assert items[1].tolist() == [0, 1, 2, -1, -1]
+    assert items[2].tolist() == [1, 2, 3, 4, 5]
+    model.URM_train = model._URM_eval
+    lists = model.recommend(np.arange(n_users), cutoff=5)
+    assert lists[0] == [] and lists[1] == [0, 1, 2] and lists[4] == [1, 2, 3, 4, 5]
+
+
+def test_wide_rows_use_global_path():
+    """score rows wider than the LDS staging limit (32768 floats) are selected in place"""
+    model, urm, rng = _model("user", 6, 40000, 3, 11, density=0.001)
+    users = np.array([5, 0, 3])
+    items, vals = model.engine.recommend(users, 7, remove_seen=True)
+    ref_items, ref_vals = _host_topk(model, users, 7, True)
+    assert np.array_equal(items, ref_items) and np.array_equal(vals, ref_vals)
+
+
+def test_recommend_errors():
+    from ganmf_amd import _lib as L
+    from ganmf_amd.engine import Engine
+    eng = Engine(10, 20, 3, 4, 4)
+    with pytest.raises(L.GanmfError, match="remove_seen needs"):
+        eng.recommend(np.arange(3), 5, remove_seen=True)
+    items, _ = eng.recommend(np.arange(3), 5, remove_seen=False)      # allowed without a seen matrix
+    assert items.shape == (3, 5)
+    with pytest.raises(L.GanmfError, match="cutoff"):
+        eng.recommend(np.arange(3), 21, remove_seen=False)
+    with pytest.raises(L.GanmfError, match="out of range"):
+        eng.recommend(np.array([10]), 5, remove_seen=False)
+    bad = sps.csr_matrix(np.ones((10, 21), np.float32))
+    eng.set_seen(bad)
+    with pytest.raises(L.GanmfError, match="remove_seen needs"):
+        eng.recommend(np.arange(3), 5, remove_seen=True)
+    eng.close()
+
+
+def test_fast_evaluator_on_device_matches_slow(golden_dir):
+    """Whole-protocol check on ML-1M shapes: the device top-k + block evaluator returns the metrics of the
+    reference-order evaluator (which pulls every score row to the host)."""
+    from ganmf_amd.GANMF import GANMF
+    from ganmf_amd.evaluation import EvaluatorHoldout, EvaluatorHoldoutFast
+    train = sps.load_npz(os.path.join(golden_dir, "Movielens1M_URM_train.npz")).tocsr()
+    test = sps.load_npz(os.path.join(golden_dir, "Movielens1M_URM_test.npz")).tocsr()
+    for mode in ("user", "item"):
+        model = GANMF(train, mode=mode, is_experiment=True, seed=3)
+        model.fit(num_factors=16, emb_dim=32, epochs=2, batch_size=128, d_lr=1e-3, g_lr=1e-3, m=10, recon_coefficient=0.1)
+        slow, _ = EvaluatorHoldout(test, [5, 20]).evaluateRecommender(model)
+        fast, _ = EvaluatorHoldoutFast(test, [5, 20]).evaluateRecommender(model)
+        for c in (5, 20):
+            for k, v in slow[c].items():
+                if k == "RMSE":
+                    assert np.isnan(fast[c][k])
+                    continue
+                assert abs(fast[c][k] - v) <= 1e-9 + 2e-5 * abs(v), (mode, c, k, fast[c][k], v)
