@@ -82,8 +82,19 @@ class DisGANMF(GANMF):
         raise AttributeError("DisGANMF has no autoencoder")
 
     def saveModel(self, folder_path, file_name):
+        """DisGANMF.py:264-266: the Saver bundle only (the reference writes no build_params here and has no
+        loadModel); load_bundle() below is the build's inverse, given the architecture."""
         import os
+        from .tf_bundle import write_bundle
         self._require_engine()
         os.makedirs(folder_path, exist_ok=True)
-        tensors = {ref.name: self.sess.run(ref) for ref in self.params['D'] + self.params['G']}
-        np.savez(os.path.join(folder_path, file_name + '.npz'), **tensors)
+        write_bundle(os.path.join(folder_path, file_name),
+                     {ref.name: self.sess.run(ref) for ref in self.params['D'] + self.params['G']})
+
+    def load_bundle(self, folder_path, file_name, num_factors, d_layers, d_nodes, d_hidden_act='linear'):
+        import os
+        from .tf_bundle import read_bundle
+        data = read_bundle(os.path.join(folder_path, file_name))
+        self._build_dis(num_factors, d_layers, d_nodes, d_hidden_act, batch_size=32)
+        for ref in self.params['D'] + self.params['G']:
+            self.engine.set_tensor(ref.tid, data[ref.name])

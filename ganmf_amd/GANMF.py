@@ -280,23 +280,34 @@ class GANMF(BaseRecommender):
         return np.asarray(self._URM_fit.dot(self._get(0)) + self._get(1), dtype=np.float32)
 
     # ---- persistence (GANMF.py:309-342) -----------------------------------------------------------
+    # Same files as the reference: build_params.pkl + the tf.train.Saver bundle <name>.index /
+    # <name>.data-00000-of-00001 holding params['D'] + params['G'] (ganmf_amd/tf_bundle.py), so models
+    # saved by either side load on the other (AblationStudy.py:85-88, MFLearned.py:95).
+    def _model_file(self, folder_path, file_name):
+        return os.path.join(folder_path, self.RECOMMENDER_NAME + '_' + self.mode if file_name is None else file_name)
+
     def saveModel(self, folder_path, file_name=None):
+        from .tf_bundle import write_bundle
         self._require_engine()
         os.makedirs(folder_path, exist_ok=True)
         build_params = {'num_factors': self.num_factors, 'emb_dim': self.emb_dim}
         with open(os.path.join(folder_path, 'build_params.pkl'), 'wb') as f:
             pickle.dump(build_params, f, pickle.HIGHEST_PROTOCOL)
-        name = self.RECOMMENDER_NAME + '_' + self.mode if file_name is None else file_name
-        tensors = {ref.name: self.sess.run(ref) for ref in self.params['D'] + self.params['G']}
-        np.savez(os.path.join(folder_path, name + '.npz'), **tensors)
+        write_bundle(self._model_file(folder_path, file_name),
+                     {ref.name: self.sess.run(ref) for ref in self.params['D'] + self.params['G']})
 
     def loadModel(self, folder_path, file_name=None):
-        with open(os.path.join(folder_path, 'build_params.pkl'), 'rb') as f:
+        from .tf_bundle import read_bundle
+        filepath = os.path.join(folder_path, 'build_params.pkl')
+        if self.verbose:
+            print(self.RECOMMENDER_NAME + ': Loading model from file ' + filepath)
+        with open(filepath, 'rb') as f:
             build_params = pickle.load(f)
+        data = read_bundle(self._model_file(folder_path, file_name))
         self._build(build_params['num_factors'], build_params['emb_dim'], batch_size=32)
-        name = self.RECOMMENDER_NAME + '_' + self.mode if file_name is None else file_name
-        data = np.load(os.path.join(folder_path, name + '.npz'))
         for ref in self.params['D'] + self.params['G']:
+            if ref.name not in data:
+                raise KeyError("%s: checkpoint has no tensor %r" % (self.RECOMMENDER_NAME, ref.name))
             self.engine.set_tensor(ref.tid, data[ref.name])
         if self.verbose:
             print(self.RECOMMENDER_NAME + ': Loading complete')

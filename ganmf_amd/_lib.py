@@ -20,7 +20,7 @@ SYMBOLS = [
     "ganmf_set_tensor", "ganmf_get_tensor", "ganmf_tensor_shape", "ganmf_get_adam_powers",
     "ganmf_set_adam_powers", "ganmf_train_epoch", "ganmf_train_step", "ganmf_scores",
     "ganmf_set_seen_csr", "ganmf_recommend", "ganmf_snapshot_best", "ganmf_restore_best", "ganmf_profile_enable", "ganmf_profile_read",
-    "ganmf_bench_scores", "ganmf_gemm_f32", "ganmf_device_count", "ganmf_abi_version", "ganmf_last_error",
+    "ganmf_bench_scores", "ganmf_gemm_f32", "ganmf_crc32c", "ganmf_device_count", "ganmf_abi_version", "ganmf_last_error",
 ]
 
 
@@ -85,6 +85,7 @@ def load_library():
         "ganmf_scores": (C.c_int, [vp, P(C.c_int32), i64, C.c_int, f32p]),
         "ganmf_set_seen_csr": (C.c_int, [vp, P(C.c_int64), P(C.c_int32), i64, i64]),
         "ganmf_recommend": (C.c_int, [vp, P(C.c_int32), i64, C.c_int, i32, C.c_int, P(C.c_int32), f32p]),
+        "ganmf_crc32c": (C.c_uint32, [C.c_uint32, vp, C.c_uint64]),
         "ganmf_snapshot_best": (C.c_int, [vp]),
         "ganmf_restore_best": (C.c_int, [vp]),
         "ganmf_profile_enable": (C.c_int, [vp, C.c_int]),

@@ -24,6 +24,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <mutex>
 #include <vector>
 
 #include "../../include/ganmf_hip.h"
@@ -849,6 +850,35 @@ extern "C" {
 
 int ganmf_abi_version(void) { return GANMF_ABI_VERSION; }
 const char* ganmf_last_error(void) { return g_err.c_str(); }
+
+// CRC-32C, slicing-by-8 (reflected polynomial 0x82F63B78); host only.
+static uint32_t g_crc_tab[8][256];
+static std::once_flag g_crc_once;
+static void crc_init() {
+  for (uint32_t i = 0; i < 256; ++i) {
+    uint32_t c = i;
+    for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+    g_crc_tab[0][i] = c;
+  }
+  for (uint32_t i = 0; i < 256; ++i)
+    for (int t = 1; t < 8; ++t) g_crc_tab[t][i] = (g_crc_tab[t - 1][i] >> 8) ^ g_crc_tab[0][g_crc_tab[t - 1][i] & 0xff];
+}
+uint32_t ganmf_crc32c(uint32_t crc, const void* data, uint64_t n) {
+  std::call_once(g_crc_once, crc_init);
+  const uint8_t* p = static_cast<const uint8_t*>(data);
+  uint32_t c = ~crc;
+  while (n >= 8) {
+    uint64_t w;
+    memcpy(&w, p, 8);
+    w ^= c;
+    c = g_crc_tab[7][w & 0xff] ^ g_crc_tab[6][(w >> 8) & 0xff] ^ g_crc_tab[5][(w >> 16) & 0xff] ^
+        g_crc_tab[4][(w >> 24) & 0xff] ^ g_crc_tab[3][(w >> 32) & 0xff] ^ g_crc_tab[2][(w >> 40) & 0xff] ^
+        g_crc_tab[1][(w >> 48) & 0xff] ^ g_crc_tab[0][(w >> 56) & 0xff];
+    p += 8; n -= 8;
+  }
+  while (n--) c = (c >> 8) ^ g_crc_tab[0][(c ^ *p++) & 0xff];
+  return ~c;
+}
 
 int ganmf_device_count(void) {
   int n = 0;

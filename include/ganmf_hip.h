@@ -160,6 +160,11 @@ int ganmf_bench_scores(ganmf_handle* h, int64_t n, int transposed, int32_t iters
 int ganmf_gemm_f32(int device, const float* A, const float* B, float* C, int64_t M, int64_t N,
                    int64_t K, int a_kmajor, int b_kmajor, int tile, int nsplit, int iters, float* ms);
 
+/* Host-only helper of the checkpoint writer/reader (ganmf_amd/tf_bundle.py): CRC-32C (Castagnoli), the
+ * checksum tf.train.Saver stores per tensor and per table block (GANMF.py:309-314,337-339).  Pass crc = 0
+ * to start; feed the previous return value to continue over a second buffer. */
+uint32_t ganmf_crc32c(uint32_t crc, const void* data, uint64_t n);
+
 int ganmf_device_count(void);
 int ganmf_abi_version(void);
 const char* ganmf_last_error(void);

@@ -78,6 +78,33 @@ def kat1(BaseRecommender, EvaluatorHoldout):
     print("KAT-1 reproduced: MAP@5 =", got[5]["MAP"], "RMSE =", got[5]["RMSE"])
 
 
+def bundle_golden():
+    """Checkpoint-format pin: the surviving TF V2 bundle is read by the
+    build's reader, re-written by the build's writer and must come out byte for byte; the 354-byte .index
+    (data, not source) and one data-less .index of another run are committed as fixtures."""
+    import hashlib
+    import tempfile
+    from ganmf_amd import tf_bundle
+    d = os.path.join(REF, "feature_matching/GANMF_item_LastFM_00/GANMF_item_LastFM/GANMF_item")
+    tensors = tf_bundle.read_bundle(d)            # verifies every block and tensor CRC-32C
+    tmp = tempfile.mkdtemp()
+    tf_bundle.write_bundle(os.path.join(tmp, "GANMF_item"), tensors)
+    sha = {}
+    for ext in (".index", ".data-00000-of-00001"):
+        ref, got = open(d + ext, "rb").read(), open(os.path.join(tmp, "GANMF_item" + ext), "rb").read()
+        assert ref == got, "bundle writer does not reproduce the reference " + ext
+        sha[ext] = hashlib.sha256(ref).hexdigest()
+    shutil.copyfile(d + ".index", os.path.join(OUT, "kat1_GANMF_item.index"))
+    shutil.copyfile(os.path.join(REF, "test_results/GANMF_user_1M/GANMF_user.index"),
+                    os.path.join(OUT, "ml1m_GANMF_user.index"))
+    _, e1m = tf_bundle.read_index(os.path.join(OUT, "ml1m_GANMF_user.index"))
+    json.dump({"writer_reproduces_reference_bytes": True, "sha256": sha,
+               "ml1m_user_entries": {k: {"shape": list(v["shape"]), "offset": v["offset"], "size": v["size"]}
+                                     for k, v in e1m.items()}},
+              open(os.path.join(OUT, "kat1_bundle_check.json"), "w"), indent=1)
+    print("bundle: writer reproduces the reference .index/.data byte for byte")
+
+
 def evaluator_golden(BaseRecommender, EvaluatorHoldout):
     """Non-degenerate regime for the build's own evaluator: a seeded random rank-8 model scored
     by the reference evaluator on the hetrec2011 validation split."""
@@ -167,6 +194,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     BR, EH = _import_reference()
     kat1(BR, EH)
+    bundle_golden()
     evaluator_golden(BR, EH)
     tiny_trajectories()
     statistical_fixture()

@@ -120,3 +120,37 @@ def test_fast_evaluator_on_device_matches_slow(golden_dir):
                     assert np.isnan(fast[c][k])
                     continue
                 assert abs(fast[c][k] - v) <= 1e-9 + 2e-5 * abs(v), (mode, c, k, fast[c][k], v)
+
+
+def test_save_load_model_round_trip_in_reference_format(tmp_path, golden_dir):
+    """saveModel writes build_params.pkl + the Saver bundle (GANMF.py:309-314); loadModel (GANMF.py:316-339)
+    restores identical scores; the index carries the reference's tensor names."""
+    import pickle
+    from ganmf_amd import tf_bundle
+    from ganmf_amd.DisGANMF import DisGANMF
+    model, urm, rng = _model("item", 57, 91, 6, 21)
+    users = np.arange(57)
+    before = model._compute_item_score(users)
+    model.saveModel(str(tmp_path))
+    assert pickle.load(open(tmp_path / "build_params.pkl", "rb")) == {"num_factors": 6, "emb_dim": 16}
+    _, entries = tf_bundle.read_index(str(tmp_path / "GANMF_item.index"))
+    _, ref_entries = tf_bundle.read_index(os.path.join(golden_dir, "kat1_GANMF_item.index"))
+    assert list(entries) == list(ref_entries)
+    from ganmf_amd.GANMF import GANMF
+    again = GANMF(urm, mode="item", is_experiment=True)
+    again.loadModel(str(tmp_path))
+    assert np.array_equal(again._compute_item_score(users), before)
+    assert again.recommend(users, cutoff=5) == model.recommend(users, cutoff=5)
+    with pytest.raises(FileNotFoundError):
+        again.loadModel(str(tmp_path), file_name="missing")
+
+    d = DisGANMF(urm, mode="user", is_experiment=True, seed=2)
+    d.fit(num_factors=4, d_layers=2, d_nodes=8, d_hidden_act="tanh", epochs=1, batch_size=16)
+    d.saveModel(str(tmp_path), "dis")
+    keys = list(tf_bundle.read_index(str(tmp_path / "dis.index"))[1])
+    assert keys == ["discriminator/D_output/bias", "discriminator/D_output/kernel", "discriminator/layer_0/bias",
+                    "discriminator/layer_0/kernel", "discriminator/layer_1/bias", "discriminator/layer_1/kernel",
+                    "generator/item_embeddings", "generator/user_embeddings"]
+    d2 = DisGANMF(urm, mode="user", is_experiment=True)
+    d2.load_bundle(str(tmp_path), "dis", 4, 2, 8, "tanh")
+    assert np.array_equal(d2._compute_item_score(users[:9]), d._compute_item_score(users[:9]))
