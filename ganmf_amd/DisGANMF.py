@@ -33,7 +33,7 @@ class DisGANMF(GANMF):
         if self.engine is not None:
             self.engine.close()
         self.engine = Engine(self.num_users, self.num_items, num_factors, d_nodes, batch_size, model=L.MODEL_DISGANMF,
-                             d_layers=d_layers, d_act=d_hidden_act, device=self.device, **hp)
+                             d_layers=d_layers, d_act=d_hidden_act, device=self.device, mfma=self.mfma, **hp)
         self.engine.set_urm(self._URM_fit)
         self.engine.set_seen(self._URM_eval)
         self.params = {'D': [_TensorRef(i, n) for i, n in enumerate(self._d_names())],

@@ -85,6 +85,7 @@ class GANMF(BaseRecommender):
         self.items_to_ignore_ID = np.array([], dtype=int)
         self.filterTopPop = False
         self.filterTopPop_ItemsID = np.array([], dtype=int)
+        self.mfma = None                # None | "f32" | "bf16": arithmetic of the GEMM K loops (engine.Engine)
         self.initial_weights = None     # optional dict {We,be,Wd,bd,U,V}: explicit init (parity tests)
         self.engine = None
         self.params = None
@@ -103,7 +104,8 @@ class GANMF(BaseRecommender):
         self.num_factors, self.emb_dim = num_factors, emb_dim
         if self.engine is not None:
             self.engine.close()
-        self.engine = Engine(self.num_users, self.num_items, num_factors, emb_dim, batch_size, device=self.device, **hp)
+        self.engine = Engine(self.num_users, self.num_items, num_factors, emb_dim, batch_size, device=self.device,
+                             mfma=self.mfma, **hp)
         self.engine.set_urm(self._URM_fit)
         self.engine.set_seen(self._URM_eval)            # for device-side recommend()
         self.params = {'D': [_TensorRef(t, n) for t, n in self._D_TENSORS],

@@ -70,6 +70,18 @@ int env_int(const char* name, int dflt) {
   return (s && *s) ? atoi(s) : dflt;
 }
 
+// K-loop arithmetic: GANMF_MFMA = f32 | bf16x3 | bf16 overrides the handle's choice (tests, A/B timing)
+constexpr int MFMA_DEFAULT = MFMA_AUTO;
+int env_mfma_mode(int dflt) {
+  const char* v = getenv("GANMF_MFMA");
+  if (!v || !*v) return dflt;
+  if (!strcmp(v, "auto")) return MFMA_AUTO;
+  if (!strcmp(v, "f32")) return MFMA_F32;
+  if (!strcmp(v, "bf16x3")) return MFMA_BF16X3;
+  if (!strcmp(v, "bf16")) return MFMA_BF16;
+  return dflt;
+}
+
 constexpr int ADAM_GRID = 1024;
 constexpr int RED_GRID = GEMM_RED_GRID;
 constexpr int COUNTER_CAP = 1 << 16;
@@ -314,8 +326,9 @@ int run_gemm(ganmf_handle* h, int tag_gemm, int tag_red, GemmP g, bool akm, bool
     const long long key = ((long long)tag_gemm << 48) ^ ((long long)g.M << 32) ^ ((long long)g.N << 16) ^ g.K;
     if (std::find(h->seen_plans.begin(), h->seen_plans.end(), key) == h->seen_plans.end()) {
       h->seen_plans.push_back(key);
-      fprintf(stderr, "[ganmf plan] %-28s M=%d N=%d K=%d batch=%d -> tile %d ring %d nsplit %d (kps %d) wgs %d est %.1f us%s\n",
+      fprintf(stderr, "[ganmf plan] %-28s M=%d N=%d K=%d batch=%d -> tile %d ring %d nsplit %d (kps %d) mfma %s wgs %d est %.1f us%s\n",
               kTagName[tag_gemm], g.M, g.N, g.K, g.nbatch, pl.tile, pl.ring, pl.nsplit, pl.kps,
+              pl.mode == MFMA_BF16X3 ? "bf16x3" : pl.mode == MFMA_BF16 ? "bf16" : "f32",
               pl.tiles_m * pl.tiles_n * pl.nsplit * g.nbatch, pl.est_us, in_launch ? " (in-launch reduce)" : "");
     }
   }
@@ -445,7 +458,7 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
     const bool regD = h->cfg.d_reg != 0.f;
     fused = h->fuse_adam && !dist;
     GemmTune ft;
-    ft.tile = 64; ft.ring = 2; ft.nsplit = 1;
+    ft.tile = 64; ft.ring = 2; ft.nsplit = 1; ft.mode = h->tune.mode;
     auto gemm_gWd = [&]() -> int {  // gWd_ext = (rs*[E|1])^T . Delta   -> rows 0..e-1 = gWd, row e = gbd
       GemmP g{};
       g.A = h->Es; g.lda = h->lde; g.B = h->Dl; g.ldb = h->ldN;
@@ -911,6 +924,7 @@ int ganmf_create(const ganmf_cfg* cfg, ganmf_handle** out) {
   h->tune.ring = env_int("GANMF_RING", 0);
   if (h->tune.ring != 0 && h->tune.ring != 2 && h->tune.ring != 3 && h->tune.ring != 4) h->tune.ring = 0;
   h->tune.nsplit = std::max(0, env_int("GANMF_NSPLIT", 0));
+  h->tune.mode = env_mfma_mode((cfg->flags & GANMF_FLAG_MFMA_BF16) ? MFMA_BF16 : (cfg->flags & GANMF_FLAG_MFMA_F32) ? MFMA_F32 : MFMA_DEFAULT);
   h->debug_plan = env_int("GANMF_DEBUG_PLAN", 0) != 0;
   HIP_TRY(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
   HIP_TRY(hipStreamCreateWithFlags(&h->st2, hipStreamNonBlocking));
@@ -1426,6 +1440,7 @@ int ganmf_gemm_f32(int device, const float* A, const float* B, float* C, int64_t
   g.M = (int)M; g.N = (int)N; g.K = (int)K; g.nbatch = 1; g.epi.kind = EPI_STORE; g.zero_page = zp;
   GemmTune tune;
   tune.tile = tile; tune.nsplit = nsplit;
+  tune.mode = env_mfma_mode(MFMA_DEFAULT);
   tune.ring = env_int("GANMF_RING", 0);
   if (tune.ring != 0 && tune.ring != 2 && tune.ring != 3 && tune.ring != 4) tune.ring = 0;
   const GemmPlan pl = gemm_plan(g.M, g.N, g.K, 1, false, tune);

@@ -17,7 +17,9 @@ def _i32p(a):
 class Engine:
     def __init__(self, num_users, num_items, num_factors, emb_dim, batch_size, d_lr=1e-4, g_lr=1e-4, d_reg=0.0,
                  g_reg=0.0, m=1.0, recon_coefficient=1e-2, model=L.MODEL_GANMF, d_layers=1, d_act="linear",
-                 device=0, world_size=1, rank=0, row_offset=0):
+                 device=0, world_size=1, rank=0, row_offset=0, mfma=None):
+        """mfma: None/"auto" (fp32-accurate, kernel chosen per GEMM), "f32" (plain fp32 MFMA everywhere) or "bf16"
+        (operands rounded to bf16, fp32 accumulate and fp32 master weights/Adam: the mixed-precision variant)."""
         self.lib = L.load_library()
         if self.lib.ganmf_device_count() < 1:
             raise L.GanmfError("no HIP device visible: libganmf_hip has no CPU fallback")
@@ -25,7 +27,7 @@ class Engine:
                     num_factors=num_factors, emb_dim=emb_dim, d_layers=d_layers, d_act=L.ACT[d_act],
                     batch_size=batch_size, d_lr=d_lr, g_lr=g_lr, d_reg=d_reg, g_reg=g_reg, m=m,
                     recon_coefficient=recon_coefficient, device=device, world_size=world_size, rank=rank,
-                    row_offset=row_offset, flags=0)
+                    row_offset=row_offset, flags=L.MFMA_FLAGS[mfma])
         self.cfg = cfg
         self.h = C.c_void_p()
         L.check(self.lib.ganmf_create(C.byref(cfg), C.byref(self.h)), "ganmf_create")
