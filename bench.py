@@ -38,6 +38,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 FLOP/clk/CU x 256 CU x 2.4 GHz
+PEAK_BF16_MFMA_TFLOPS = 2516.6  # same guide: v_mfma_f32_32x32x16_bf16, 4096 FLOP/clk/CU x 256 CU x 2.4 GHz
 PEAK_HBM_GBS = 8000.0          # HBM3E spec; ~6.3 TB/s achievable
 
 C2 = dict(U=6040, N=3706, k=250, e=992, B=128, density=0.035,
@@ -215,11 +216,30 @@ def main():
         step_flops = sum(p["flops"] for p in prof)
         step_ms = sum(p["ms"] for p in prof)
         roofline["whole_step_tflops_kernel_time"] = round(step_flops / step_ms / 1e9, 2)
-        # generator / scoring GEMM at the shape the north star quotes (6040 x 3706, k = 250)
+        # generator / scoring GEMM at the shape the north star quotes (6040 x 3706, k = 250).  The library runs it
+        # on the bf16 matrix cores with every fp32 operand split EXACTLY into three bf16 pieces and the six piece
+        # products of weight >= 2^-16 accumulated in fp32 (fp32-accurate: tests/test_gpu_mfma_modes.py); `achieved`
+        # counts the ALGORITHMIC 2MNK flops against the fp32 MFMA roof (the dtype of operands and result); the
+        # executed bf16 flops (6x) against the bf16 roof and the plain fp32-MFMA kernel are reported beside it.
         ms_sc = eng.bench_scores(w["U"], transposed=False, iters=20)
         sc_tf = 2.0 * w["U"] * w["N"] * w["k"] / ms_sc / 1e9
         scoring = {"shape": [w["U"], w["N"], w["k"]], "ms": round(ms_sc, 4), "achieved": round(sc_tf, 2),
-                   "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(sc_tf / PEAK_F32_MFMA_TFLOPS, 4)}
+                   "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(sc_tf / PEAK_F32_MFMA_TFLOPS, 4),
+                   "arithmetic": "f32 in/out; K loop = 3-way exact bf16 split, 6 piece products on "
+                                 "v_mfma_f32_32x32x16_bf16, f32 accumulate",
+                   "executed_bf16_tflops": round(6 * sc_tf, 1), "peak_bf16": PEAK_BF16_MFMA_TFLOPS,
+                   "frac_of_bf16_peak": round(6 * sc_tf / PEAK_BF16_MFMA_TFLOPS, 4)}
+        try:
+            e32 = Engine(w["U"], w["N"], w["k"], w["e"], w["B"], device=local_rank, mfma="f32", **w["hp"])
+            e32.set_tensor(100, params["U"])
+            e32.set_tensor(101, params["V"])
+            ms32 = e32.bench_scores(w["U"], transposed=False, iters=20)
+            e32.close()
+            tf32 = 2.0 * w["U"] * w["N"] * w["k"] / ms32 / 1e9
+            scoring["plain_f32_mfma"] = {"ms": round(ms32, 4), "achieved": round(tf32, 2),
+                                         "frac": round(tf32 / PEAK_F32_MFMA_TFLOPS, 4)}
+        except Exception as ex:   # never lose the bench line to the side measurement
+            scoring["plain_f32_mfma"] = {"error": str(ex)}
         out = {
             "metric": "GANMF training steps/sec", "value": round(world * done / el, 2), "unit": "steps/s",
             "n_gpus": world, "steps": done, "warmup": warmup, "ms_per_step": round(el / done * 1e3, 4),

@@ -29,6 +29,7 @@
 
 #include "../../include/ganmf_hip.h"
 #include "gemm_f32.hpp"
+#include "gemm_bf16s.hpp"
 #include "kernels.hpp"
 
 using namespace ganmf;
@@ -968,7 +969,7 @@ int ganmf_create(const ganmf_cfg* cfg, ganmf_handle** out) {
     for (int l = 0; l < h->L; ++l) { h->Wl[l].g = gp; gp += h->Wl[l].padded(); }
     h->Wo.g = gp;
   }
-  TRY(dalloc(&h->zero_page, 1024 + 64));   // 4 KiB: one 16-byte line per lane of a workgroup
+  TRY(dalloc(&h->zero_page, 2048 + 64));   // 8 KiB: one 32-byte line per lane of a workgroup
   TRY(dalloc((float**)&h->perm, U));
   TRY(dalloc((float**)&h->pos, U));
   TRY(dalloc(&h->XF, (size_t)2 * B * h->ldN));
@@ -1431,7 +1432,7 @@ int ganmf_gemm_f32(int device, const float* A, const float* B, float* C, int64_t
   const int br = b_kmajor ? K : N, bc = b_kmajor ? N : K;
   const int lda = round_up(ac, LD_ALIGN), ldb = round_up(bc, LD_ALIGN), ldc = round_up((int)N, LD_ALIGN);
   float *dA = nullptr, *dB = nullptr, *dC = nullptr, *slab = nullptr, *zp = nullptr;
-  TRY(dalloc(&zp, 1024 + 64));
+  TRY(dalloc(&zp, 2048 + 64));
   TRY(dalloc(&dA, (size_t)ar * lda)); TRY(dalloc(&dB, (size_t)br * ldb)); TRY(dalloc(&dC, (size_t)M * ldc));
   HIP_TRY(hipMemcpy2D(dA, (size_t)lda * 4, A, (size_t)ac * 4, (size_t)ac * 4, ar, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy2D(dB, (size_t)ldb * 4, B, (size_t)bc * 4, (size_t)bc * 4, br, hipMemcpyHostToDevice));

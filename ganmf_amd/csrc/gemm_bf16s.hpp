@@ -1,0 +1,237 @@
+// fp32 GEMM on the bf16 matrix cores, operands split ONCE when they are staged (gfx950 / CDNA4).
+//
+// Same contract as gemm_f32_mfma (GemmP, operand layouts NT / NN / TN, zero-page convention, split-K slabs,
+// shared epilogue) with a different K loop:
+//   * every fp32 operand element is split exactly into three bf16 pieces x = hi + mid + lo (gemm_f32.hpp,
+//     split_bf16x3) by the thread that LOADS it, and the pieces are written to three LDS planes per operand;
+//     a.b is accumulated in fp32 from the six piece products of weight >= 2^-16 on v_mfma_f32_32x32x16_bf16.
+//     (Splitting at fragment-read time instead — fp32 tiles in LDS, each wave splitting what it reads — repeats the
+//     VALU work in both waves that share a fragment; measured on MI355X, VALU and MFMA issue time ADD on a SIMD
+//     (tools/ubench/mfma_valu.hip), and that variant was 3 % slower at 4096^3 and 30 % slower in bf16 mode.)
+//   * HBM/L2 -> registers -> split -> LDS.  One LDS buffer, the next K-tile prefetched into registers while the
+//     current one is multiplied; two workgroups per CU cover each other's barriers.
+//   * LDS plane layouts (dword = two bf16 with consecutive k, low half first):
+//       K-contiguous operand  [row][BK/2], the 16-byte chunk (8 k's) index XOR-swizzled by the row
+//                             -> one conflict-free ds_read_b128 per piece and fragment;
+//       K-major operand       [k/2][R], the row index XOR 32 on odd groups of four k-pairs
+//                             -> four conflict-free ds_read_b32 per piece and fragment.
+//     A lane (i = lane & 31, h = lane >> 5) holds k = 16c + 8h + 0..7 of MFMA step c for both operands.
+//   * NPIECE = 1 rounds each operand to a single bf16 (RNE): the mixed-precision mode.
+#pragma once
+#include "gemm_f32.hpp"
+
+namespace ganmf {
+
+template <int R, int BK, bool KM>
+struct SplitStage {
+  static constexpr int NW = R * BK / 8;       // work items (8 elements each) per K-tile
+  static constexpr int NI = NW / 256;         // per thread
+  static constexpr int PLANE = R * BK / 2;    // dwords per piece plane
+  static constexpr int CH = BK / 8;           // K-contiguous: 16-byte chunks per row
+  static constexpr int RQ = R / 4;            // K-major: row quads per k-row
+  static_assert(NW % 256 == 0 && NI >= 1, "tile too small for 256 threads");
+  static_assert(BK == 32 || BK == 64, "BK must be 32 or 64");
+
+  __device__ static inline int swz(int row) { return BK == 32 ? (row >> 2) & 3 : (row >> 1) & 7; }
+
+  const float* zp;          // this lane's 32-byte line of the zero page
+  const float* ptr[NI];     // source of the next tile (KM: first of the two k-rows)
+  int aux[NI];              // !KM: pointer increment per tile (0: zero-page lane); KM: first k-row of the item or -1
+  int dst[NI];              // dword offset inside a plane
+
+  __device__ inline void init(const float* __restrict__ base, int ld, int r0, int rlimit, int kbeg,
+                              const float* zero, int tid) {
+    zp = zero + (tid & 255) * 8;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int w = j * 256 + tid;
+      if constexpr (!KM) {
+        const int row = w / CH, c8 = w % CH;
+        const bool ok = (r0 + row) < rlimit;
+        ptr[j] = ok ? base + (size_t)(r0 + row) * ld + kbeg + 8 * c8 : zp;
+        aux[j] = ok ? BK : 0;
+        dst[j] = row * (BK / 2) + 4 * (c8 ^ swz(row));
+      } else {
+        const int kp = w / RQ, rq = w % RQ;
+        const bool ok = (r0 + 4 * rq) < ld;
+        ptr[j] = base + (size_t)(kbeg + 2 * kp) * ld + r0 + 4 * rq;
+        aux[j] = ok ? 2 * kp : -1;
+        dst[j] = kp * R + ((4 * rq) ^ (((kp >> 2) & 1) << 5));
+      }
+    }
+  }
+
+  // fetch this thread's share of the tile that starts kleft k's before the end of the K range
+  __device__ inline void load(float4 (&v)[NI][2], int ld, int kleft) {
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      if constexpr (!KM) {
+        const float* s = ptr[j];
+        v[j][0] = *reinterpret_cast<const float4*>(s);
+        v[j][1] = *reinterpret_cast<const float4*>(s + 4);
+        ptr[j] += aux[j];
+      } else {
+        const float* s0 = (aux[j] >= 0 && aux[j] < kleft) ? ptr[j] : zp;
+        const float* s1 = (aux[j] >= 0 && aux[j] + 1 < kleft) ? ptr[j] + ld : zp;
+        v[j][0] = *reinterpret_cast<const float4*>(s0);
+        v[j][1] = *reinterpret_cast<const float4*>(s1);
+        ptr[j] += (size_t)BK * ld;
+      }
+    }
+  }
+
+  // split / round and write the pieces to the planes at `planes` (piece q at planes + q * PLANE)
+  template <int NPIECE>
+  __device__ inline void store(unsigned* __restrict__ planes, const float4 (&v)[NI][2]) const {
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      float x[8];
+      if constexpr (!KM) {   // 8 consecutive k of one row
+        x[0] = v[j][0].x; x[1] = v[j][0].y; x[2] = v[j][0].z; x[3] = v[j][0].w;
+        x[4] = v[j][1].x; x[5] = v[j][1].y; x[6] = v[j][1].z; x[7] = v[j][1].w;
+      } else {               // (k, k+1) pairs of four consecutive rows
+        x[0] = v[j][0].x; x[1] = v[j][1].x; x[2] = v[j][0].y; x[3] = v[j][1].y;
+        x[4] = v[j][0].z; x[5] = v[j][1].z; x[6] = v[j][0].w; x[7] = v[j][1].w;
+      }
+      u32x4 pc[3];
+      if constexpr (NPIECE == 3) split_bf16x3(x, pc[0], pc[1], pc[2]);
+      else pc[0] = round_bf16(x);
+#pragma unroll
+      for (int q = 0; q < NPIECE; ++q) *reinterpret_cast<u32x4*>(planes + q * PLANE + dst[j]) = pc[q];
+    }
+  }
+
+  // one piece of the fragment of the 32-row block at tile row rb, MFMA step c, lane (i, h)
+  __device__ static inline u32x4 frag(const unsigned* __restrict__ plane, int rb, int c, int i, int h) {
+    if constexpr (!KM) {
+      return *reinterpret_cast<const u32x4*>(plane + (rb + i) * (BK / 2) + 4 * ((2 * c + h) ^ swz(i)));
+    } else {
+      const unsigned* q = plane + (8 * c + 4 * h) * R + ((rb + i) ^ (h << 5));
+      u32x4 r;
+      r[0] = q[0]; r[1] = q[R]; r[2] = q[2 * R]; r[3] = q[3 * R];
+      return r;
+    }
+  }
+};
+
+template <int BM, int BN, int BK, bool AKM, bool BKM, int NPIECE>
+__global__ __launch_bounds__(256) void gemm_bf16s_mfma(const GemmP p) {
+  using SA = SplitStage<BM, BK, AKM>;
+  using SB = SplitStage<BN, BK, BKM>;
+  constexpr int WM = BM / 2, WN = BN / 2;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int NC = BK / 16;
+  static_assert(NPIECE == 1 || NPIECE == 3, "pieces per operand");
+  static_assert(BM % 32 == 0 && BN % 32 == 0, "row XOR of the K-major layout needs 32-row blocks");
+  constexpr int OPER = NPIECE * (SA::PLANE + SB::PLANE);
+  constexpr int LDS_DW = OPER > BM * BN ? OPER : BM * BN;    // the epilogue stages the C tile here
+  __shared__ __attribute__((aligned(16))) float smem[LDS_DW];
+  unsigned* const planes_a = reinterpret_cast<unsigned*>(smem);
+  unsigned* const planes_b = planes_a + NPIECE * SA::PLANE;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+
+  int t = xcd_remap(blockIdx.x, gridDim.x);
+  const int tm = t % p.tiles_m; t /= p.tiles_m;
+  const int tn = t % p.tiles_n; t /= p.tiles_n;
+  const int sp = t % p.nsplit;
+  const int bz = t / p.nsplit;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int kbeg = sp * p.k_per_split;
+  const int kend = min(p.K, kbeg + p.k_per_split);
+  const int nt = (kend - kbeg + BK - 1) / BK;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  SA la;
+  SB lb;
+  la.init(p.A + (size_t)bz * p.a_batch_stride, p.lda, m0, p.M, kbeg, p.zero_page, tid);
+  lb.init(p.B, p.ldb, n0, p.N, kbeg, p.zero_page, tid);
+
+  float4 ra[SA::NI][2], rb[SB::NI][2];
+  int kleft = kend - kbeg;
+  la.load(ra, p.lda, kleft);
+  lb.load(rb, p.ldb, kleft);
+  kleft -= BK;
+  la.template store<NPIECE>(planes_a, ra);
+  lb.template store<NPIECE>(planes_b, rb);
+  __syncthreads();
+
+  u32x4 pa[2][TM][NPIECE], pb[2][TN][NPIECE];
+  auto load_frags = [&](int set, int c) {
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int q = 0; q < NPIECE; ++q) pa[set][a][q] = SA::frag(planes_a + q * SA::PLANE, wr * WM + a * 32, c, li, lh);
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int q = 0; q < NPIECE; ++q) pb[set][b][q] = SB::frag(planes_b + q * SB::PLANE, wc * WN + b * 32, c, li, lh);
+  };
+  auto mfmas = [&](int set) {
+    // piece products in increasing weight, blocks innermost (dependent MFMAs are TM*TN issues apart)
+    constexpr int NT = NPIECE == 3 ? 6 : 1;
+    constexpr int ta[6] = {1, 0, 2, 1, 0, 0}, tb[6] = {1, 2, 0, 0, 1, 0};   // (mid,mid) (hi,lo) (lo,hi) (mid,hi) (hi,mid) (hi,hi)
+#pragma unroll
+    for (int t6 = 0; t6 < NT; ++t6)
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+          const int ia = NT == 6 ? ta[t6] : 0, ib = NT == 6 ? tb[t6] : 0;
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pa[set][a][ia]),
+                                                              __builtin_bit_cast(bf16x8, pb[set][b][ib]), acc[a][b], 0, 0, 0);
+        }
+  };
+
+  for (int it = 0; it < nt; ++it) {
+    const bool more = it + 1 < nt;
+    if (more) {                      // next K-tile into registers while this one is multiplied
+      la.load(ra, p.lda, kleft);
+      lb.load(rb, p.ldb, kleft);
+      kleft -= BK;
+    }
+    load_frags(0, 0);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      if (c + 1 < NC) load_frags((c + 1) & 1, c + 1);
+      mfmas(c & 1);
+    }
+    __syncthreads();                 // every wave has read its fragments: the planes may be overwritten
+    if (more) {
+      la.template store<NPIECE>(planes_a, ra);
+      lb.template store<NPIECE>(planes_b, rb);
+      __syncthreads();
+    }
+  }
+  gemm_epilogue<BM, BN, TM, TN>(p, acc, smem, TileCoord{tm, tn, sp, bz, m0, n0});
+}
+
+template <int BM, int BN, int BK, int NPIECE>
+inline hipError_t gemm_bf16s_launch(hipStream_t st, const GemmP& p, bool akm, bool bkm) {
+  const int grid = p.tiles_m * p.tiles_n * p.nsplit * p.nbatch;
+  if (grid <= 0) return hipSuccess;
+  if (!akm && !bkm) hipLaunchKernelGGL((gemm_bf16s_mfma<BM, BN, BK, false, false, NPIECE>), dim3(grid), dim3(256), 0, st, p);
+  else if (!akm && bkm) hipLaunchKernelGGL((gemm_bf16s_mfma<BM, BN, BK, false, true, NPIECE>), dim3(grid), dim3(256), 0, st, p);
+  else if (akm && bkm) hipLaunchKernelGGL((gemm_bf16s_mfma<BM, BN, BK, true, true, NPIECE>), dim3(grid), dim3(256), 0, st, p);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+inline hipError_t gemm_dispatch_staged(hipStream_t st, const GemmP& p, bool akm, bool bkm, const GemmPlan& pl) {
+  if (pl.mode == MFMA_BF16X3)
+    return pl.tile == 128 ? gemm_bf16s_launch<128, 128, 32, 3>(st, p, akm, bkm) : gemm_bf16s_launch<64, 64, 64, 3>(st, p, akm, bkm);
+  return pl.tile == 128 ? gemm_bf16s_launch<128, 128, 32, 1>(st, p, akm, bkm) : gemm_bf16s_launch<64, 64, 64, 1>(st, p, akm, bkm);
+}
+
+}  // namespace ganmf

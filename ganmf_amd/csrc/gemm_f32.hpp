@@ -40,15 +40,15 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-// MFMA arithmetic of the K loop (template parameter MODE of the GEMM kernel):
-//   MFMA_F32    v_mfma_f32_32x32x2_f32 on the fp32 operands (256 FLOP/clk/CU)
-//   MFMA_BF16X3 every fp32 operand is split EXACTLY into three bf16 pieces x = hi + mid + lo (8 + 8 + 8
-//               mantissa bits, truncation, so the sum is bit-exact) and a.b is accumulated in fp32 from the six
-//               piece products of weight >= 2^-16 (hi.hi, hi.mid, mid.hi, hi.lo, lo.hi, mid.mid) on
+// MFMA arithmetic of the K loop (GemmPlan::mode):
+//   MFMA_F32    gemm_f32_mfma below: v_mfma_f32_32x32x2_f32 on the fp32 operands (256 FLOP/clk/CU)
+//   MFMA_BF16X3 gemm_bf16s.hpp: every fp32 operand is split EXACTLY into three bf16 pieces x = hi + mid + lo
+//               (8 + 8 + 8 mantissa bits, truncation, so the sum is bit-exact) and a.b is accumulated in fp32 from
+//               the six piece products of weight >= 2^-16 (hi.hi, hi.mid, mid.hi, hi.lo, lo.hi, mid.mid) on
 //               v_mfma_f32_32x32x16_bf16 (4096 FLOP/clk/CU): 6/16 of the fp32 MFMA time; the three dropped
 //               products are <= 2^-24 |a||b| each, the size of one fp32 rounding of the product.
-//   MFMA_BF16   operands rounded to one bf16 (round to nearest even), fp32 accumulate: the mixed-precision
-//               variant BASELINE configs[4] asks for (master weights and Adam stay fp32).
+//   MFMA_BF16   gemm_bf16s.hpp: operands rounded to one bf16 (round to nearest even), fp32 accumulate: the
+//               mixed-precision variant BASELINE configs[4] asks for (master weights and Adam stay fp32).
 enum MfmaMode : int { MFMA_AUTO = -1, MFMA_F32 = 0, MFMA_BF16 = 1, MFMA_BF16X3 = 3 };
 
 constexpr unsigned PERM_HI16 = 0x07060302u;   // v_perm_b32(S0, S1): {S0[31:16], S1[31:16]}
@@ -287,20 +287,6 @@ struct Stage {
       return make_float4(q[0], q[R], q[2 * R], q[3 * R]);
     }
   }
-
-  // bf16 modes: the 8 operands j = 0..7 with k = 16c + 8h + j of the 32x32x16 MFMA step c
-  __device__ static inline void frag8(const float* __restrict__ s, int rb, int c, int i, int h, float (&x)[8]) {
-    if constexpr (!KM) {
-      const float* row = s + (rb + i) * BK;
-      const float4 u = *reinterpret_cast<const float4*>(row + 4 * ((4 * c + 2 * h) ^ swz(i)));
-      const float4 w = *reinterpret_cast<const float4*>(row + 4 * ((4 * c + 2 * h + 1) ^ swz(i)));
-      x[0] = u.x; x[1] = u.y; x[2] = u.z; x[3] = u.w; x[4] = w.x; x[5] = w.y; x[6] = w.z; x[7] = w.w;
-    } else {
-      const float* q = s + (c * 16 + 8 * h) * R + rb + i;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) x[j] = q[j * R];
-    }
-  }
 };
 
 __device__ inline int xcd_remap(int bid, int nwg) {
@@ -309,200 +295,19 @@ __device__ inline int xcd_remap(int bid, int nwg) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
 }
 
-template <int BM, int BN, int BK, int NS, bool AKM, bool BKM, int MODE>
-__global__ __launch_bounds__(256) void gemm_f32_mfma(const GemmP p) {
-  using SA = Stage<BM, BK, AKM>;
-  using SB = Stage<BN, BK, BKM>;
-  constexpr int WM = BM / 2, WN = BN / 2;
-  constexpr int TM = WM / 32, TN = WN / 32;
-  static_assert(TM >= 1 && TN >= 1, "wave tile must hold at least one 32x32 MFMA block");
-  static_assert(NS >= 2 && NS <= 4, "ring depth");
-  constexpr int BUF = SA::SZ + SB::SZ;            // ring slot b: A at smem + b*BUF, B right behind
-  constexpr int LOADS = SA::NP + SB::NP;          // glds per wave per tile
-  __shared__ __attribute__((aligned(16))) float smem[NS * BUF];   // the ONLY LDS object (cdna guide §5 item 4a)
+// ---- epilogue shared by every GEMM kernel.  C/D layout of the 32x32 MFMA: col = lane & 31,
+// row = (reg&3) + 8*(reg>>2) + 4*(lane>>5), i.e. a lane owns a column.  `smem` must hold BM*BN floats and be idle.
+struct TileCoord { int tm, tn, sp, bz, m0, n0; };
 
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
+template <int BM, int BN, int TM, int TN>
+__device__ inline void gemm_epilogue(const GemmP& p, const f32x16 (&acc)[TM][TN], float* smem, const TileCoord& tc_) {
+  constexpr int WM = BM / 2, WN = BN / 2;
+  const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
   const int li = lane & 31, lh = lane >> 5;
-
-  int t = xcd_remap(blockIdx.x, gridDim.x);
-  const int tm = t % p.tiles_m; t /= p.tiles_m;
-  const int tn = t % p.tiles_n; t /= p.tiles_n;
-  const int sp = t % p.nsplit;
-  const int bz = t / p.nsplit;
-
-  const int m0 = tm * BM, n0 = tn * BN;
-  const int kbeg = sp * p.k_per_split;
-  const int kend = min(p.K, kbeg + p.k_per_split);
-  const int nt = (kend - kbeg + BK - 1) / BK;
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int a = 0; a < TM; ++a)
-#pragma unroll
-    for (int b = 0; b < TN; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-  SA la;
-  SB lb;
-  la.init(p.A + (size_t)bz * p.a_batch_stride, p.lda, m0, p.M, kbeg, p.zero_page, tid);
-  lb.init(p.B, p.ldb, n0, p.N, kbeg, p.zero_page, tid);
-
-  // A K-tile is walked in NC chunks: 8 k's (four 32x32x2 fp32 MFMAs per block) or 16 k's (one 32x32x16 bf16
-  // MFMA per piece product and block).  Chunk c uses fragment set c & 1 (NC is even).
-  constexpr int KC = MODE == MFMA_F32 ? 8 : 16;
-  constexpr int NC = BK / KC;
-  constexpr int NP = MODE == MFMA_BF16X3 ? 3 : 1;   // bf16 pieces per operand
-  static_assert(NC >= 2 && NC % 2 == 0, "chunks per tile");
-  float4 fa[2][TM], fb[2][TN];                       // MFMA_F32 fragments
-  u32x4 pa[2][TM][NP], pb[2][TN][NP];                // bf16 piece fragments
-  auto load_one = [&](auto is_a, int set, const float* __restrict__ tile, int c, int blk) {
-    constexpr bool A = decltype(is_a)::value;
-    if constexpr (MODE == MFMA_F32) {
-      if constexpr (A) fa[set][blk] = SA::frag(tile, wr * WM + blk * 32, c, li, lh);
-      else fb[set][blk] = SB::frag(tile + SA::SZ, wc * WN + blk * 32, c, li, lh);
-    } else {
-      float x[8];
-      if constexpr (A) SA::frag8(tile, wr * WM + blk * 32, c, li, lh, x);
-      else SB::frag8(tile + SA::SZ, wc * WN + blk * 32, c, li, lh, x);
-      u32x4 pc[3];
-      if constexpr (MODE == MFMA_BF16X3) split_bf16x3(x, pc[0], pc[1], pc[2]);
-      else pc[0] = round_bf16(x);
-#pragma unroll
-      for (int q = 0; q < NP; ++q) {
-        if constexpr (A) pa[set][blk][q] = pc[q];
-        else pb[set][blk][q] = pc[q];
-      }
-    }
-  };
-  auto load_frags = [&](int set, const float* __restrict__ tile, int c) {
-#pragma unroll
-    for (int a = 0; a < TM; ++a) load_one(std::true_type{}, set, tile, c, a);
-#pragma unroll
-    for (int b = 0; b < TN; ++b) load_one(std::false_type{}, set, tile, c, b);
-  };
-  auto mfmas = [&](int set) {
-    if constexpr (MODE == MFMA_F32) {
-#pragma unroll
-      for (int a = 0; a < TM; ++a)
-#pragma unroll
-        for (int b = 0; b < TN; ++b) {
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][a].x, fb[set][b].x, acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][a].y, fb[set][b].y, acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][a].z, fb[set][b].z, acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][a].w, fb[set][b].w, acc[a][b], 0, 0, 0);
-        }
-    } else {
-      // piece products in increasing weight, blocks innermost (dependent MFMAs are TM*TN issues apart)
-      constexpr int NT = MODE == MFMA_BF16X3 ? 6 : 1;
-      constexpr int ta[6] = {1, 0, 2, 1, 0, 0}, tb[6] = {1, 2, 0, 0, 1, 0};   // (mid,mid) (hi,lo) (lo,hi) (mid,hi) (hi,mid) (hi,hi)
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-          for (int b = 0; b < TN; ++b) {
-            const int ia = NT == 6 ? ta[t] : 0, ib = NT == 6 ? tb[t] : 0;
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pa[set][a][ia]),
-                                                                __builtin_bit_cast(bf16x8, pb[set][b][ib]), acc[a][b], 0, 0, 0);
-          }
-    }
-  };
-
-  // prologue: tiles 0 .. min(NS, nt)-1 in flight.  No loads are issued past the K range (a dummy tile
-  // makes every lane of every workgroup read the same zero-page line: an L2 hot spot that cost
-  // 20-40 us on the short-K GEMMs); the tail therefore waits with vmcnt(0) instead of the counted wait.
-  int kleft = kend - kbeg;   // k's remaining from the next tile to issue
-#pragma unroll
-  for (int s = 0; s < NS; ++s) {
-    if (kleft > 0) {
-      la.issue(smem + s * BUF, p.lda, kleft, p.zero_page, wave);
-      lb.issue(smem + s * BUF + SA::SZ, p.ldb, kleft, p.zero_page, wave);
-    }
-    kleft -= BK;
-  }
-  if (nt >= NS) GANMF_WAIT_VMCNT((NS - 1) * LOADS);   // tile 0 of this wave has landed ...
-  else GANMF_WAIT_VMCNT(0);
-  __builtin_amdgcn_s_barrier();                        // ... and of every other wave
-  load_frags(0, smem, 0);
-
-  // The refill of a freed ring slot is spread over the chunks of the FOLLOWING tile, LOADS / NC glds per
-  // chunk: a single wave per SIMD issues in order, so the ~60 address/issue instructions of a whole
-  // tile in one block stall the MFMA pipe at every tile boundary; one or two pieces per chunk hide in
-  // the MFMA gaps.  (All pieces of a tile are still issued between two boundary waits, so the counted
-  // vmcnt bookkeeping is unchanged.)
-  constexpr int PPC = (LOADS + NC - 1) / NC;      // pieces per chunk
-  int slot = 0;         // ring slot of tile `it`
-  int pend_slot = 0;    // slot being refilled during this tile (freed at the previous boundary)
-  int pend_kleft = 0;   // <= 0: nothing to refill
-  // fp32 mode spreads the refill over the chunks (see above); the bf16 modes have far fewer MFMA cycles per
-  // tile to hide issue slots in and issue the whole refill in one guarded group at the top of the tile.
-  auto refill_chunk = [&](auto cc) {
-    constexpr int c = decltype(cc)::value;
-    if (pend_kleft > 0) {
-      float* base = smem + pend_slot * BUF;
-      constexpr int q0 = c * PPC < LOADS ? c * PPC : LOADS, q1 = (c + 1) * PPC < LOADS ? (c + 1) * PPC : LOADS;
-      // pieces [0, NP_A) belong to A, [NP_A, LOADS) to B
-      constexpr int a0 = q0 < SA::NP ? q0 : SA::NP, a1 = q1 < SA::NP ? q1 : SA::NP;
-      constexpr int b0 = q0 > SA::NP ? q0 - SA::NP : 0, b1 = q1 > SA::NP ? q1 - SA::NP : 0;
-      la.template issue_range<a0, a1>(base, p.lda, pend_kleft, wave);
-      lb.template issue_range<b0, b1>(base + SA::SZ, p.ldb, pend_kleft, wave);
-    }
-  };
-  // Two loops, not one loop with a conditional wait: tiles that still have NS-1 younger tiles behind them wait
-  // with the counted vmcnt, the last NS-1 tiles drain with vmcnt(0).
-  auto tile = [&](auto tail_tag) {
-    constexpr bool TAIL = decltype(tail_tag)::value;
-    const float* __restrict__ cur = smem + slot * BUF;
-    const int nslot = (slot + 1 == NS) ? 0 : slot + 1;
-    if constexpr (MODE != MFMA_F32) {
-      if (pend_kleft > 0) {
-        la.issue(smem + pend_slot * BUF, p.lda, pend_kleft, p.zero_page, wave);
-        lb.issue(smem + pend_slot * BUF + SA::SZ, p.ldb, pend_kleft, p.zero_page, wave);
-      }
-    }
-    static_for<0, NC>([&](auto cc) {
-      constexpr int c = decltype(cc)::value;
-      if constexpr (c + 1 < NC) {
-        load_frags((c + 1) & 1, cur, c + 1);     // next chunk's fragments under this chunk's MFMAs
-        if constexpr (MODE == MFMA_F32) {
-          refill_chunk(cc);
-          __builtin_amdgcn_sched_barrier(0);     // keep the reads ahead of the MFMAs (hipcc sinks them)
-        }
-      } else {
-        // Last chunk: its fragments are in registers once lgkmcnt drains, so this wave no longer
-        // reads slot `slot`.  Tile it+1 has landed when at most NS-2 younger tiles are outstanding
-        // (tiles it+2 .. it+NS-1 exist only while it+NS-1 < nt; in the tail nothing younger is in
-        // flight and the wait is vmcnt(0)); after the barrier that holds for every wave and slot
-        // `slot` is free: tile it+NS is refilled into it during the next tile.
-        if constexpr (MODE == MFMA_F32) refill_chunk(cc);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if constexpr (TAIL) GANMF_WAIT_VMCNT(0);
-        else GANMF_WAIT_VMCNT((NS - 2) * LOADS);
-        __builtin_amdgcn_s_barrier();
-        pend_slot = slot;
-        pend_kleft = kleft;
-        kleft -= BK;
-        load_frags(0, smem + nslot * BUF, 0);    // first fragments of tile it+1 under the last MFMAs
-        if constexpr (MODE == MFMA_F32) __builtin_amdgcn_sched_barrier(0);
-      }
-      mfmas(c & 1);
-    });
-    slot = nslot;
-  };
-  int it = 0;
-  for (; it + NS - 1 < nt; ++it) tile(std::false_type{});
-  for (; it < nt; ++it) tile(std::true_type{});
-  // nothing is in flight any more; LDS reads must be done before the ring is reused as C staging
-  GANMF_WAIT_VMCNT(0);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-
-  // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5),
-  // i.e. a lane owns a column.  Stored straight from registers that is one dword per lane per
+  const int tm = tc_.tm, tn = tc_.tn, sp = tc_.sp, bz = tc_.bz, m0 = tc_.m0, n0 = tc_.n0;
+  // Stored straight from registers that is one dword per lane per
   // instruction (measured ~2 TB/s chip-wide on 15-90 MB outputs); instead the tile is staged
   // through the now idle ring as a natural [BM][BN] image and written as whole rows, 16 B per lane.
   float* __restrict__ ct = smem;
@@ -636,6 +441,150 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const GemmP p) {
   }
 }
 
+template <int BM, int BN, int BK, int NS, bool AKM, bool BKM>
+__global__ __launch_bounds__(256) void gemm_f32_mfma(const GemmP p) {
+  using SA = Stage<BM, BK, AKM>;
+  using SB = Stage<BN, BK, BKM>;
+  constexpr int WM = BM / 2, WN = BN / 2;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  static_assert(TM >= 1 && TN >= 1, "wave tile must hold at least one 32x32 MFMA block");
+  static_assert(NS >= 2 && NS <= 4, "ring depth");
+  constexpr int BUF = SA::SZ + SB::SZ;            // ring slot b: A at smem + b*BUF, B right behind
+  constexpr int LOADS = SA::NP + SB::NP;          // glds per wave per tile
+  __shared__ __attribute__((aligned(16))) float smem[NS * BUF];   // the ONLY LDS object (cdna guide §5 item 4a)
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+
+  int t = xcd_remap(blockIdx.x, gridDim.x);
+  const int tm = t % p.tiles_m; t /= p.tiles_m;
+  const int tn = t % p.tiles_n; t /= p.tiles_n;
+  const int sp = t % p.nsplit;
+  const int bz = t / p.nsplit;
+
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int kbeg = sp * p.k_per_split;
+  const int kend = min(p.K, kbeg + p.k_per_split);
+  const int nt = (kend - kbeg + BK - 1) / BK;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  SA la;
+  SB lb;
+  la.init(p.A + (size_t)bz * p.a_batch_stride, p.lda, m0, p.M, kbeg, p.zero_page, tid);
+  lb.init(p.B, p.ldb, n0, p.N, kbeg, p.zero_page, tid);
+
+  constexpr int NC = BK / 8;   // 8-wide k chunks per tile (even: chunk c uses fragment set c & 1)
+  float4 fa[2][TM], fb[2][TN];
+  auto load_frags = [&](int set, const float* __restrict__ tile, int c) {
+#pragma unroll
+    for (int a = 0; a < TM; ++a) fa[set][a] = SA::frag(tile, wr * WM + a * 32, c, li, lh);
+#pragma unroll
+    for (int b = 0; b < TN; ++b) fb[set][b] = SB::frag(tile + SA::SZ, wc * WN + b * 32, c, li, lh);
+  };
+  auto mfmas = [&](int set) {
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][a].x, fb[set][b].x, acc[a][b], 0, 0, 0);
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][a].y, fb[set][b].y, acc[a][b], 0, 0, 0);
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][a].z, fb[set][b].z, acc[a][b], 0, 0, 0);
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][a].w, fb[set][b].w, acc[a][b], 0, 0, 0);
+      }
+  };
+
+  // prologue: tiles 0 .. min(NS, nt)-1 in flight.  No loads are issued past the K range (a dummy tile
+  // makes every lane of every workgroup read the same zero-page line: an L2 hot spot that cost
+  // 20-40 us on the short-K GEMMs); the tail therefore waits with vmcnt(0) instead of the counted wait.
+  int kleft = kend - kbeg;   // k's remaining from the next tile to issue
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    if (kleft > 0) {
+      la.issue(smem + s * BUF, p.lda, kleft, p.zero_page, wave);
+      lb.issue(smem + s * BUF + SA::SZ, p.ldb, kleft, p.zero_page, wave);
+    }
+    kleft -= BK;
+  }
+  if (nt >= NS) GANMF_WAIT_VMCNT((NS - 1) * LOADS);   // tile 0 of this wave has landed ...
+  else GANMF_WAIT_VMCNT(0);
+  __builtin_amdgcn_s_barrier();                        // ... and of every other wave
+  load_frags(0, smem, 0);
+
+  // The refill of a freed ring slot is spread over the chunks of the FOLLOWING tile, LOADS / NC glds per
+  // chunk: a single wave per SIMD issues in order, so the ~60 address/issue instructions of a whole
+  // tile in one block stall the MFMA pipe at every tile boundary; one or two pieces per chunk hide in
+  // the MFMA gaps.  (All pieces of a tile are still issued between two boundary waits, so the counted
+  // vmcnt bookkeeping is unchanged.)
+  constexpr int PPC = (LOADS + NC - 1) / NC;      // pieces per chunk
+  int slot = 0;         // ring slot of tile `it`
+  int pend_slot = 0;    // slot being refilled during this tile (freed at the previous boundary)
+  int pend_kleft = 0;   // <= 0: nothing to refill
+  auto refill_chunk = [&](auto cc) {
+    constexpr int c = decltype(cc)::value;
+    if (pend_kleft > 0) {
+      float* base = smem + pend_slot * BUF;
+      constexpr int q0 = c * PPC < LOADS ? c * PPC : LOADS, q1 = (c + 1) * PPC < LOADS ? (c + 1) * PPC : LOADS;
+      // pieces [0, NP_A) belong to A, [NP_A, LOADS) to B
+      constexpr int a0 = q0 < SA::NP ? q0 : SA::NP, a1 = q1 < SA::NP ? q1 : SA::NP;
+      constexpr int b0 = q0 > SA::NP ? q0 - SA::NP : 0, b1 = q1 > SA::NP ? q1 - SA::NP : 0;
+      la.template issue_range<a0, a1>(base, p.lda, pend_kleft, wave);
+      lb.template issue_range<b0, b1>(base + SA::SZ, p.ldb, pend_kleft, wave);
+    }
+  };
+  // Two loops, not one loop with a conditional wait: tiles that still have NS-1 younger tiles behind them wait
+  // with the counted vmcnt, the last NS-1 tiles drain with vmcnt(0).
+  auto tile = [&](auto tail_tag) {
+    constexpr bool TAIL = decltype(tail_tag)::value;
+    const float* __restrict__ cur = smem + slot * BUF;
+    const int nslot = (slot + 1 == NS) ? 0 : slot + 1;
+    static_for<0, NC>([&](auto cc) {
+      constexpr int c = decltype(cc)::value;
+      if constexpr (c + 1 < NC) {
+        load_frags((c + 1) & 1, cur, c + 1);     // next chunk's fragments under this chunk's MFMAs
+        refill_chunk(cc);
+        __builtin_amdgcn_sched_barrier(0);       // keep the reads ahead of the MFMAs (hipcc sinks them)
+      } else {
+        // Last chunk: its fragments are in registers once lgkmcnt drains, so this wave no longer
+        // reads slot `slot`.  Tile it+1 has landed when at most NS-2 younger tiles are outstanding
+        // (tiles it+2 .. it+NS-1 exist only while it+NS-1 < nt; in the tail nothing younger is in
+        // flight and the wait is vmcnt(0)); after the barrier that holds for every wave and slot
+        // `slot` is free: tile it+NS is refilled into it during the next tile.
+        refill_chunk(cc);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (TAIL) GANMF_WAIT_VMCNT(0);
+        else GANMF_WAIT_VMCNT((NS - 2) * LOADS);
+        __builtin_amdgcn_s_barrier();
+        pend_slot = slot;
+        pend_kleft = kleft;
+        kleft -= BK;
+        load_frags(0, smem + nslot * BUF, 0);    // first fragments of tile it+1 under the last MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      mfmas(c & 1);
+    });
+    slot = nslot;
+  };
+  int it = 0;
+  for (; it + NS - 1 < nt; ++it) tile(std::false_type{});
+  for (; it < nt; ++it) tile(std::true_type{});
+  // nothing is in flight any more; LDS reads must be done before the ring is reused as C staging
+  GANMF_WAIT_VMCNT(0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  gemm_epilogue<BM, BN, TM, TN>(p, acc, smem, TileCoord{tm, tn, sp, bz, m0, n0});
+}
+
 // Reduce split-K slabs and apply the deferred epilogue: out[m,n] = epi(sum_s part[s][m,n]).
 // grid = (gx, nbatch); columns >= N are never written (ones / pad columns keep their values).
 struct RedP {
@@ -752,8 +701,8 @@ inline GemmPlan gemm_plan(int M, int N, int K, int nbatch, bool wants_sq, const 
   best.ring = tune.ring ? tune.ring : (wgs > GEMM_CUS ? 2 : 3);
   if (best.nsplit == 1) best.kps = ((K + GEMM_K_ALIGN - 1) / GEMM_K_ALIGN) * GEMM_K_ALIGN;
   // MFMA_AUTO: the split-bf16 K loop wins where the fp32 K loop is MFMA-bound — 128x128 tiles with at least two
-  // workgroups per CU (measured 112 vs 78 TFLOP/s on 6040x3706x250, 155 vs 120 on 4096^3); the skinny GEMMs of
-  // a 128-row training step are ingest/epilogue-bound and lose 4 % to the split's VALU work, so they stay fp32.
+  // workgroups per CU (measured 108 vs 78 TFLOP/s on 6040x3706x250, 161 vs 120 on 4096^3); the skinny GEMMs of
+  // a 128-row training step are ingest/epilogue-bound and lose 4-7 % to the split's VALU work, so they stay fp32.
   best.mode = tune.mode != MFMA_AUTO ? tune.mode : (best.tile == 128 && wgs >= 2 * GEMM_CUS ? MFMA_BF16X3 : MFMA_F32);
   best.sq_count = wants_sq ? best.tiles_m * best.tiles_n : 0;   // (separate reduce kernel: GEMM_RED_GRID, set by gemm_run)
   return best;
@@ -763,22 +712,15 @@ inline size_t gemm_slab_elems(const GemmPlan& pl, int M, int ldc, int nbatch) {
   return pl.nsplit > 1 ? (size_t)pl.nsplit * nbatch * M * ldc : 0;
 }
 
-template <int BM, int BN, int BK, int NS, int MODE>
-inline hipError_t gemm_launch_m(hipStream_t st, const GemmP& p, bool akm, bool bkm) {
+template <int BM, int BN, int BK, int NS>
+inline hipError_t gemm_launch_t(hipStream_t st, const GemmP& p, bool akm, bool bkm) {
   const int grid = p.tiles_m * p.tiles_n * p.nsplit * p.nbatch;
   if (grid <= 0) return hipSuccess;
-  if (!akm && !bkm) hipLaunchKernelGGL((gemm_f32_mfma<BM, BN, BK, NS, false, false, MODE>), dim3(grid), dim3(256), 0, st, p);
-  else if (!akm && bkm) hipLaunchKernelGGL((gemm_f32_mfma<BM, BN, BK, NS, false, true, MODE>), dim3(grid), dim3(256), 0, st, p);
-  else if (akm && bkm) hipLaunchKernelGGL((gemm_f32_mfma<BM, BN, BK, NS, true, true, MODE>), dim3(grid), dim3(256), 0, st, p);
+  if (!akm && !bkm) hipLaunchKernelGGL((gemm_f32_mfma<BM, BN, BK, NS, false, false>), dim3(grid), dim3(256), 0, st, p);
+  else if (!akm && bkm) hipLaunchKernelGGL((gemm_f32_mfma<BM, BN, BK, NS, false, true>), dim3(grid), dim3(256), 0, st, p);
+  else if (akm && bkm) hipLaunchKernelGGL((gemm_f32_mfma<BM, BN, BK, NS, true, true>), dim3(grid), dim3(256), 0, st, p);
   else return hipErrorInvalidValue;  // TT is not needed by the GANMF step
   return hipGetLastError();
-}
-
-template <int BM, int BN, int BK, int NS>
-inline hipError_t gemm_launch_t(hipStream_t st, const GemmP& p, bool akm, bool bkm, int mode) {
-  if (mode == MFMA_BF16X3) return gemm_launch_m<BM, BN, BK, NS, MFMA_BF16X3>(st, p, akm, bkm);
-  if (mode == MFMA_BF16) return gemm_launch_m<BM, BN, BK, NS, MFMA_BF16>(st, p, akm, bkm);
-  return gemm_launch_m<BM, BN, BK, NS, MFMA_F32>(st, p, akm, bkm);
 }
 
 struct GemmPlan;
@@ -814,11 +756,14 @@ inline hipError_t gemm_run(hipStream_t st, GemmP p, bool akm, bool bkm, const Ge
   return hipGetLastError();
 }
 
+// staged bf16 kernels (gemm_bf16s.hpp, included by the translation unit after this header)
+inline hipError_t gemm_dispatch_staged(hipStream_t st, const GemmP& p, bool akm, bool bkm, const GemmPlan& pl);
+
 inline hipError_t gemm_dispatch(hipStream_t st, const GemmP& p, bool akm, bool bkm, const GemmPlan& pl) {
-  const int m = pl.mode;
-  if (pl.tile == 128) return pl.ring >= 3 ? gemm_launch_t<128, 128, 32, 3>(st, p, akm, bkm, m) : gemm_launch_t<128, 128, 32, 2>(st, p, akm, bkm, m);
-  if (pl.ring == 4) return gemm_launch_t<64, 64, 64, 4>(st, p, akm, bkm, m);   // 128 KiB ring: three K-tiles (96 KiB) in flight
-  return pl.ring == 3 ? gemm_launch_t<64, 64, 64, 3>(st, p, akm, bkm, m) : gemm_launch_t<64, 64, 64, 2>(st, p, akm, bkm, m);
+  if (pl.mode == MFMA_BF16 || pl.mode == MFMA_BF16X3) return gemm_dispatch_staged(st, p, akm, bkm, pl);
+  if (pl.tile == 128) return pl.ring >= 3 ? gemm_launch_t<128, 128, 32, 3>(st, p, akm, bkm) : gemm_launch_t<128, 128, 32, 2>(st, p, akm, bkm);
+  if (pl.ring == 4) return gemm_launch_t<64, 64, 64, 4>(st, p, akm, bkm);   // 128 KiB ring: three K-tiles (96 KiB) in flight
+  return pl.ring == 3 ? gemm_launch_t<64, 64, 64, 3>(st, p, akm, bkm) : gemm_launch_t<64, 64, 64, 2>(st, p, akm, bkm);
 }
 
 }  // namespace ganmf
