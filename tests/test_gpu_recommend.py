@@ -154,3 +154,22 @@ def test_save_load_model_round_trip_in_reference_format(tmp_path, golden_dir):
     d2 = DisGANMF(urm, mode="user", is_experiment=True)
     d2.load_bundle(str(tmp_path), "dis", 4, 2, 8, "tanh")
     assert np.array_equal(d2._compute_item_score(users[:9]), d._compute_item_score(users[:9]))
+
+
+def test_trial_parallel_tuner_on_gpu(tmp_path, golden_dir):
+    """ganmf_amd.tune with the real GANMF class: two worker processes share the GPU, each running whole trials
+    (fit with early stopping on the device evaluator, validation, engine teardown)."""
+    from GANRec.GANMF import GANMF
+    from ganmf_amd import tune
+    train = sps.load_npz(os.path.join(golden_dir, "hetrec2011_URM_train_small.npz")).tocsr()[:600, :900]
+    val = sps.load_npz(os.path.join(golden_dir, "hetrec2011_URM_validation.npz")).tocsr()[:600, :900]
+    t = tune.TrialParallelTuner(GANMF, train, val, val, str(tmp_path / "tune"), seed=3, n_workers=2, devices=[0])
+    for d in t.dims:                       # keep the trials short
+        if d.name == "epochs":
+            d.choices = [12]
+        if d.name in ("num_factors", "emb_dim"):
+            d.high = 32
+    best, params = t.tune(evals=4, verbose=False)
+    assert len(t.func_vals) == 4 and all(np.isfinite(t.func_vals))
+    assert "trial failed" not in open(os.path.join(str(tmp_path / "tune"), "results.txt")).read()
+    assert best < 0 and set(params) == {d.name for d in t.dims}

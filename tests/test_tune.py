@@ -1,0 +1,96 @@
+"""ganmf_amd.tune: search spaces of RecSysExp.py:502-523, objective bookkeeping of :246-311, trial-parallel
+execution and resume.  CPU only (stand-in recommender in tests/helpers_tune.py)."""
+import json
+import os
+import pickle
+import sys
+
+import numpy as np
+import pytest
+import scipy.sparse as sps
+
+from ganmf_amd import tune
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _data(seed=0, n_users=120, n_items=60):
+    rng = np.random.RandomState(seed)
+    pop = rng.zipf(1.5, n_items).astype(np.float64)
+    p = pop / pop.sum()
+    def draw(n):
+        m = np.zeros((n_users, n_items), np.float32)
+        for u in range(n_users):
+            m[u, rng.choice(n_items, size=n, replace=False, p=p)] = 1
+        return m
+    full = draw(12)
+    mask = rng.rand(n_users, n_items)
+    return (sps.csr_matrix(full * (mask < 0.6)), sps.csr_matrix(full * ((mask >= 0.6) & (mask < 0.8))),
+            sps.csr_matrix(full * (mask >= 0.8)))
+
+
+def test_search_space_matches_reference_definitions():
+    dims = {d.name: d for d in tune.search_space("GANMF", 6040, 3706)}
+    assert list(dims) == ["epochs", "num_factors", "batch_size", "m", "d_lr", "g_lr", "d_reg", "recon_coefficient", "emb_dim"]
+    assert dims["epochs"].choices == [300] and dims["batch_size"].choices == [64, 128, 256, 512, 1024]
+    assert (dims["num_factors"].low, dims["num_factors"].high) == (1, 250)
+    assert (dims["m"].low, dims["m"].high) == (1, 10)
+    assert (dims["d_lr"].low, dims["d_lr"].high, dims["d_lr"].prior) == (1e-4, 1e-2, "log-uniform")
+    assert (dims["d_reg"].low, dims["d_reg"].high) == (1e-6, 1e-4)
+    assert (dims["recon_coefficient"].low, dims["recon_coefficient"].high, dims["recon_coefficient"].prior) == (1e-2, 0.5, "uniform")
+    assert (dims["emb_dim"].low, dims["emb_dim"].high) == (4, 1024)          # I > 1024 (RecSysExp.py:341)
+    small = {d.name: d for d in tune.search_space("GANMF", 100, 80)}
+    assert small["emb_dim"].high == 60 and small["num_factors"].high == 80   # int(0.75 I); clamp to min(U, I)
+    dis = {d.name: d for d in tune.search_space("DisGANMF", 6040, 3706)}
+    assert list(dis) == ["epochs", "d_hidden_act", "d_layers", "num_factors", "batch_size", "d_lr", "g_lr", "d_reg",
+                         "recon_coefficient", "d_nodes"]
+    assert dis["d_hidden_act"].choices == ["linear", "tanh", "relu", "sigmoid"] and (dis["d_layers"].low, dis["d_layers"].high) == (1, 5)
+    rng = np.random.RandomState(0)
+    for d in dims.values():
+        for _ in range(50):
+            v = d.sample(rng)
+            assert 0.0 <= d.to_unit(v) <= 1.0
+    with pytest.raises(ValueError):
+        tune.search_space("CFGAN", 10, 10)
+
+
+@pytest.mark.parametrize("method", ["random", "bayesian"])
+def test_trial_parallel_search_and_resume(tmp_path, monkeypatch, method):
+    monkeypatch.setenv("PYTHONPATH", HERE + os.pathsep + os.path.dirname(HERE) + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    sys.path.insert(0, HERE)
+    from helpers_tune import StubGAN
+    from ganmf_amd.evaluation import EvaluatorHoldoutFast
+    train, early, val = _data()
+    logs = str(tmp_path / "exp")
+    t = tune.TrialParallelTuner(StubGAN, train, early, val, logs, seed=5, method=method, n_workers=2, devices=[0],
+                                evaluator_class=EvaluatorHoldoutFast)
+    best, params = t.tune(evals=14, verbose=False)
+    assert len(t.func_vals) == 14 and best == min(t.func_vals) and best < 0
+    assert set(params) == {d.name for d in t.dims}
+    # epochs correction of RecSysExp.py:272-276: early-stopped trials report last_epoch - allow_worse*freq
+    assert params["epochs"] == 300 or params["epochs"] == 40 + (params["num_factors"] % 7) * 5 - 25
+    assert pickle.load(open(os.path.join(logs, "best_params.pkl"), "rb")) == params
+    assert json.load(open(os.path.join(logs, "best_params.txt"))) == params
+    text = open(os.path.join(logs, "results.txt")).read()
+    assert text.count("CUTOFF: 5") + text.count("out of memory") == 14 and "Best MAP score" in text   # the stand-in OOMs at num_factors 13
+    # resume: a second tuner on the same logsdir only runs the missing trials
+    t2 = tune.TrialParallelTuner(StubGAN, train, early, val, logs, seed=5, method=method, n_workers=2, devices=[0],
+                                 evaluator_class=EvaluatorHoldoutFast)
+    best2, _ = t2.tune(evals=16, verbose=False)
+    assert len(t2.func_vals) == 16 and best2 <= best
+    assert t2.x_iters[:14] == t.x_iters
+
+
+def test_failed_and_oom_trials_score_zero(tmp_path, monkeypatch):
+    monkeypatch.setenv("PYTHONPATH", HERE + os.pathsep + os.path.dirname(HERE) + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    sys.path.insert(0, HERE)
+    from helpers_tune import StubGAN
+    train, early, val = _data(1)
+    spec_tuner = tune.TrialParallelTuner(StubGAN, train, early, val, str(tmp_path / "e"), n_workers=1, devices=[0])
+    params = {d.name: d.sample(np.random.RandomState(0)) for d in spec_tuner.dims}
+    params["num_factors"] = 13                         # the stand-in raises MemoryError here
+    with pytest.raises(MemoryError):
+        tune.run_trial(spec_tuner.spec, params, 0)
+    params["num_factors"] = 12
+    out = tune.run_trial(spec_tuner.spec, params, 0)
+    assert out["fitness"] <= 0 and out["fit_params"]["epochs"] == 40 + (12 % 7) * 5 - 25
