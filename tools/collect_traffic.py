@@ -34,23 +34,28 @@ plan_log, fdir, wdir = sys.argv[1:4]
 fetch, write = counters(fdir, "FETCH_SIZE"), counters(wdir, "WRITE_SIZE")
 out = {}
 for line in open(plan_log):
-    m = re.search(r"\[ganmf plan\] (\S+)\s+M=(\d+) N=(\d+) K=(\d+) batch=(\d+) -> tile (\d+) ring (\d+) nsplit (\d+) \(kps \d+\) wgs (\d+)", line)
+    m = re.search(r"\[ganmf plan\] (\S+)\s+M=(\d+) N=(\d+) K=(\d+) batch=(\d+) -> tile (\d+) ring (\d+) nsplit (\d+) \(kps \d+\) mfma (\S+) wgs (\d+)", line)
     if not m:
         continue
-    tag, M, N, K, nb, tile, ring, ns, wgs = m.group(1), *map(int, m.groups()[1:])
+    g = m.groups()
+    tag, mode = g[0], g[8]
+    M, N, K, nb, tile, ring, ns, wgs = map(int, g[1:8] + (g[9],))
     base = tag.split("[")[0]
     if base not in LAYOUT:
         continue
     a, b = LAYOUT[base]
     bk = 32 if tile == 128 else 64
-    pat = "gemm_f32_mfma<%d, %d, %d, %d, %s, %s>" % (tile, tile, bk, ring, a, b)
+    if mode == "f32":
+        pat = "gemm_f32_mfma<%d, %d, %d, %d, %s, %s>" % (tile, tile, bk, ring, a, b)
+    else:   # bf16 matrix-core kernels (gemm_bf16s.hpp): <BM, BN, BK, AKM, BKM, NPIECE>
+        pat = "gemm_bf16s_mfma<%d, %d, %d, %s, %s, %d>" % (tile, tile, bk, a, b, 3 if mode == "bf16x3" else 1)
     key = [k for k in fetch if pat in k[0] and int(k[1]) == wgs * 256]
     if not key:
         continue
     k0 = key[0]
     f_kib = sum(fetch[k0]) / len(fetch[k0])
     w_kib = sum(write[k0]) / len(write[k0]) if k0 in write else 0.0
-    name = "%s M=%d N=%d K=%d batch=%d" % (tag, M, N, K, nb)
+    name = "%s M=%d N=%d K=%d batch=%d" % (tag, M, N, K, nb) + ("" if mode == "f32" else " mfma=" + mode)
     out[name] = {"kernel": pat, "grid_threads": wgs * 256, "launches_sampled": len(fetch[k0]),
                  "FETCH_SIZE_KiB_raw": round(f_kib, 1), "WRITE_SIZE_KiB_raw": round(w_kib, 1),
                  "hbm_bytes_per_launch": int((2 * f_kib + w_kib) * 1024),
