@@ -170,6 +170,8 @@ struct ganmf_handle {
   float* topk_vals = nullptr;
   size_t topk_cap = 0;
   // scoring scratch
+  int* sc_ids = nullptr;
+  size_t sc_ids_cap = 0;
   float *sc_rows = nullptr, *sc_out = nullptr;
   size_t sc_rows_cap = 0, sc_out_cap = 0;
   // RCCL
@@ -578,7 +580,7 @@ int gen_update(ganmf_handle* h, int nb, int start, int* regn_v, float* reg_u, fl
 int g_step(ganmf_handle* h, const int* rows_dev, int nb, int start, int b_global, float* parts, float* arena) {
   // this step's arena slot: seg0 = sum Delta_f^2, seg1 = sum (Ef-Er)^2, seg2 = sum U^2, seg3 = sum V^2 partials
   const size_t cap = h->reg_cap;
-  const int N = h->N, e = h->e, k = h->k;
+  const int N = h->N, e = h->e;
   const float alpha = h->cfg.recon_coefficient;
   const float inv_bn = 1.0f / ((float)b_global * (float)N);
   int sqn = 0, fmn = 0;
@@ -732,7 +734,7 @@ int dis_d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float
 }
 
 int dis_g_step(ganmf_handle* h, const int* rows_dev, int nb, int start, int b_global, float* parts) {
-  const int N = h->N, e = h->e, k = h->k;
+  const int N = h->N, e = h->e;
   const float alpha = h->cfg.recon_coefficient;
   const float inv_b = 1.0f / (float)b_global;
   int fmn = 0;
@@ -1028,7 +1030,7 @@ int ganmf_destroy(ganmf_handle* h) {
   hipFree(h->gD); hipFree(h->indptr); hipFree(h->indices); hipFree(h->data); hipFree(h->perm); hipFree(h->pos);
   hipFree(h->XF); hipFree(h->Ub); hipFree(h->E); hipFree(h->Dl); hipFree(h->dE); hipFree(h->dF); hipFree(h->gUb);
   hipFree(h->slab); hipFree(h->rs); hipFree(h->scal); hipFree(h->sqp); hipFree(h->fmp);
-  hipFree(h->seen_indptr); hipFree(h->seen_indices); hipFree(h->topk_items); hipFree(h->topk_vals);
+  hipFree(h->seen_indptr); hipFree(h->seen_indices); hipFree(h->topk_items); hipFree(h->topk_vals); hipFree(h->sc_ids);
   hipFree(h->regp); hipFree(h->d_parts); hipFree(h->g_parts); hipFree(h->d_arena); hipFree(h->g_arena); hipFree(h->sc_rows); hipFree(h->sc_out);
   for (auto& r : h->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
   hipStreamSynchronize(h->st2);
@@ -1253,6 +1255,21 @@ static int scores_device(ganmf_handle* h, const int* ids_dev, int64_t n, int tra
   return 0;
 }
 
+// device copy of an id list in the handle's reusable buffer (scores / recommend are called once per 1000-user
+// block by the evaluators: no allocation per call)
+static int upload_ids(ganmf_handle* h, const int32_t* ids, int64_t n, int** out) {
+  if ((size_t)n > h->sc_ids_cap) {
+    HIP_TRY(hipStreamSynchronize(h->st));
+    if (h->sc_ids) hipFree(h->sc_ids);
+    h->sc_ids = nullptr; h->sc_ids_cap = 0;
+    HIP_TRY(hipMalloc((void**)&h->sc_ids, (size_t)n * sizeof(int)));
+    h->sc_ids_cap = (size_t)n;
+  }
+  HIP_TRY(hipMemcpyAsync(h->sc_ids, ids, n * sizeof(int), hipMemcpyHostToDevice, h->st));
+  *out = h->sc_ids;
+  return 0;
+}
+
 int ganmf_scores(ganmf_handle* h, const int32_t* ids, int64_t n, int transposed, float* out) {
   if (!h || !ids || !out) return fail(-1, "ganmf_scores: null argument");
   if (n < 1 || n > (1 << 30)) return fail(-1, "ganmf_scores: n out of range");
@@ -1261,8 +1278,7 @@ int ganmf_scores(ganmf_handle* h, const int32_t* ids, int64_t n, int transposed,
     if (ids[i] < 0 || ids[i] >= limit) return fail(-1, "ganmf_scores: id %d out of range [0,%d)", ids[i], limit);
   HIP_TRY(hipSetDevice(h->dev));
   int* ids_dev = nullptr;
-  HIP_TRY(hipMalloc((void**)&ids_dev, n * sizeof(int)));
-  HIP_TRY(hipMemcpyAsync(ids_dev, ids, n * sizeof(int), hipMemcpyHostToDevice, h->st));
+  TRY(upload_ids(h, ids, n, &ids_dev));
   float* od = nullptr; int W = 0, ldw = 0;
   int rc = scores_device(h, ids_dev, n, transposed, &od, &W, &ldw);
   if (rc == 0) {
@@ -1271,7 +1287,6 @@ int ganmf_scores(ganmf_handle* h, const int32_t* ids, int64_t n, int transposed,
     if (e != hipSuccess) rc = fail(-2, "ganmf_scores: copy back failed: %s", hipGetErrorString(e));
   }
   hipStreamSynchronize(h->st);
-  hipFree(ids_dev);
   return rc;
 }
 
@@ -1306,8 +1321,7 @@ int ganmf_recommend(ganmf_handle* h, const int32_t* ids, int64_t n, int transpos
     return fail(-1, "ganmf_recommend: remove_seen needs ganmf_set_seen_csr with a %d x %d matrix", limit, W);
   HIP_TRY(hipSetDevice(h->dev));
   int* ids_dev = nullptr;
-  HIP_TRY(hipMalloc((void**)&ids_dev, n * sizeof(int)));
-  HIP_TRY(hipMemcpyAsync(ids_dev, ids, n * sizeof(int), hipMemcpyHostToDevice, h->st));
+  TRY(upload_ids(h, ids, n, &ids_dev));
   const size_t need = (size_t)n * cutoff;
   if (need > h->topk_cap) {
     HIP_TRY(hipStreamSynchronize(h->st));
@@ -1333,7 +1347,6 @@ int ganmf_recommend(ganmf_handle* h, const int32_t* ids, int64_t n, int transpos
     if (e != hipSuccess) rc = fail(-2, "ganmf_recommend: %s", hipGetErrorString(e));
   }
   hipStreamSynchronize(h->st);
-  hipFree(ids_dev);
   return rc;
 }
 
@@ -1345,11 +1358,11 @@ int ganmf_bench_scores(ganmf_handle* h, int64_t n, int transposed, int32_t iters
   std::vector<int> ids(n);
   for (int64_t i = 0; i < n; ++i) ids[i] = (int)i;
   int* ids_dev = nullptr;
-  HIP_TRY(hipMalloc((void**)&ids_dev, n * sizeof(int)));
-  HIP_TRY(hipMemcpy(ids_dev, ids.data(), n * sizeof(int), hipMemcpyHostToDevice));
+  TRY(upload_ids(h, ids.data(), n, &ids_dev));
+  HIP_TRY(hipStreamSynchronize(h->st));      // `ids` is a local: the copy must be done before it goes away
   float* od; int W, ldw;
   int rc = scores_device(h, ids_dev, n, transposed, &od, &W, &ldw);  // warm-up + allocation
-  if (rc) { hipFree(ids_dev); return rc; }
+  if (rc) return rc;
   Tensor& colsT = transposed ? h->Ue : h->V;
   GemmP g{};
   g.A = h->sc_rows; g.lda = h->ldk; g.B = colsT.p; g.ldb = h->ldk;
@@ -1367,7 +1380,6 @@ int ganmf_bench_scores(ganmf_handle* h, int64_t n, int transposed, int32_t iters
   float ms = 0.f;
   hipEventElapsedTime(&ms, a, b);
   hipEventDestroy(a); hipEventDestroy(b);
-  hipFree(ids_dev);
   if (e != hipSuccess) return fail(-2, "ganmf_bench_scores: %s", hipGetErrorString(e));
   if (ms_per_launch) *ms_per_launch = ms / iters;
   return 0;
