@@ -188,6 +188,22 @@ def statistical_fixture():
     json.dump({"best_params": hp, "published": _clean(pub)},
               open(os.path.join(OUT, "statistical_kat_ml1m_user.json"), "w"), indent=1)
     print("statistical fixture: published MAP@5 =", pub[5]["MAP"])
+    # LastFM (BASELINE configs[0]) in both modes: the train/test splits are already fixtures (KAT-1)
+    for mode in ("user", "item"):
+        hp = json.load(open(os.path.join(REF, "experiments/GANMF_%s_LastFM/best_params.txt" % mode)))
+        pub = pickle.load(open(os.path.join(REF, "test_results/GANMF_%s_LastFM/test_results.pkl" % mode), "rb"))
+        json.dump({"best_params": hp, "published": _clean(pub)},
+                  open(os.path.join(OUT, "statistical_kat_lastfm_%s.json" % mode), "w"), indent=1)
+        print("statistical fixture LastFM %s: published MAP@5 =" % mode, pub[5]["MAP"])
+    # hetrec2011 item mode (BASELINE configs[2])
+    for split in ("train", "test"):
+        shutil.copyfile(os.path.join(REF, "experiments/datasets/Movielenshetrec2011_URM_%s.npz" % split),
+                        os.path.join(OUT, "hetrec2011_URM_%s.npz" % split))
+    hp = json.load(open(os.path.join(REF, "experiments/GANMF_item_hetrec2011/best_params.txt")))
+    pub = pickle.load(open(os.path.join(REF, "test_results/GANMF_item_hetrec2011/test_results.pkl"), "rb"))
+    json.dump({"best_params": hp, "published": _clean(pub)},
+              open(os.path.join(OUT, "statistical_kat_hetrec_item.json"), "w"), indent=1)
+    print("statistical fixture hetrec item: published MAP@5 =", pub[5]["MAP"])
 
 
 if __name__ == "__main__":

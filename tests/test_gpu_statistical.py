@@ -34,3 +34,35 @@ def test_ml1m_user_full_training_reaches_published_map(golden_dir):
         assert abs(res[5][metric] - pub["5"][metric]) <= 0.005, (metric, res[5][metric], pub["5"][metric])
     for c in ("10", "20", "50"):
         assert abs(res[int(c)]["MAP"] - pub[c]["MAP"]) <= 0.005, (c, res[int(c)]["MAP"], pub[c]["MAP"])
+
+
+DATASETS = {"lastfm_user": ("LastFM", "user"), "lastfm_item": ("LastFM", "item"), "hetrec_item": ("hetrec2011", "item")}
+
+
+@pytest.mark.parametrize("case", list(DATASETS))
+def test_lastfm_hetrec_full_training_reaches_published_map(golden_dir, case):
+    """BASELINE configs[0] (LastFM 1892 x 17632, user and item mode) and configs[2] (hetrec2011 item mode,
+    2113 x 10109) with the reference's tuned hyper-parameters (experiments/GANMF_*/best_params.txt) against
+    test_results/GANMF_*/test_results.txt:1.  Same +-0.005 band; the device-side recommend path and the block
+    evaluator produce the metrics."""
+    from ganmf_amd.GANMF import GANMF
+    from ganmf_amd.evaluation import EvaluatorHoldoutFast
+    data, mode = DATASETS[case]
+    kat = json.load(open(os.path.join(golden_dir, "statistical_kat_%s.json" % case)))
+    train = sps.load_npz(os.path.join(golden_dir, "%s_URM_train.npz" % data)).tocsr()
+    test = sps.load_npz(os.path.join(golden_dir, "%s_URM_test.npz" % data)).tocsr()
+    np.random.seed(1337)
+    model = GANMF(train, mode=mode, seed=1337, is_experiment=True)
+    t0 = time.time()
+    ret = model.fit(validation_set=None, sample_every=None, validation_evaluator=None, **kat["best_params"])
+    train_s = time.time() - t0
+    assert ret == kat["best_params"]["epochs"] + 1
+    res, _ = EvaluatorHoldoutFast(test, [5, 10]).evaluateRecommender(model)
+    pub = kat["published"]
+    rows = model.num_users
+    steps = kat["best_params"]["epochs"] * 2 * -(-rows // kat["best_params"]["batch_size"])
+    print("%s GANMF-%s: %d updates in %.2f s (%.0f steps/s); MAP@5 %.4f (published %.4f) NDCG@5 %.4f (%.4f)"
+          % (data, mode, steps, train_s, steps / train_s, res[5]["MAP"], pub["5"]["MAP"], res[5]["NDCG"], pub["5"]["NDCG"]))
+    for metric in ("MAP", "NDCG", "PRECISION", "RECALL"):
+        assert abs(res[5][metric] - pub["5"][metric]) <= 0.005, (case, metric, res[5][metric], pub["5"][metric])
+    assert abs(res[10]["MAP"] - pub["10"]["MAP"]) <= 0.005
