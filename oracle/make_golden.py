@@ -204,6 +204,13 @@ def statistical_fixture():
     json.dump({"best_params": hp, "published": _clean(pub)},
               open(os.path.join(OUT, "statistical_kat_hetrec_item.json"), "w"), indent=1)
     print("statistical fixture hetrec item: published MAP@5 =", pub[5]["MAP"])
+    # DisGANMF on ML-1M (BASELINE configs[4]), both modes
+    for mode in ("user", "item"):
+        hp = json.load(open(os.path.join(REF, "experiments/DisGANMF_%s_1M/best_params.txt" % mode)))
+        pub = pickle.load(open(os.path.join(REF, "test_results/DisGANMF_%s_1M/test_results.pkl" % mode), "rb"))
+        json.dump({"best_params": hp, "published": _clean(pub)},
+                  open(os.path.join(OUT, "statistical_kat_disganmf_ml1m_%s.json" % mode), "w"), indent=1)
+        print("statistical fixture DisGANMF ML-1M %s: published MAP@5 =" % mode, pub[5]["MAP"])
 
 
 if __name__ == "__main__":
