@@ -3,8 +3,9 @@
 // Same contract as gemm_f32_mfma (GemmP, operand layouts NT / NN / TN, zero-page convention, split-K slabs,
 // shared epilogue) with a different K loop:
 //   * every fp32 operand element is split exactly into three bf16 pieces x = hi + mid + lo (gemm_f32.hpp,
-//     split_bf16x3) by the thread that LOADS it, and the pieces are written to three LDS planes per operand;
-//     a.b is accumulated in fp32 from the six piece products of weight >= 2^-16 on v_mfma_f32_32x32x16_bf16.
+//     split_bf16x3: round-to-nearest at each level) by the thread that LOADS it, and the pieces are written to
+//     three LDS planes per operand; a.b is accumulated in fp32 from the six piece products of weight >= 2^-18
+//     on v_mfma_f32_32x32x16_bf16.
 //     (Splitting at fragment-read time instead — fp32 tiles in LDS, each wave splitting what it reads — repeats the
 //     VALU work in both waves that share a fragment; measured on MI355X, VALU and MFMA issue time ADD on a SIMD
 //     (tools/ubench/mfma_valu.hip), and that variant was 3 % slower at 4096^3 and 30 % slower in bf16 mode.)
@@ -85,17 +86,27 @@ struct SplitStage {
   __device__ inline void store(unsigned* __restrict__ planes, const float4 (&v)[NI][2]) const {
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
-      float x[8];
-      if constexpr (!KM) {   // 8 consecutive k of one row
-        x[0] = v[j][0].x; x[1] = v[j][0].y; x[2] = v[j][0].z; x[3] = v[j][0].w;
-        x[4] = v[j][1].x; x[5] = v[j][1].y; x[6] = v[j][1].z; x[7] = v[j][1].w;
-      } else {               // (k, k+1) pairs of four consecutive rows
-        x[0] = v[j][0].x; x[1] = v[j][1].x; x[2] = v[j][0].y; x[3] = v[j][1].y;
-        x[4] = v[j][0].z; x[5] = v[j][1].z; x[6] = v[j][0].w; x[7] = v[j][1].w;
-      }
+      // the four (k, k+1) pairs of this item: 8 consecutive k of one row, or two k-rows of four consecutive rows
+      // (no private arrays here: hipcc parks them in scratch / LDS)
+      const float4 a = v[j][0], b = v[j][1];
       u32x4 pc[3];
-      if constexpr (NPIECE == 3) split_bf16x3(x, pc[0], pc[1], pc[2]);
-      else pc[0] = round_bf16(x);
+      auto one = [&](float x0, float x1, auto qq) {
+        constexpr int q = decltype(qq)::value;
+        if constexpr (NPIECE == 3) {
+          unsigned h, m, l;
+          split_bf16x3(x0, x1, h, m, l);
+          pc[0][q] = h; pc[1][q] = m; pc[2][q] = l;
+        } else {
+          pc[0][q] = cvt_pk_bf16(x0, x1);
+        }
+      };
+      if constexpr (KM) {
+        one(a.x, b.x, std::integral_constant<int, 0>{}); one(a.y, b.y, std::integral_constant<int, 1>{});
+        one(a.z, b.z, std::integral_constant<int, 2>{}); one(a.w, b.w, std::integral_constant<int, 3>{});
+      } else {
+        one(a.x, a.y, std::integral_constant<int, 0>{}); one(a.z, a.w, std::integral_constant<int, 1>{});
+        one(b.x, b.y, std::integral_constant<int, 2>{}); one(b.z, b.w, std::integral_constant<int, 3>{});
+      }
 #pragma unroll
       for (int q = 0; q < NPIECE; ++q) *reinterpret_cast<u32x4*>(planes + q * PLANE + dst[j]) = pc[q];
     }
@@ -179,7 +190,8 @@ __global__ __launch_bounds__(256) void gemm_bf16s_mfma(const GemmP p) {
       for (int q = 0; q < NPIECE; ++q) pb[set][b][q] = SB::frag(planes_b + q * SB::PLANE, wc * WN + b * 32, c, li, lh);
   };
   auto mfmas = [&](int set) {
-    // piece products in increasing weight, blocks innermost (dependent MFMAs are TM*TN issues apart)
+    // piece products in increasing weight, blocks innermost (dependent MFMAs are TM*TN issues apart).  (A second
+    // accumulator for the five correction products was tried: no change in accuracy, 128 more registers.)
     constexpr int NT = NPIECE == 3 ? 6 : 1;
     constexpr int ta[6] = {1, 0, 2, 1, 0, 0}, tb[6] = {1, 2, 0, 0, 1, 0};   // (mid,mid) (hi,lo) (lo,hi) (mid,hi) (hi,mid) (hi,hi)
 #pragma unroll

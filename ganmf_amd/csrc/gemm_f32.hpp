@@ -43,43 +43,39 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // MFMA arithmetic of the K loop (GemmPlan::mode):
 //   MFMA_F32    gemm_f32_mfma below: v_mfma_f32_32x32x2_f32 on the fp32 operands (256 FLOP/clk/CU)
 //   MFMA_BF16X3 gemm_bf16s.hpp: every fp32 operand is split EXACTLY into three bf16 pieces x = hi + mid + lo
-//               (8 + 8 + 8 mantissa bits, truncation, so the sum is bit-exact) and a.b is accumulated in fp32 from
-//               the six piece products of weight >= 2^-16 (hi.hi, hi.mid, mid.hi, hi.lo, lo.hi, mid.mid) on
+//               (round-to-nearest at each level, see split_bf16x3) and a.b is accumulated in fp32 from the six
+//               piece products of weight >= 2^-18 (hi.hi, hi.mid, mid.hi, hi.lo, lo.hi, mid.mid) on
 //               v_mfma_f32_32x32x16_bf16 (4096 FLOP/clk/CU): 6/16 of the fp32 MFMA time; the three dropped
-//               products are <= 2^-24 |a||b| each, the size of one fp32 rounding of the product.
+//               products sum to <= 2^-26 |a||b|, below one fp32 rounding of the product, and are unbiased.
 //   MFMA_BF16   gemm_bf16s.hpp: operands rounded to one bf16 (round to nearest even), fp32 accumulate: the
 //               mixed-precision variant BASELINE configs[4] asks for (master weights and Adam stay fp32).
 enum MfmaMode : int { MFMA_AUTO = -1, MFMA_F32 = 0, MFMA_BF16 = 1, MFMA_BF16X3 = 3 };
 
-constexpr unsigned PERM_HI16 = 0x07060302u;   // v_perm_b32(S0, S1): {S0[31:16], S1[31:16]}
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
-__device__ inline unsigned hi16_bits(float x) { return __float_as_uint(x) & 0xffff0000u; }
-
-// 8 fp32 -> three vectors of 8 bf16 (element 2q in the low half of dword q)
-__device__ inline void split_bf16x3(const float (&x)[8], u32x4& hi, u32x4& mid, u32x4& lo) {
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const f32x2 v = {x[2 * q], x[2 * q + 1]};
-    const f32x2 h = {__uint_as_float(hi16_bits(v.x)), __uint_as_float(hi16_bits(v.y))};
-    const f32x2 r1 = v - h;                                   // exact
-    const f32x2 m = {__uint_as_float(hi16_bits(r1.x)), __uint_as_float(hi16_bits(r1.y))};
-    const f32x2 r2 = r1 - m;                                  // exact, <= 8 significant bits
-    hi[q] = __builtin_amdgcn_perm(__float_as_uint(h.y), __float_as_uint(h.x), PERM_HI16);
-    mid[q] = __builtin_amdgcn_perm(__float_as_uint(m.y), __float_as_uint(m.x), PERM_HI16);
-    lo[q] = __builtin_amdgcn_perm(__float_as_uint(r2.y), __float_as_uint(r2.x), PERM_HI16);
-  }
+// two fp32 -> two bf16 in one dword (x0 in the low half), round to nearest even: v_cvt_pk_bf16_f32
+// (inline asm: through __builtin_convertvector hipcc first builds a float2, and builds it through scratch / LDS
+// when x0 and x1 live in registers that are not adjacent)
+__device__ inline unsigned cvt_pk_bf16(float x0, float x1) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(x0), "v"(x1));
+  return r;
 }
 
-// 8 fp32 -> 8 bf16, round to nearest even (inputs are finite)
-__device__ inline u32x4 round_bf16(const float (&x)[8]) {
-  u32x4 out;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const unsigned a = __float_as_uint(x[2 * q]), b = __float_as_uint(x[2 * q + 1]);
-    const unsigned ra = a + 0x7fffu + ((a >> 16) & 1u), rb = b + 0x7fffu + ((b >> 16) & 1u);
-    out[q] = __builtin_amdgcn_perm(rb, ra, PERM_HI16);
-  }
-  return out;
+// two fp32 -> three dwords of two bf16 each with x = hi + mid + lo EXACTLY:
+// hi = rne(x) keeps 8 bits, r1 = x - hi is exact (<= 16 bits), mid = rne(r1), r2 = r1 - mid is exact and has <= 8
+// significant bits, so lo = r2.  Round-to-nearest keeps |mid| <= 2^-9 |x|, |lo| <= 2^-18 |x| with signs that are
+// not tied to the sign of x: the three dropped piece products are <= 2^-26 |a||b| together and unbiased
+// (truncation would leave residues of the sign of x and a systematic 2^-23 |a||b| under-estimate that long
+// sums with cancellation amplify).  Scalar operands on purpose: the two elements of a pair come from different
+// registers for K-major operands, and hipcc builds a cross-register float2 through scratch / LDS.
+__device__ inline void split_bf16x3(float x0, float x1, unsigned& hi, unsigned& mid, unsigned& lo) {
+  hi = cvt_pk_bf16(x0, x1);
+  float r0 = x0 - __uint_as_float(hi << 16), r1 = x1 - __uint_as_float(hi & 0xffff0000u);
+  mid = cvt_pk_bf16(r0, r1);
+  r0 -= __uint_as_float(mid << 16);
+  r1 -= __uint_as_float(mid & 0xffff0000u);
+  lo = cvt_pk_bf16(r0, r1);
 }
 
 template <int I, int N, class F>
