@@ -1314,7 +1314,8 @@ int ganmf_recommend(ganmf_handle* h, const int32_t* ids, int64_t n, int transpos
   if (!h || !ids || !out_items) return fail(-1, "ganmf_recommend: null argument");
   if (n < 1 || n > (1 << 30)) return fail(-1, "ganmf_recommend: n out of range");
   const int limit = transposed ? h->N : h->U, W = transposed ? h->U : h->N;
-  if (cutoff < 1 || cutoff > W) return fail(-1, "ganmf_recommend: cutoff %d out of range [1,%d]", cutoff, W);
+  if (cutoff < 1 || cutoff > W || cutoff > GANMF_RECOMMEND_MAX_CUTOFF)
+    return fail(-1, "ganmf_recommend: cutoff %d out of range [1,%d]", cutoff, std::min(W, GANMF_RECOMMEND_MAX_CUTOFF));
   for (int64_t i = 0; i < n; ++i)
     if (ids[i] < 0 || ids[i] >= limit) return fail(-1, "ganmf_recommend: id %d out of range [0,%d)", ids[i], limit);
   if (remove_seen && (!h->seen_indptr || h->seen_rows != limit || h->seen_cols != W))

@@ -134,7 +134,10 @@ int ganmf_scores(ganmf_handle* h, const int32_t* ids, int64_t n, int transposed,
  * row are selected there; only n*cutoff ids (and their scores) cross PCIe.  SURVEY §8(f) row 1.
  * ganmf_set_seen_csr uploads URM_train in EVALUATION orientation (rows = users as evaluators see them,
  * columns = items; n_rows/n_cols must match the id domain / score width of the chosen `transposed`).
- * Ties go to the smaller item id; rows with fewer than `cutoff` finite scores are padded with -1. */
+ * Ties go to the smaller item id; rows with fewer than `cutoff` finite scores are padded with -1.
+ * cutoff <= GANMF_RECOMMEND_MAX_CUTOFF (the selection runs `cutoff` arg-max rounds per row; full rankings are
+ * the job of ganmf_scores + a host sort). */
+#define GANMF_RECOMMEND_MAX_CUTOFF 1024
 int ganmf_set_seen_csr(ganmf_handle* h, const int64_t* indptr, const int32_t* indices, int64_t n_rows, int64_t n_cols);
 int ganmf_recommend(ganmf_handle* h, const int32_t* ids, int64_t n, int transposed, int32_t cutoff, int remove_seen,
                     int32_t* out_items, float* out_scores);

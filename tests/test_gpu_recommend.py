@@ -93,6 +93,11 @@ def test_recommend_errors():
     assert items.shape == (3, 5)
     with pytest.raises(L.GanmfError, match="cutoff"):
         eng.recommend(np.arange(3), 21, remove_seen=False)
+    wide = Engine(4, 3000, 2, 4, 4)
+    with pytest.raises(L.GanmfError, match="cutoff"):     # GANMF_RECOMMEND_MAX_CUTOFF
+        wide.recommend(np.arange(2), 1025, remove_seen=False)
+    assert wide.recommend(np.arange(2), 1024, remove_seen=False)[0].shape == (2, 1024)
+    wide.close()
     with pytest.raises(L.GanmfError, match="out of range"):
         eng.recommend(np.array([10]), 5, remove_seen=False)
     bad = sps.csr_matrix(np.ones((10, 21), np.float32))
