@@ -1,0 +1,83 @@
+"""Randomised engine configurations (shapes, batch sizes larger / smaller than the matrix, hyper-parameters with the
+hinge on either side, d_steps / g_steps, activations and depths for DisGANMF) — two epochs through the C ABI against
+the fp64 oracle.  Complements the fixed cases of test_gpu_parity.py / test_gpu_configs.py."""
+import numpy as np
+import pytest
+import scipy.sparse as sps
+
+from oracle.ganmf_oracle import DisGANMFOracle, GANMFOracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _err(got, ref):
+    return np.max(np.abs(np.asarray(got, np.float64).reshape(np.shape(ref)) - ref)) / (np.max(np.abs(ref)) + 1e-30)
+
+
+def _urm(rng, U, N):
+    dens = rng.choice([0.02, 0.1, 0.4])
+    m = (rng.rand(U, N) < dens).astype(np.float32)
+    m[rng.rand(U) < 0.15] = 0.0                       # cold rows
+    return sps.csr_matrix(m)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_ganmf_random_config(seed):
+    from ganmf_amd.engine import Engine
+    rng = np.random.RandomState(1000 + seed)
+    U, N = int(rng.randint(3, 400)), int(rng.randint(2, 700))
+    k, e, B = int(rng.randint(1, 70)), int(rng.randint(1, 140)), int(rng.choice([1, 2, 7, 32, 64, 129, 500]))
+    hp = dict(d_lr=float(10 ** rng.uniform(-4, -2.5)), g_lr=float(10 ** rng.uniform(-4, -2.5)),
+              d_reg=float(rng.choice([0.0, 1e-4, 1e-2])), g_reg=float(rng.choice([0.0, 1e-3])),
+              m=float(rng.choice([0.001, 1.0, 10.0])), recon_coefficient=float(rng.uniform(0, 1)))
+    d_steps, g_steps = int(rng.randint(1, 3)), int(rng.randint(1, 3))
+    urm = _urm(rng, U, N)
+    o = GANMFOracle(U, N, k, e, dtype=np.float64, seed=seed, **hp)
+    o.set_params(be=rng.randn(e) * 0.01, bd=rng.randn(N) * 0.01)
+    eng = Engine(U, N, k, e, B, **hp)
+    eng.set_urm(urm)
+    ids = {"We": 0, "be": 1, "Wd": 2, "bd": 3, "U": 100, "V": 101}
+    for n, tid in ids.items():
+        eng.set_tensor(tid, o.p[n])
+    for _ in range(2):
+        perm = rng.permutation(U)
+        dl_ref, gl_ref = o.train_epoch(urm, perm, min(B, U), d_steps, g_steps)
+        dl, gl = eng.train_epoch(perm, d_steps, g_steps)
+        np.testing.assert_allclose(dl, dl_ref, rtol=2e-4, atol=1e-7, err_msg=str((U, N, k, e, B, hp)))
+        np.testing.assert_allclose(gl, gl_ref, rtol=2e-4, atol=1e-7, err_msg=str((U, N, k, e, B, hp)))
+    for n, tid in ids.items():
+        assert _err(eng.get_tensor(tid), o.p[n]) <= 2e-4, (n, U, N, k, e, B, hp)
+    users = rng.permutation(U)[:min(U, 50)]
+    assert _err(eng.scores(users), o.scores(users)) <= 2e-4
+    assert _err(eng.scores(np.arange(min(N, 40)), transposed=True), o.scores(np.arange(U))[:, :min(N, 40)].T) <= 2e-4
+    eng.close()
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_disganmf_random_config(seed):
+    from ganmf_amd import _lib as L
+    from ganmf_amd.engine import Engine
+    rng = np.random.RandomState(2000 + seed)
+    U, N = int(rng.randint(3, 90)), int(rng.randint(2, 300))      # float(uid) feeds the net: keep logits moderate
+    k, e, B = int(rng.randint(1, 40)), int(rng.randint(1, 70)), int(rng.choice([1, 5, 32, 64, 200]))
+    layers, act = int(rng.randint(1, 4)), str(rng.choice(["linear", "tanh", "relu", "sigmoid"]))
+    hp = dict(d_lr=float(10 ** rng.uniform(-4, -3)), g_lr=float(10 ** rng.uniform(-4, -3)),
+              d_reg=float(rng.choice([0.0, 1e-4])), g_reg=0.0, recon_coefficient=float(rng.uniform(0, 1)))
+    urm = _urm(rng, U, N)
+    o = DisGANMFOracle(U, N, k, d_layers=layers, d_nodes=e, d_hidden_act=act, dtype=np.float64, seed=seed, **hp)
+    eng = Engine(U, N, k, e, B, model=L.MODEL_DISGANMF, d_layers=layers, d_act=act, m=0.0, **hp)
+    eng.set_urm(urm)
+    ids = {}
+    for l in range(layers):
+        ids["W%d" % l], ids["b%d" % l] = 2 * l, 2 * l + 1
+    ids.update({"Wo": 2 * layers, "bo": 2 * layers + 1, "U": 100, "V": 101})
+    for n, tid in ids.items():
+        eng.set_tensor(tid, o.p[n])
+    perm = rng.permutation(U)
+    dl_ref, gl_ref = o.train_epoch(urm, perm, min(B, U), 1, 1)
+    dl, gl = eng.train_epoch(perm, 1, 1)
+    np.testing.assert_allclose(dl, dl_ref, rtol=5e-4, atol=1e-6, err_msg=str((U, N, k, e, B, layers, act)))
+    np.testing.assert_allclose(gl, gl_ref, rtol=5e-4, atol=1e-6, err_msg=str((U, N, k, e, B, layers, act)))
+    for n, tid in ids.items():
+        assert _err(eng.get_tensor(tid), o.p[n]) <= 5e-4, (n, U, N, k, e, B, layers, act)
+    eng.close()
