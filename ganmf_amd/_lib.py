@@ -18,7 +18,7 @@ PROF_MAX = 48
 
 # every exported symbol of include/ganmf_hip.h (checked by tests/test_abi.py)
 SYMBOLS = [
-    "ganmf_create", "ganmf_destroy", "ganmf_comm_unique_id", "ganmf_comm_init", "ganmf_set_urm_csr",
+    "ganmf_create", "ganmf_destroy", "ganmf_comm_unique_id", "ganmf_comm_init", "ganmf_comm_init_local", "ganmf_set_urm_csr",
     "ganmf_set_tensor", "ganmf_get_tensor", "ganmf_tensor_shape", "ganmf_get_adam_powers",
     "ganmf_set_adam_powers", "ganmf_train_epoch", "ganmf_train_step", "ganmf_scores",
     "ganmf_set_seen_csr", "ganmf_recommend", "ganmf_snapshot_best", "ganmf_restore_best", "ganmf_profile_enable", "ganmf_profile_read",
@@ -76,6 +76,7 @@ def load_library():
         "ganmf_destroy": (C.c_int, [vp]),
         "ganmf_comm_unique_id": (C.c_int, [P(C.c_uint8)]),
         "ganmf_comm_init": (C.c_int, [vp, P(C.c_uint8)]),
+        "ganmf_comm_init_local": (C.c_int, [vp, i32]),
         "ganmf_set_urm_csr": (C.c_int, [vp, P(C.c_int64), P(C.c_int32), f32p, i64, i64]),
         "ganmf_set_tensor": (C.c_int, [vp, C.c_int, C.c_int, f32p, i64]),
         "ganmf_get_tensor": (C.c_int, [vp, C.c_int, C.c_int, f32p, i64]),

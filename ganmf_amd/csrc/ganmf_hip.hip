@@ -24,6 +24,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <chrono>
+#include <condition_variable>
+#include <map>
+#include <memory>
 #include <mutex>
 #include <vector>
 
@@ -114,6 +118,26 @@ struct ProfRec { int tag; hipEvent_t a, b; double flops, bytes; };
 
 }  // namespace
 
+// ---- in-process loopback communicator: group state (see allreduce_local) ----
+constexpr int LOCAL_MAX_WORLD = 8;
+struct LocalPtrs { float* p[LOCAL_MAX_WORLD]; };
+__global__ void local_allreduce_kernel(LocalPtrs b, int world, size_t count) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+    float s = b.p[0][i];
+    for (int r = 1; r < world; ++r) s += b.p[r][i];
+    for (int r = 0; r < world; ++r) b.p[r][i] = s;
+  }
+}
+struct LocalGroup {
+  std::mutex mu;
+  std::condition_variable cv;
+  int world = 0, dev = -1, arrived = 0, joined = 0;
+  long long generation = 0;
+  size_t count = 0;
+  bool failed = false;
+  LocalPtrs bufs{};
+};
+
 struct ganmf_handle {
   ganmf_cfg cfg;
   int dev = 0;
@@ -177,6 +201,7 @@ struct ganmf_handle {
   // RCCL
   ncclComm_t comm = nullptr;
   bool has_comm = false;
+  std::shared_ptr<LocalGroup> local;   // in-process loopback communicator (ganmf_comm_init_local)
   // tuning knobs (environment: GANMF_TILE, GANMF_RING, GANMF_NSPLIT; 0 = cost model decides)
   GemmTune tune;
   bool debug_plan = false;
@@ -283,10 +308,49 @@ float* slot_ptr(Tensor* t, int slot) {
 inline double gemm_flops(double M, double N, double K) { return 2.0 * M * N * K; }
 inline double gemm_bytes(double M, double N, double K) { return 4.0 * (M * K + N * K + M * N); }
 
+// ---- in-process loopback communicator ---------------------------------------------------------------
+// Several handles of ONE process (driven by one host thread each) on the same device form a group; an all-reduce
+// is a rendezvous: every member drains the stream its buffer is produced on, the last to arrive sums the buffers in
+// rank order (deterministic) into every member's buffer and releases the others.  It exists so that the
+// data-parallel arithmetic (global-batch scales, the two-float exchange before the hinge, ranks that run out of
+// rows) can be exercised with world_size > 1 on a single GPU; multi-GPU runs use RCCL.
+static std::mutex g_local_mu;
+static std::map<int, std::shared_ptr<LocalGroup>> g_local_groups;
+
+int allreduce_local(ganmf_handle* h, float* buf, size_t count, hipStream_t st) {
+  LocalGroup& g = *h->local;
+  HIP_TRY(hipStreamSynchronize(st));                    // this member's contribution is complete
+  std::unique_lock<std::mutex> lk(g.mu);
+  if (g.failed) return fail(-3, "local communicator: a peer failed");
+  if (g.arrived == 0) g.count = count;
+  else if (g.count != count) { g.failed = true; g.cv.notify_all(); return fail(-3, "local communicator: members disagree on the element count"); }
+  g.bufs.p[h->cfg.rank] = buf;
+  if (++g.arrived == g.world) {
+    const int grid = (int)std::min<size_t>(1024, (count + 255) / 256);
+    hipLaunchKernelGGL(local_allreduce_kernel, dim3(std::max(grid, 1)), dim3(256), 0, st, g.bufs, g.world, count);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    g.arrived = 0;
+    ++g.generation;
+    if (e != hipSuccess) g.failed = true;
+    g.cv.notify_all();
+    if (e != hipSuccess) return fail(-2, "local communicator: %s", hipGetErrorString(e));
+    return 0;
+  }
+  const long long gen = g.generation;
+  if (!g.cv.wait_for(lk, std::chrono::seconds(120), [&] { return g.generation != gen || g.failed; })) {
+    g.failed = true;
+    g.cv.notify_all();
+    return fail(-3, "local communicator: timed out waiting for %d peer(s)", g.world - g.arrived);
+  }
+  return g.failed ? fail(-3, "local communicator: a peer failed") : 0;
+}
+
 int allreduce(ganmf_handle* h, float* buf, size_t count, int lane = 0) {
   if (!h->has_comm) return 0;
   hipStream_t st = lane ? h->st2 : h->st;
   Scope s(h, T_ALLREDUCE, 0, 4.0 * count, st);
+  if (h->local) return allreduce_local(h, buf, count, st);
   NCCL_TRY(ncclAllReduce(buf, buf, count, ncclFloat, ncclSum, h->comm, st));
   return 0;
 }
@@ -837,7 +901,9 @@ void finish_losses(const ganmf_handle* h, const std::vector<float>& dp, const st
   if (h->cfg.model == GANMF_MODEL_DISGANMF) {
     for (int64_t i = 0; i < nd && d_losses; ++i) {
       const float bg = (float)bglob[i % per_pass];
-      d_losses[i] = (dp[4 * i] / bg + dp[4 * i + 1] / bg) + h->cfg.d_reg * (dp[4 * i + 2] / 2.0f);
+      float sq = dp[4 * i + 2];
+      if (h->has_comm && h->cfg.world_size > 1) sq /= (float)h->cfg.world_size;   // replicated tensors: summed world times
+      d_losses[i] = (dp[4 * i] / bg + dp[4 * i + 1] / bg) + h->cfg.d_reg * (sq / 2.0f);
     }
     for (int64_t i = 0; i < ng && g_losses; ++i) {
       const float bg = (float)bglob[i % per_pass];
@@ -1020,7 +1086,12 @@ int ganmf_destroy(ganmf_handle* h) {
   if (!h) return 0;
   hipSetDevice(h->dev);
   hipStreamSynchronize(h->st);
-  if (h->has_comm) ncclCommDestroy(h->comm);
+  if (h->has_comm && !h->local) ncclCommDestroy(h->comm);
+  if (h->local) {
+    std::lock_guard<std::mutex> lk(h->local->mu);
+    h->local->failed = true;            // a group does not outlive any of its members
+    h->local->cv.notify_all();
+  }
   free_tensor(h->We, false); free_tensor(h->Wd, false); hipFree(h->zero_page); hipFree(h->Es);
   for (auto& t : h->Wl) free_tensor(t, false);
   free_tensor(h->Wo, false);
@@ -1047,6 +1118,26 @@ int ganmf_comm_unique_id(uint8_t out128[128]) {
   ncclUniqueId id;
   NCCL_TRY(ncclGetUniqueId(&id));
   memcpy(out128, &id, 128);
+  return 0;
+}
+
+int ganmf_comm_init_local(ganmf_handle* h, int32_t group_id) {
+  if (!h) return fail(-1, "null handle");
+  if (h->has_comm) return fail(-1, "ganmf_comm_init_local: handle already has a communicator");
+  const int world = h->cfg.world_size, rank = h->cfg.rank;
+  if (world < 1 || world > LOCAL_MAX_WORLD || rank < 0 || rank >= world)
+    return fail(-1, "ganmf_comm_init_local: world_size %d / rank %d out of range (max %d)", world, rank, LOCAL_MAX_WORLD);
+  std::lock_guard<std::mutex> lk(g_local_mu);
+  std::shared_ptr<LocalGroup>& slot = g_local_groups[group_id];
+  if (!slot || slot->joined == slot->world || slot->failed) {      // first member of a new group with this id
+    slot = std::make_shared<LocalGroup>();
+    slot->world = world; slot->dev = h->dev;
+  }
+  if (slot->world != world || slot->dev != h->dev)
+    return fail(-1, "ganmf_comm_init_local: group %d is for world_size %d on device %d", group_id, slot->world, slot->dev);
+  ++slot->joined;
+  h->local = slot;
+  h->has_comm = true;
   return 0;
 }
 
@@ -1187,6 +1278,9 @@ int ganmf_train_epoch(ganmf_handle* h, const int32_t* perm, int64_t n, int32_t d
       TRY(any_g_step(h, h->perm + std::min<int64_t>(a, std::max<int64_t>(n - 1, 0)), nb, (int)a, bglob[i], idx));
     }
   TRY(arenas_finish(h, nd, ng));
+  // loss parts are sums over this rank's rows: one all-reduce per epoch.  (GANMF's D loss is formed on the device
+  // from the sums that were all-reduced before the hinge and is global already.)
+  if (dist && nd > 0 && h->cfg.model == GANMF_MODEL_DISGANMF) TRY(allreduce(h, h->d_parts, (size_t)nd * 4));
   if (dist && ng > 0) TRY(allreduce(h, h->g_parts, (size_t)ng * 4));
   std::vector<float> dp((size_t)std::max<int64_t>(nd, 1) * 4), gp((size_t)std::max<int64_t>(ng, 1) * 4);
   HIP_TRY(hipMemcpyAsync(dp.data(), h->d_parts, dp.size() * sizeof(float), hipMemcpyDeviceToHost, h->st));

@@ -151,6 +151,10 @@ class Engine:
         L.check(self.lib.ganmf_bench_scores(self.h, n, int(transposed), iters, C.byref(ms)), "ganmf_bench_scores")
         return ms.value
 
+    def comm_init_local(self, group_id):
+        """join the in-process loopback communicator `group_id` (all world_size engines of this process must)"""
+        L.check(self.lib.ganmf_comm_init_local(self.h, int(group_id)), "ganmf_comm_init_local")
+
     def comm_init(self, id_bytes):
         arr = (C.c_uint8 * 128).from_buffer_copy(bytes(id_bytes))
         L.check(self.lib.ganmf_comm_init(self.h, arr), "ganmf_comm_init")

@@ -88,6 +88,10 @@ int ganmf_destroy(ganmf_handle* h);
  * ganmf_comm_unique_id, the host broadcasts the 128 bytes, every rank calls ganmf_comm_init. */
 int ganmf_comm_unique_id(uint8_t out128[128]);
 int ganmf_comm_init(ganmf_handle* h, const uint8_t id128[128]);
+/* In-process alternative to the RCCL communicator: the world_size handles that call this with the same group_id
+ * (same process, same device, one host thread each) all-reduce among themselves by rendezvous; sums run in rank
+ * order.  For exercising the data-parallel path with world_size > 1 on one GPU (tests/test_gpu_dist_local.py). */
+int ganmf_comm_init_local(ganmf_handle* h, int32_t group_id);
 
 /* Replaces the per-minibatch host work `URM_train[uids].toarray()` + feed_dict upload
  * (GANMF.py:183-187,198-201): the CSR matrix (training orientation, this handle's rows) is

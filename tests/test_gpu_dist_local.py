@@ -1,0 +1,138 @@
+"""The data-parallel path of the library with world_size > 1 on ONE GPU, through the in-process loopback
+communicator (ganmf_comm_init_local): one host thread per rank, each with its own engine, shard of the CSR matrix,
+rows of U and row_offset.  One epoch (a D pass then a G pass over ragged, unequal shards — one rank runs out of rows
+before the others) must reproduce the single-process oracle on the UNION batches: replicated tensors identical on
+every rank (bitwise) and equal to the oracle's, every rank's rows of U equal to the oracle's rows, and the losses
+every rank reports equal to the union-batch losses.  The RCCL communicator takes the same code path with
+ncclAllReduce in place of the rendezvous (tests/test_gpu_parity.py runs it with one rank)."""
+import threading
+
+import numpy as np
+import pytest
+import scipy.sparse as sps
+
+from ganmf_amd.dist import epoch_plan, shard_bounds
+from oracle.ganmf_oracle import DisGANMFOracle, GANMFOracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _err(got, ref):
+    return np.max(np.abs(np.asarray(got, np.float64).reshape(np.shape(ref)) - ref)) / (np.max(np.abs(ref)) + 1e-30)
+
+
+def _run_ranks(world, make_engine, bounds, perms, B, group):
+    from ganmf_amd import _lib as L
+    steps, grows = epoch_plan([b - a for a, b in bounds], B)
+    out, errs = [None] * world, []
+    engines = [make_engine(r) for r in range(world)]
+    for e in engines:
+        e.comm_init_local(group)
+
+    def work(r):
+        try:
+            out[r] = engines[r].train_epoch(perms[r], 1, 1, steps_per_pass=steps, global_batch_rows=grows)
+        except Exception as ex:      # a failed rank must not leave its peers in the rendezvous
+            errs.append((r, ex))
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(300)
+    assert not errs, errs
+    assert all(not t.is_alive() for t in threads)
+    return engines, out, steps
+
+
+@pytest.mark.parametrize("world,U", [(2, 37), (3, 50)])
+def test_ganmf_sharded_epoch_equals_union_batch(world, U):
+    from ganmf_amd.engine import Engine
+    N, k, e, B = 61, 5, 9, 8
+    rng = np.random.RandomState(world)
+    urm = sps.csr_matrix((rng.rand(U, N) < 0.15).astype(np.float32))
+    hp = dict(d_lr=1e-3, g_lr=2e-3, d_reg=1e-3, g_reg=1e-4, m=10.0, recon_coefficient=0.2)
+    o = GANMFOracle(U, N, k, e, dtype=np.float64, seed=3, **hp)
+    o.set_params(be=rng.randn(e) * 0.01, bd=rng.randn(N) * 0.01)
+    p0 = o.get_params()
+    bounds = shard_bounds(U, world)
+    perms = [rng.permutation(b - a) for a, b in bounds]
+
+    def make_engine(r):
+        lo, hi = bounds[r]
+        eng = Engine(hi - lo, N, k, e, B, world_size=world, rank=r, row_offset=lo, **hp)
+        eng.set_urm(urm[lo:hi])
+        for n, tid in (("We", 0), ("be", 1), ("Wd", 2), ("bd", 3), ("V", 101)):
+            eng.set_tensor(tid, p0[n])
+        eng.set_tensor(100, p0["U"][lo:hi])
+        return eng
+
+    engines, out, steps = _run_ranks(world, make_engine, bounds, perms, B, group=100 + world)
+    # oracle on the union batches: D pass, then G pass, over the same slices
+    unions = [np.concatenate([bounds[r][0] + perms[r][i * B:(i + 1) * B] for r in range(world)]) for i in range(steps)]
+    dl_ref = [o.d_step(u, urm[u].toarray()) for u in unions]
+    gl_ref = [o.g_step(u, urm[u].toarray()) for u in unions]
+    for r in range(world):
+        np.testing.assert_allclose(out[r][0], dl_ref, rtol=1e-4, atol=1e-7)
+        np.testing.assert_allclose(out[r][1], gl_ref, rtol=1e-4, atol=1e-7)
+    for n, tid in (("We", 0), ("be", 1), ("Wd", 2), ("bd", 3), ("V", 101)):
+        t0 = engines[0].get_tensor(tid)
+        assert _err(t0, o.p[n]) <= 1e-4, n
+        for r in range(1, world):
+            assert np.array_equal(engines[r].get_tensor(tid), t0), (n, r)       # replicas stay identical
+    for r, (lo, hi) in enumerate(bounds):
+        assert _err(engines[r].get_tensor(100), o.p["U"][lo:hi]) <= 1e-4, r
+    for eng in engines:
+        eng.close()
+
+
+def test_disganmf_sharded_epoch_equals_union_batch():
+    from ganmf_amd import _lib as L
+    from ganmf_amd.engine import Engine
+    world, U, N, k, e, B = 2, 29, 40, 4, 7, 8
+    rng = np.random.RandomState(9)
+    urm = sps.csr_matrix((rng.rand(U, N) < 0.2).astype(np.float32))
+    hp = dict(d_lr=1e-3, g_lr=1e-3, d_reg=1e-4, g_reg=0.0, recon_coefficient=0.3)
+    o = DisGANMFOracle(U, N, k, d_layers=2, d_nodes=e, d_hidden_act="tanh", dtype=np.float64, seed=2, **hp)
+    p0 = {n: v.copy() for n, v in o.p.items()}
+    bounds = shard_bounds(U, world)
+    perms = [rng.permutation(b - a) for a, b in bounds]
+    ids = {"W0": 0, "b0": 1, "W1": 2, "b1": 3, "Wo": 4, "bo": 5, "V": 101}
+
+    def make_engine(r):
+        lo, hi = bounds[r]
+        eng = Engine(hi - lo, N, k, e, B, model=L.MODEL_DISGANMF, d_layers=2, d_act="tanh", m=0.0, world_size=world, rank=r,
+                     row_offset=lo, **hp)     # row_offset: the net is fed float(GLOBAL uid) (DisGANMF.py:110)
+        eng.set_urm(urm[lo:hi])
+        for n, tid in ids.items():
+            eng.set_tensor(tid, p0[n])
+        eng.set_tensor(100, p0["U"][lo:hi])
+        return eng
+
+    engines, out, steps = _run_ranks(world, make_engine, bounds, perms, B, group=77)
+    unions = [np.concatenate([bounds[r][0] + perms[r][i * B:(i + 1) * B] for r in range(world)]) for i in range(steps)]
+    dl_ref = [o.d_step(u, urm[u].toarray()) for u in unions]
+    gl_ref = [o.g_step(u, urm[u].toarray()) for u in unions]
+    for r in range(world):
+        np.testing.assert_allclose(out[r][0], dl_ref, rtol=5e-4, atol=1e-6)
+        np.testing.assert_allclose(out[r][1], gl_ref, rtol=5e-4, atol=1e-6)
+    for n, tid in ids.items():
+        t0 = engines[0].get_tensor(tid)
+        assert _err(t0, o.p[n]) <= 5e-4, n
+        assert np.array_equal(engines[1].get_tensor(tid), t0), n
+    for r, (lo, hi) in enumerate(bounds):
+        assert _err(engines[r].get_tensor(100), o.p["U"][lo:hi]) <= 5e-4, r
+    for eng in engines:
+        eng.close()
+
+
+def test_local_group_errors():
+    from ganmf_amd import _lib as L
+    from ganmf_amd.engine import Engine
+    a = Engine(8, 9, 2, 3, 4, world_size=2, rank=0)
+    a.comm_init_local(5)
+    with pytest.raises(L.GanmfError, match="already has a communicator"):
+        a.comm_init_local(5)
+    b = Engine(8, 9, 2, 3, 4, world_size=3, rank=1)
+    with pytest.raises(L.GanmfError, match="world_size"):
+        b.comm_init_local(5)
+    a.close(); b.close()
