@@ -1,12 +1,16 @@
 // Does VALU work overlap with bf16 MFMAs on one SIMD?  Each wave runs ITER rounds of
-//   NM x v_mfma_f32_32x32x16_bf16 (4 independent accumulators)  +  NV x VALU ops (and / pk_add / perm mix)
-// in three orders: MFMAs only, VALU only, blocked (all MFMAs then all VALU), fine (1 MFMA : NV/NM VALU).
+//   24 x v_mfma_f32_32x32x16_bf16 (4 independent accumulators)  and / or  168 x VALU (v_and_b32 on 8 registers)
+// in four orders: MFMAs only, VALU only, blocked (all MFMAs then all VALU), fine (1 MFMA : 7 VALU).
+// Every instruction is its own `asm volatile`, so hipcc keeps the written order (a first version used builtins and
+// sched_barrier: the compiler regrouped the MFMAs and the "fine" case was not fine at all).
 // Launched with 1 and 2 waves per SIMD.  Build: hipcc -O3 --offload-arch=gfx950 mfma_valu.hip -o mfma_valu
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+#define MF(q) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[(q) & 3]) : "v"(a), "v"(b))
+#define VA(j) asm volatile("v_and_b32 %0, 0xffff0fff, %0" : "+v"(v[(j) & 7]))
 
 template <int MODE>
 __global__ __launch_bounds__(256) void k(const unsigned* in, float* out, long long* cyc, int iters) {
@@ -17,29 +21,22 @@ __global__ __launch_bounds__(256) void k(const unsigned* in, float* out, long lo
   for (int j = 0; j < 8; ++j) v[j] = in[threadIdx.x + 8 + j];
   const long long t0 = __builtin_readcyclecounter();
   for (int it = 0; it < iters; ++it) {
-#define MF(q) acc[q & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc[q & 3], 0, 0, 0)
-#define VA(j) { v[j & 7] = (v[j & 7] & 0xffff0000u) + v[(j + 1) & 7]; v[(j + 3) & 7] = __builtin_amdgcn_perm(v[j & 7], v[(j + 5) & 7], 0x07060302u); \
-                v[(j + 2) & 7] = __float_as_uint(__uint_as_float(v[(j + 2) & 7]) - __uint_as_float(v[(j + 6) & 7])); }
     if (MODE == 0) {
 #pragma unroll
       for (int q = 0; q < 24; ++q) MF(q);
     } else if (MODE == 1) {
 #pragma unroll
-      for (int j = 0; j < 48; ++j) VA(j);     // 48 x 4 = 192 VALU ops
+      for (int j = 0; j < 168; ++j) VA(j);
     } else if (MODE == 2) {
 #pragma unroll
       for (int q = 0; q < 24; ++q) MF(q);
-      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int j = 0; j < 48; ++j) VA(j);
-      __builtin_amdgcn_sched_barrier(0);
+      for (int j = 0; j < 168; ++j) VA(j);
     } else {
 #pragma unroll
       for (int q = 0; q < 24; ++q) {
         MF(q);
-        __builtin_amdgcn_sched_barrier(0);
-        VA(2 * q); VA(2 * q + 1);
-        __builtin_amdgcn_sched_barrier(0);
+        VA(7 * q); VA(7 * q + 1); VA(7 * q + 2); VA(7 * q + 3); VA(7 * q + 4); VA(7 * q + 5); VA(7 * q + 6);
       }
     }
   }
@@ -56,7 +53,7 @@ int main() {
   hipMalloc(&in, 4096); hipMemset(in, 0, 4096);
   hipMalloc(&out, 1024 * 256 * 4); hipMalloc(&cyc, 1024 * 8);
   const int iters = 2000;
-  const char* names[4] = {"24 MFMA only", "192 VALU only", "blocked 24 MFMA + 192 VALU", "fine 1 MFMA : 8 VALU"};
+  const char* names[4] = {"24 MFMA only", "168 VALU only", "blocked 24 MFMA + 168 VALU", "fine 1 MFMA : 7 VALU"};
   for (int wgs = 256; wgs <= 512; wgs *= 2) {     // 256 = 1 wave/SIMD, 512 = 2 waves/SIMD
     for (int m = 0; m < 4; ++m) {
       for (int rep = 0; rep < 2; ++rep) {
@@ -68,7 +65,7 @@ int main() {
       }
       long long h[1024]; hipMemcpy(h, cyc, wgs * 8, hipMemcpyDeviceToHost);
       double avg = 0; for (int i = 0; i < wgs; ++i) avg += h[i]; avg /= wgs;
-      printf("%d waves/SIMD  %-30s %8.1f clk-counter ticks per round per wave\n", wgs / 256, names[m], avg / iters);
+      printf("%d waves/SIMD  %-30s %8.1f cycles per round per wave\n", wgs / 256, names[m], avg / iters);
     }
   }
   return 0;
