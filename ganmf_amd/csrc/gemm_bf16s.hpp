@@ -7,8 +7,9 @@
 //     three LDS planes per operand; a.b is accumulated in fp32 from the six piece products of weight >= 2^-18
 //     on v_mfma_f32_32x32x16_bf16.
 //     (Splitting at fragment-read time instead — fp32 tiles in LDS, each wave splitting what it reads — repeats the
-//     VALU work in both waves that share a fragment; measured on MI355X, VALU and MFMA issue time ADD on a SIMD
-//     (tools/ubench/mfma_valu.hip), and that variant was 3 % slower at 4096^3 and 30 % slower in bf16 mode.)
+//     VALU work in both waves that share a fragment; hipcc emits VALU work and MFMAs in blocks, whose issue times
+//     add on a SIMD (tools/ubench/mfma_valu.hip), and that variant was 3 % slower at 4096^3 and 30 % slower in
+//     bf16 mode.)
 //   * HBM/L2 -> registers -> split -> LDS.  One LDS buffer, the next K-tile prefetched into registers while the
 //     current one is multiplied; two workgroups per CU cover each other's barriers.
 //   * LDS plane layouts (dword = two bf16 with consecutive k, low half first):
@@ -190,8 +191,7 @@ __global__ __launch_bounds__(256) void gemm_bf16s_mfma(const GemmP p) {
       for (int q = 0; q < NPIECE; ++q) pb[set][b][q] = SB::frag(planes_b + q * SB::PLANE, wc * WN + b * 32, c, li, lh);
   };
   auto mfmas = [&](int set) {
-    // piece products in increasing weight, blocks innermost (dependent MFMAs are TM*TN issues apart).  (A second
-    // accumulator for the five correction products was tried: no change in accuracy, 128 more registers.)
+    // piece products in increasing weight, blocks innermost (dependent MFMAs are TM*TN issues apart)
     constexpr int NT = NPIECE == 3 ? 6 : 1;
     constexpr int ta[6] = {1, 0, 2, 1, 0, 0}, tb[6] = {1, 2, 0, 0, 1, 0};   // (mid,mid) (hi,lo) (lo,hi) (mid,hi) (hi,mid) (hi,hi)
 #pragma unroll
