@@ -697,8 +697,8 @@ inline GemmPlan gemm_plan(int M, int N, int K, int nbatch, bool wants_sq, const 
   best.ring = tune.ring ? tune.ring : (wgs > GEMM_CUS ? 2 : 3);
   if (best.nsplit == 1) best.kps = ((K + GEMM_K_ALIGN - 1) / GEMM_K_ALIGN) * GEMM_K_ALIGN;
   // MFMA_AUTO: the split-bf16 K loop wins where the fp32 K loop is MFMA-bound — 128x128 tiles with at least two
-  // workgroups per CU (measured 108 vs 78 TFLOP/s on 6040x3706x250, 161 vs 120 on 4096^3); the skinny GEMMs of
-  // a 128-row training step are ingest/epilogue-bound and lose 4-7 % to the split's VALU work, so they stay fp32.
+  // workgroups per CU (measured 115 vs 78 TFLOP/s on 6040x3706x250, 172 vs 120 on 4096^3); the skinny GEMMs of
+  // a 128-row training step are ingest/epilogue-bound and lose 3 % to the split's VALU work, so they stay fp32.
   best.mode = tune.mode != MFMA_AUTO ? tune.mode : (best.tile == 128 && wgs >= 2 * GEMM_CUS ? MFMA_BF16X3 : MFMA_F32);
   best.sq_count = wants_sq ? best.tiles_m * best.tiles_n : 0;   // (separate reduce kernel: GEMM_RED_GRID, set by gemm_run)
   return best;
