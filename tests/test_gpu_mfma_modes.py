@@ -84,7 +84,11 @@ def test_ganmf_steps_all_modes_vs_oracle():
         X = urm[uids].toarray()
         ref_losses.append((o.d_step(uids, X), o.g_step(uids, X)))
     ref_scores = o.scores(perm[:2048])
-    for mfma, ltol, ptol, stol in ((None, 5e-5, 5e-5, 1e-4), ("f32", 5e-5, 5e-5, 1e-4), ("bf16", 5e-3, 2e-2, 1e-2)):   # bf16: an Adam step is +-lr whatever |g|, so a near-zero gradient
+    # parameter bound 1e-4 for the fp32-accurate modes: after two updates the decoder bias (|g| ~ Adam's epsilon, so the
+    # update divides by |g| + eps) is 3e-5 off the fp64 oracle in the numpy-fp32 restatement itself, 4.6e-5 with the
+    # fp32 MFMA everywhere and 5.2e-5 with the split-bf16 loop on the two weight-gradient GEMMs; every other tensor
+    # agrees to 1e-6 .. 4e-6 in all three
+    for mfma, ltol, ptol, stol in ((None, 5e-5, 1e-4, 1e-4), ("f32", 5e-5, 1e-4, 1e-4), ("bf16", 5e-3, 2e-2, 1e-2)):   # bf16: an Adam step is +-lr whatever |g|, so a near-zero gradient
                                                 # whose sign flips under rounding moves theta by 2 lr T = 1 % of max|We|
         eng = Engine(U, N, k, e, B, mfma=mfma, **hp)
         eng.set_urm(urm)
