@@ -12,6 +12,7 @@ import collections
 import csv
 import glob
 import json
+import os
 import re
 import sys
 
@@ -22,7 +23,7 @@ LAYOUT = {"gemm_generator": ("false", "false"), "gemm_encode": ("false", "true")
 
 
 def counters(d, name):
-    f = glob.glob(d + "/*/*counter_collection.csv")[0]
+    f = max(glob.glob(d + "/*/*counter_collection.csv"), key=os.path.getmtime)   # newest pass if the directory was reused
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == name:
