@@ -696,10 +696,14 @@ inline GemmPlan gemm_plan(int M, int N, int K, int nbatch, bool wants_sq, const 
   const long long wgs = (long long)best.tiles_m * best.tiles_n * nbatch * best.nsplit;
   best.ring = tune.ring ? tune.ring : (wgs > GEMM_CUS ? 2 : 3);
   if (best.nsplit == 1) best.kps = ((K + GEMM_K_ALIGN - 1) / GEMM_K_ALIGN) * GEMM_K_ALIGN;
-  // MFMA_AUTO: the split-bf16 K loop wins where the fp32 K loop is MFMA-bound — 128x128 tiles with at least two
-  // workgroups per CU (measured 115 vs 78 TFLOP/s on 6040x3706x250, 172 vs 120 on 4096^3); the skinny GEMMs of
-  // a 128-row training step are ingest/epilogue-bound and lose 3 % to the split's VALU work, so they stay fp32.
-  best.mode = tune.mode != MFMA_AUTO ? tune.mode : (best.tile == 128 && wgs >= 2 * GEMM_CUS ? MFMA_BF16X3 : MFMA_F32);
+  // MFMA_AUTO: the staged split-bf16 kernel has the better throughput per CU once two or more workgroups share a
+  // CU (K sweeps on MI355X, 993x3706xK: 1.28 vs 1.41 us per 64x64x64 workgroup-tile; 6040x3706x250: 97 vs 141 us;
+  // 4096^3: 172 vs 120 TFLOP/s), the fp32 ring kernel the shorter latency when a workgroup has its CU to itself
+  // (256x3706x2048 on 232 workgroups: 48 vs 57 us).  Every K-heavy 128/256-row GEMM of the C2 step is planned onto
+  // <= 256 workgroups and stays fp32.  GEMMs of >= 6 GFLOP (the C4-sized steps: K or N = 50 000) run long enough
+  // per workgroup that the split-bf16 loop wins on any grid (C4 shard: 955 vs 846 steps/s with every GEMM on it).
+  const double gflop = 2.0 * M * (double)N * K * nbatch * 1e-9;
+  best.mode = tune.mode != MFMA_AUTO ? tune.mode : (wgs >= 2 * GEMM_CUS || gflop >= 6.0 ? MFMA_BF16X3 : MFMA_F32);
   best.sq_count = wants_sq ? best.tiles_m * best.tiles_n : 0;   // (separate reduce kernel: GEMM_RED_GRID, set by gemm_run)
   return best;
 }
