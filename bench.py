@@ -247,6 +247,9 @@ def main():
             "config": {"workload": "GANMF --user, MovieLens-1M shape %dx%d per GPU, k=%d, emb_dim=%d, batch=%d/GPU, "
                                    "tuned hyper-parameters (BASELINE.json configs[1])" % (w["U"], w["N"], w["k"], w["e"], w["B"]),
                        "step": "one 128-row minibatch update (D or G), K/2 D then K/2 G",
+                       "arithmetic": "float32 tensors throughout; GEMM K loops on the fp32 MFMA, except the two fused-Adam "
+                                     "weight-gradient GEMMs of the D-step, which run the fp32-accurate split-bf16 loop "
+                                     "(3 exact bf16 pieces per operand, 6 piece products, fp32 accumulate)",
                        "global_steps_per_s": round(done / el, 2), "rows_per_s": round(world * done * w["B"] / el, 1),
                        "parallelism": "dp%d (users sharded row-wise, RCCL all-reduce of D and V gradients)" % world},
             "roofline": roofline, "scoring_gemm": scoring, "kernels": kernels,
