@@ -81,3 +81,29 @@ def test_disganmf_random_config(seed):
     for n, tid in ids.items():
         assert _err(eng.get_tensor(tid), o.p[n]) <= 5e-4, (n, U, N, k, e, B, layers, act)
     eng.close()
+
+
+def test_engine_create_destroy_does_not_leak():
+    """The tuner creates and destroys an engine per trial: device memory must return to the pool."""
+    import torch
+    from ganmf_amd.engine import Engine
+    rng = np.random.RandomState(0)
+    urm = sps.csr_matrix((rng.rand(300, 500) < 0.05).astype(np.float32))
+
+    def cycle(n):
+        for _ in range(n):
+            eng = Engine(300, 500, 16, 24, 64)
+            eng.set_urm(urm)
+            eng.set_seen(urm)
+            eng.train_epoch(rng.permutation(300), 1, 1)
+            eng.scores(np.arange(300))
+            eng.recommend(np.arange(300), 5)
+            eng.snapshot_best()
+            eng.close()
+    cycle(3)                                   # warm allocator / RCCL / HIP module state
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    cycle(40)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 8 << 20, "device memory shrank by %.1f MiB over 40 engine lifetimes" % ((free0 - free1) / 2 ** 20)
