@@ -144,7 +144,6 @@ struct ganmf_handle {
   hipStream_t st = nullptr;
   hipStream_t st2 = nullptr;             // side lane: independent kernels overlap the main lane
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_mid = nullptr;
-  bool overlap = true;
   int U = 0, N = 0, k = 0, e = 0, B = 0;
   int ldN = 0, ldk = 0, lde = 0;
   // DisGANMF (model 1): hidden layers W_l_ext and the output unit; see the DisGANMF section below
@@ -1007,7 +1006,6 @@ int ganmf_create(const ganmf_cfg* cfg, ganmf_handle** out) {
   HIP_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&h->ev_mid, hipEventDisableTiming));
-  h->overlap = env_int("GANMF_OVERLAP", 0) != 0;
   h->fuse_adam = env_int("GANMF_FUSE_ADAM", 1) != 0;
   h->inkernel_reduce = env_int("GANMF_INKERNEL_REDUCE", 0) != 0;   // measured slower than the chip-wide reduce kernel
   h->inlaunch_max = env_int("GANMF_INLAUNCH_MAX", 4);
