@@ -204,6 +204,13 @@ def statistical_fixture():
     json.dump({"best_params": hp, "published": _clean(pub)},
               open(os.path.join(OUT, "statistical_kat_hetrec_item.json"), "w"), indent=1)
     print("statistical fixture hetrec item: published MAP@5 =", pub[5]["MAP"])
+    # the remaining published GANMF rows: ML-1M item mode, hetrec2011 user mode (splits already fixtures)
+    for name, exp in (("ml1m_item", "GANMF_item_1M"), ("hetrec_user", "GANMF_user_hetrec2011")):
+        hp = json.load(open(os.path.join(REF, "experiments/%s/best_params.txt" % exp)))
+        pub = pickle.load(open(os.path.join(REF, "test_results/%s/test_results.pkl" % exp), "rb"))
+        json.dump({"best_params": hp, "published": _clean(pub)},
+                  open(os.path.join(OUT, "statistical_kat_%s.json" % name), "w"), indent=1)
+        print("statistical fixture %s: published MAP@5 =" % name, pub[5]["MAP"])
     # DisGANMF on ML-1M (BASELINE configs[4]), both modes
     for mode in ("user", "item"):
         hp = json.load(open(os.path.join(REF, "experiments/DisGANMF_%s_1M/best_params.txt" % mode)))

@@ -36,7 +36,8 @@ def test_ml1m_user_full_training_reaches_published_map(golden_dir):
         assert abs(res[int(c)]["MAP"] - pub[c]["MAP"]) <= 0.005, (c, res[int(c)]["MAP"], pub[c]["MAP"])
 
 
-DATASETS = {"lastfm_user": ("LastFM", "user"), "lastfm_item": ("LastFM", "item"), "hetrec_item": ("hetrec2011", "item")}
+DATASETS = {"lastfm_user": ("LastFM", "user"), "lastfm_item": ("LastFM", "item"), "hetrec_item": ("hetrec2011", "item"),
+            "hetrec_user": ("hetrec2011", "user"), "ml1m_item": ("Movielens1M", "item")}
 
 
 @pytest.mark.parametrize("case", list(DATASETS))
