@@ -211,6 +211,17 @@ def statistical_fixture():
         json.dump({"best_params": hp, "published": _clean(pub)},
                   open(os.path.join(OUT, "statistical_kat_%s.json" % name), "w"), indent=1)
         print("statistical fixture %s: published MAP@5 =" % name, pub[5]["MAP"])
+    # the paper's feature-matching ablation on ML-1M user mode (feature_matching/GANMF_user_1M_XX, alpha = XX/10); each
+    # point has its own tuned parameters.  (The latent-factor sweep under latent_factors/ kept no parameter files.)
+    abl = {}
+    for kind, tags in (("feature_matching", ("00", "02", "04", "06", "08", "10")),):
+        for tag in tags:
+            d = os.path.join(REF, kind, "GANMF_user_1M_" + tag)
+            hp = json.load(open(os.path.join(d, "best_params.txt")))
+            pub = pickle.load(open(os.path.join(d, "GANMF_user_1M", "test_results.pkl"), "rb"))
+            abl["%s_%s" % (kind, tag)] = {"best_params": hp, "published_map5": float(pub[5]["MAP"])}
+    json.dump(abl, open(os.path.join(OUT, "statistical_kat_ml1m_user_ablations.json"), "w"), indent=1)
+    print("ablation fixture:", {k: round(v["published_map5"], 4) for k, v in abl.items()})
     # DisGANMF on ML-1M (BASELINE configs[4]), both modes
     for mode in ("user", "item"):
         hp = json.load(open(os.path.join(REF, "experiments/DisGANMF_%s_1M/best_params.txt" % mode)))
