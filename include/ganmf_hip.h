@@ -68,9 +68,9 @@ typedef struct ganmf_cfg {
 
 #define GANMF_FLAG_NONE 0u
 /* Arithmetic of the GEMM K loops (results are float32 tensors in every case):
- *   default          fp32-accurate products on the bf16 matrix cores (each operand split exactly into three
- *                    bf16 pieces, six piece products accumulated in fp32) or plain fp32 MFMA, whichever the
- *                    build measured faster — both meet the 1e-4 parity bound
+ *   default          fp32-accurate: per GEMM either the fp32 MFMA or the bf16 matrix cores with each operand
+ *                    split exactly into three bf16 pieces and six piece products accumulated in fp32 (chosen by
+ *                    the planner from the grid size; both pass every parity test)
  *   GANMF_FLAG_MFMA_F32   force v_mfma_f32_32x32x2_f32 on the fp32 operands
  *   GANMF_FLAG_MFMA_BF16  operands rounded to ONE bf16 (RNE), fp32 accumulate, fp32 master weights and Adam:
  *                    the mixed-precision variant of BASELINE configs[4] (bf16 instead of fp16: same MFMA rate
