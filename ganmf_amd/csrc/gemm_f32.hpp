@@ -11,7 +11,8 @@
 //   * operands go HBM/L2 -> LDS directly (global_load_lds_dwordx4, no VGPR staging) into an
 //     NS-deep ring of K-tiles; the loop keeps NS-1 tiles in flight behind a COUNTED
 //     s_waitcnt vmcnt and ONE raw s_barrier per K-tile (never __syncthreads(), which drains vmcnt).
-//     The tail issues zero-page tiles so that the count stays a compile-time constant.
+//     Steady-state tiles and the last NS-1 tiles are two loops, each with a compile-time wait count; nothing is
+//     loaded past the K range.
 //   * the LDS image of a glds is lane-linear, so K-contiguous operands are stored unpadded
 //     [row][BK] with the 16-byte chunk index XOR-swizzled by the row on the SOURCE address and
 //     again on the read (conflict-free ds_read_b128; each read feeds 4 MFMAs).  The k index inside
@@ -26,6 +27,8 @@
 //     XCD's L2 once.
 //   * split-K writes fp32 partial slabs (no float atomics: bitwise reproducible, replicas stay
 //     identical across GPUs); the caller reduces them with splitk_reduce_kernel.
+// The same contractions on the bf16 matrix cores (fp32-accurate operand split, or mixed precision): gemm_bf16s.hpp,
+// chosen per GEMM by gemm_plan below; both kernels share gemm_epilogue.
 #pragma once
 #include <hip/hip_runtime.h>
 
