@@ -142,57 +142,60 @@ class GANMF(BaseRecommender):
 
     def _epoch_loop(self, epochs, d_steps, g_steps, allow_worse, freq, after, metrics, sample_every,
                     validation_evaluator, validation_set):
-        """The `while epoch` loop shared by GANMF and DisGANMF (GANMF.py:151-244, DisGANMF.py:152-244)."""
-        self._stop_training = False
-        if validation_evaluator is not None:
-            early_stop = EarlyStoppingScheduler(self, evaluator=validation_evaluator, allow_worse=allow_worse,
-                                                freq=freq, metrics=metrics, after=after)
+        """Epochs 1..`epochs` shared by GANMF and DisGANMF (schedule of GANMF.py:151-244, DisGANMF.py:152-244).
 
-        all_users = np.array(range(self.num_users))
-        self.train_g_loss, self.train_d_loss = [], []
+        Per epoch: ONE in-place shuffle of the row ids on numpy's global stream (cumulative across epochs, which is
+        what makes a seeded run reproduce the reference's minibatch schedule, GANMF.py:175), ONE library call that
+        runs `d_steps` passes of discriminator updates and then `g_steps` passes of generator updates over the same
+        slices of that permutation (:176-203), then the optional progress evaluation and the early-stopping hook.
+        Returns the epoch early stopping fired at, or `epochs + 1` when it never did (the reference's counter is
+        incremented once more before its loop ends, :244 -- callers subtract `allow_worse * freq` from it)."""
+        self._stop_training = False
+        watcher = None
+        if validation_evaluator is not None:
+            watcher = EarlyStoppingScheduler(self, evaluator=validation_evaluator, allow_worse=allow_worse, freq=freq,
+                                             metrics=metrics, after=after)
+        row_ids = np.arange(self.num_users)
+        self.train_d_loss, self.train_g_loss = [], []
+        progress = tqdm.tqdm(total=epochs, initial=1) if (tqdm is not None and self.verbose) else None
         if self.verbose:
             print('Starting training...')
-        t_start = time.time()
-        e_start = time.time()
-        epoch = 1
-        pbar = tqdm.tqdm(total=epochs, initial=1) if (tqdm is not None and self.verbose) else None
-
-        while not self._stop_training and epoch < epochs + 1:
-            np.random.shuffle(all_users)      # global numpy stream, in place, cumulative (GANMF.py:175)
-            # one C call per epoch: d_steps passes of D updates then g_steps passes of G updates
-            # over the same slices of the permutation (GANMF.py:176-203)
-            batch_d_loss, batch_g_loss = self.engine.train_epoch(all_users, d_steps, g_steps)
-            self.train_g_loss.append(np.mean(batch_g_loss) if len(batch_g_loss) else np.nan)
-            self.train_d_loss.append(np.mean(batch_d_loss) if len(batch_d_loss) else np.nan)
+        fit_t0 = window_t0 = time.time()
+        stopped_at = None
+        for epoch in range(1, epochs + 1):
+            np.random.shuffle(row_ids)
+            d_losses, g_losses = self.engine.train_epoch(row_ids, d_steps, g_steps)
+            self.train_d_loss.append(np.mean(d_losses) if len(d_losses) else np.nan)
+            self.train_g_loss.append(np.mean(g_losses) if len(g_losses) else np.nan)
 
             if validation_set is not None and sample_every is not None and epoch % sample_every == 0:
-                t_end = time.time()
-                total = t_end - e_start
-                print('Epoch : {:d}. Total: {:.2f} secs, {:.2f} secs/epoch.'.format(epoch, total, total / sample_every))
-                self._flip_for_evaluation(True)
-                _, results_run_string = validation_evaluator.evaluateRecommender(self)
-                self._flip_for_evaluation(False)
-                print(results_run_string)
-                e_start = time.time()
-
-            if validation_evaluator is not None:
-                self._flip_for_evaluation(True)
-                early_stop(epoch)
-                self._flip_for_evaluation(False)
-                if self._stop_training:
-                    print('Training stopped, epoch:', epoch)
-
-            epoch += 1
-            if pbar is not None:
-                pbar.update()
-        if pbar is not None:
-            pbar.close()
-
+                elapsed = time.time() - window_t0
+                print('Epoch : {:d}. Total: {:.2f} secs, {:.2f} secs/epoch.'.format(epoch, elapsed, elapsed / sample_every))
+                print(self._evaluate_in_eval_orientation(lambda: validation_evaluator.evaluateRecommender(self)[1]))
+                window_t0 = time.time()
+            if watcher is not None:
+                self._evaluate_in_eval_orientation(lambda: watcher(epoch))
+            if progress is not None:
+                progress.update()
+            if self._stop_training:
+                print('Training stopped, epoch:', epoch)
+                stopped_at = epoch
+                break
+        if progress is not None:
+            progress.close()
         if self.verbose:
-            print('Training took {:.2f} seconds'.format(time.time() - t_start))
-        # leave URM_train user x item on exit (GANMF.py:241-242)
-        self.URM_train = self._URM_eval
-        return epoch - 1 if self._stop_training else epoch
+            print('Training took {:.2f} seconds'.format(time.time() - fit_t0))
+        self.URM_train = self._URM_eval      # user x item again once fit() returns (GANMF.py:241-242)
+        return epochs + 1 if stopped_at is None else stopped_at
+
+    def _evaluate_in_eval_orientation(self, call):
+        """Runs `call()` with self.URM_train in user x item orientation (what evaluators and remove-seen expect)
+        and switches back to the training orientation afterwards."""
+        self._flip_for_evaluation(True)
+        try:
+            return call()
+        finally:
+            self._flip_for_evaluation(False)
 
     def _flip_for_evaluation(self, to_eval):
         """The reference flips self.URM_train with .T.tocsr() around every evaluation in item mode
@@ -226,10 +229,18 @@ class GANMF(BaseRecommender):
 
     def recommend_topk(self, user_id_array, cutoff, remove_seen_flag=True):
         """Top-`cutoff` item ids per user as an [n, cutoff] int32 array, -1 padded where a user has fewer
-        finite scores; scores, seen-item mask and selection all stay on the device (ganmf_recommend)."""
+        finite scores; scores, seen-item mask and selection all stay on the device (ganmf_recommend).
+        Cut-offs the device selection does not take (above _DEVICE_TOPK_MAX or above the item count) are ranked by
+        the host route and padded the same way."""
         self._require_engine()
         ids = np.atleast_1d(np.asarray(user_id_array)).reshape(-1)
-        items, _ = self.engine.recommend(ids, cutoff, transposed=(self.mode == 'item'), remove_seen=remove_seen_flag)
+        if 1 <= cutoff <= min(self._DEVICE_TOPK_MAX, self.n_items):
+            items, _ = self.engine.recommend(ids, cutoff, transposed=(self.mode == 'item'), remove_seen=remove_seen_flag)
+            return items
+        lists = self.recommend(ids, cutoff=cutoff, remove_seen_flag=remove_seen_flag, return_scores=True)[0]
+        items = np.full((len(ids), cutoff), -1, dtype=np.int32)
+        for i, row in enumerate(lists):
+            items[i, :len(row)] = row
         return items
 
     def recommend(self, user_id_array, cutoff=None, remove_seen_flag=True, items_to_compute=None,

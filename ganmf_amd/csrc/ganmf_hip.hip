@@ -239,8 +239,8 @@ int dalloc(float** p, size_t elems) {
   return 0;
 }
 
-int alloc_tensor(Tensor& t, int rows, int cols, bool grad_separate) {
-  t.rows = rows; t.cols = cols; t.ld = round_up(cols + 1, LD_ALIGN);
+int alloc_tensor(Tensor& t, int rows, int cols, bool grad_separate, int ld = 0) {
+  t.rows = rows; t.cols = cols; t.ld = ld ? ld : round_up(cols + 1, LD_ALIGN);
   TRY(dalloc(&t.p, t.padded()));
   TRY(dalloc(&t.m, t.padded()));
   TRY(dalloc(&t.v, t.padded()));
@@ -884,17 +884,19 @@ int arenas_finish(ganmf_handle* h, int64_t nd, int64_t ng) {
 int ensure_parts(ganmf_handle* h, int64_t steps) {
   if (steps <= h->parts_cap) return 0;
   HIP_TRY(hipStreamSynchronize(h->st));
-  if (h->d_parts) hipFree(h->d_parts);
-  if (h->g_parts) hipFree(h->g_parts);
-  h->parts_cap = steps + 64;
-  TRY(dalloc(&h->d_parts, (size_t)h->parts_cap * 4));
-  TRY(dalloc(&h->g_parts, (size_t)h->parts_cap * 4));
+  // capacity is only published once every buffer of the new size exists: a failing dalloc leaves cap 0 and null
+  // pointers, so the next call allocates again instead of running on freed memory
+  hipFree(h->d_parts); hipFree(h->g_parts); hipFree(h->d_arena); hipFree(h->g_arena);
+  h->d_parts = h->g_parts = h->d_arena = h->g_arena = nullptr;
+  h->parts_cap = 0;
+  const int64_t cap = steps + 64;
+  TRY(dalloc(&h->d_parts, (size_t)cap * 4));
+  TRY(dalloc(&h->g_parts, (size_t)cap * 4));
   if (h->cfg.model == GANMF_MODEL_GANMF) {
-    if (h->d_arena) hipFree(h->d_arena);
-    if (h->g_arena) hipFree(h->g_arena);
-    TRY(dalloc(&h->d_arena, (size_t)h->parts_cap * 4 * h->reg_cap));
-    TRY(dalloc(&h->g_arena, (size_t)h->parts_cap * 4 * h->reg_cap));
+    TRY(dalloc(&h->d_arena, (size_t)cap * 4 * h->reg_cap));
+    TRY(dalloc(&h->g_arena, (size_t)cap * 4 * h->reg_cap));
   }
+  h->parts_cap = cap;
   return 0;
 }
 
@@ -973,6 +975,8 @@ int ganmf_device_count(void) {
   return n;
 }
 
+static int create_impl(const ganmf_cfg* cfg, ganmf_handle* h);
+
 int ganmf_create(const ganmf_cfg* cfg, ganmf_handle** out) {
   if (!cfg || !out) return fail(-1, "ganmf_create: null argument");
   if (cfg->abi_version != GANMF_ABI_VERSION) return fail(-1, "ganmf_create: ABI version %d != %d", cfg->abi_version, GANMF_ABI_VERSION);
@@ -988,6 +992,23 @@ int ganmf_create(const ganmf_cfg* cfg, ganmf_handle** out) {
   if (cfg->device < 0 || cfg->device >= ndev) return fail(-1, "ganmf_create: device %d out of range [0,%d)", cfg->device, ndev);
   HIP_TRY(hipSetDevice(cfg->device));
   ganmf_handle* h = new ganmf_handle();
+  const int rc = create_impl(cfg, h);
+  if (rc != 0) {
+    // a failed create owns nothing afterwards: every buffer / stream / event allocated so far is released (destroy
+    // tolerates null members) and a sticky hipErrorOutOfMemory is cleared, so the caller (tune.py maps MemoryError to
+    // fitness 0 and keeps running trials in the same process) neither leaks HBM nor sees a spurious error later
+    const std::string msg = g_err;
+    ganmf_destroy(h);
+    (void)hipGetLastError();
+    g_err = msg;
+    *out = nullptr;
+    return rc;
+  }
+  *out = h;
+  return 0;
+}
+
+static int create_impl(const ganmf_cfg* cfg, ganmf_handle* h) {
   h->cfg = *cfg;
   h->dev = cfg->device;
   h->U = (int)cfg->num_users; h->N = (int)cfg->num_items; h->k = cfg->num_factors; h->e = cfg->emb_dim;
@@ -1018,11 +1039,7 @@ int ganmf_create(const ganmf_cfg* cfg, ganmf_handle** out) {
   TRY(alloc_tensor(h->V, N, k, true));
   if (!dis) {
     TRY(alloc_tensor(h->We, N + 1, e, false));   // We_ext: row N = encoder bias
-    TRY(alloc_tensor(h->Wd, e + 1, N, false));   // Wd_ext: row e = decoder bias
-    h->Wd.ld = h->ldN;                           // shares the leading dimension of the [.., N] work buffers
-    hipFree(h->Wd.p); hipFree(h->Wd.m); hipFree(h->Wd.v); hipFree(h->Wd.best);
-    TRY(dalloc(&h->Wd.p, h->Wd.padded())); TRY(dalloc(&h->Wd.m, h->Wd.padded()));
-    TRY(dalloc(&h->Wd.v, h->Wd.padded())); TRY(dalloc(&h->Wd.best, h->Wd.padded()));
+    TRY(alloc_tensor(h->Wd, e + 1, N, false, h->ldN));   // Wd_ext: row e = decoder bias; shares the leading dimension of the [.., N] work buffers
     h->gD_elems = h->We.padded() + h->Wd.padded();
     TRY(dalloc(&h->gD, h->gD_elems));
     h->We.g = h->gD;
@@ -1083,14 +1100,13 @@ int ganmf_create(const ganmf_cfg* cfg, ganmf_handle** out) {
   const float pw[4] = {ADAM_B1, ADAM_B2, ADAM_B1, ADAM_B2};
   HIP_TRY(hipMemcpy(h->scal, pw, sizeof pw, hipMemcpyHostToDevice));
   HIP_TRY(hipDeviceSynchronize());
-  *out = h;
   return 0;
 }
 
 int ganmf_destroy(ganmf_handle* h) {
   if (!h) return 0;
   hipSetDevice(h->dev);
-  hipStreamSynchronize(h->st);
+  if (h->st) hipStreamSynchronize(h->st);
   if (h->has_comm && !h->local) ncclCommDestroy(h->comm);
   if (h->local) {
     std::lock_guard<std::mutex> lk(h->local->mu);
@@ -1109,10 +1125,12 @@ int ganmf_destroy(ganmf_handle* h) {
   hipFree(h->seen_indptr); hipFree(h->seen_indices); hipFree(h->topk_items); hipFree(h->topk_vals); hipFree(h->sc_ids);
   hipFree(h->regp); hipFree(h->d_parts); hipFree(h->g_parts); hipFree(h->d_arena); hipFree(h->g_arena); hipFree(h->sc_rows); hipFree(h->sc_out);
   for (auto& r : h->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
-  hipStreamSynchronize(h->st2);
-  hipEventDestroy(h->ev_fork); hipEventDestroy(h->ev_join); hipEventDestroy(h->ev_mid);
-  hipStreamDestroy(h->st2);
-  hipStreamDestroy(h->st);
+  if (h->st2) hipStreamSynchronize(h->st2);
+  if (h->ev_fork) hipEventDestroy(h->ev_fork);
+  if (h->ev_join) hipEventDestroy(h->ev_join);
+  if (h->ev_mid) hipEventDestroy(h->ev_mid);
+  if (h->st2) hipStreamDestroy(h->st2);
+  if (h->st) hipStreamDestroy(h->st);
   hipFree(h->slab2); hipFree(h->counters); hipFree(h->counters2);
   delete h;
   return 0;
@@ -1335,11 +1353,13 @@ static int scores_device(ganmf_handle* h, const int* ids_dev, int64_t n, int tra
   const int W = colsT.rows, ldw = round_up(W, LD_ALIGN);
   const size_t need_rows = (size_t)n * h->ldk, need_out = (size_t)n * ldw;
   if (need_rows > h->sc_rows_cap) {
-    if (h->sc_rows) hipFree(h->sc_rows);
+    HIP_TRY(hipStreamSynchronize(h->st));
+    hipFree(h->sc_rows); h->sc_rows = nullptr; h->sc_rows_cap = 0;
     TRY(dalloc(&h->sc_rows, need_rows)); h->sc_rows_cap = need_rows;
   }
   if (need_out > h->sc_out_cap) {
-    if (h->sc_out) hipFree(h->sc_out);
+    HIP_TRY(hipStreamSynchronize(h->st));
+    hipFree(h->sc_out); h->sc_out = nullptr; h->sc_out_cap = 0;
     TRY(dalloc(&h->sc_out, need_out)); h->sc_out_cap = need_out;
   }
   const long long total = (long long)n * (h->ldk / 4);
@@ -1425,7 +1445,8 @@ int ganmf_recommend(ganmf_handle* h, const int32_t* ids, int64_t n, int transpos
   const size_t need = (size_t)n * cutoff;
   if (need > h->topk_cap) {
     HIP_TRY(hipStreamSynchronize(h->st));
-    if (h->topk_items) { hipFree(h->topk_items); hipFree(h->topk_vals); }
+    hipFree(h->topk_items); hipFree(h->topk_vals);
+    h->topk_items = nullptr; h->topk_vals = nullptr; h->topk_cap = 0;
     HIP_TRY(hipMalloc((void**)&h->topk_items, need * sizeof(int)));
     HIP_TRY(hipMalloc((void**)&h->topk_vals, need * sizeof(float)));
     h->topk_cap = need;
@@ -1435,12 +1456,15 @@ int ganmf_recommend(ganmf_handle* h, const int32_t* ids, int64_t n, int transpos
   if (rc == 0) {
     const int lds_cap = 32768;   // floats: 128 KiB of the CU's 160 KiB
     const size_t shmem = Wd <= lds_cap ? (size_t)Wd * sizeof(float) : 0;
+    hipError_t e = hipSuccess;
     if (shmem > 48 * 1024)
-      hipFuncSetAttribute(reinterpret_cast<const void*>(mask_topk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(mask_topk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    if (e == hipSuccess) {
     hipLaunchKernelGGL(mask_topk_kernel, dim3((int)n), dim3(256), shmem, h->st, od, ldw, Wd, ids_dev,
                        remove_seen ? h->seen_indptr : (const long long*)nullptr, h->seen_indices, (int)cutoff, lds_cap,
                        h->topk_items, h->topk_vals);
-    hipError_t e = hipGetLastError();
+    e = hipGetLastError();
+    }
     if (e == hipSuccess) e = hipMemcpyAsync(out_items, h->topk_items, need * sizeof(int), hipMemcpyDeviceToHost, h->st);
     if (e == hipSuccess && out_scores) e = hipMemcpyAsync(out_scores, h->topk_vals, need * sizeof(float), hipMemcpyDeviceToHost, h->st);
     if (e == hipSuccess) e = hipStreamSynchronize(h->st);

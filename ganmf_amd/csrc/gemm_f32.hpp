@@ -272,7 +272,7 @@ struct Stage {
       issue_range<J0 + 1, J1>(s, ld, kleft, wave);
     }
   }
-  __device__ inline void issue(float* s, int ld, int kleft, const float* __restrict__ zero, int wave) {
+  __device__ inline void issue(float* s, int ld, int kleft, int wave) {
     issue_range<0, NP>(s, ld, kleft, wave);
   }
 
@@ -509,8 +509,8 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const GemmP p) {
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
     if (kleft > 0) {
-      la.issue(smem + s * BUF, p.lda, kleft, p.zero_page, wave);
-      lb.issue(smem + s * BUF + SA::SZ, p.ldb, kleft, p.zero_page, wave);
+      la.issue(smem + s * BUF, p.lda, kleft, wave);
+      lb.issue(smem + s * BUF + SA::SZ, p.ldb, kleft, wave);
     }
     kleft -= BK;
   }

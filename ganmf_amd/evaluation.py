@@ -1,95 +1,109 @@
-"""Hold-out evaluation — the consumer of the scores (Base/Evaluation/Evaluator.py:214-414,
-metrics.py).  Restates the accuracy metrics the GANMF callers read (early stopping uses
-results_dic[5][metric], Utils_.py:64); beyond-accuracy metrics of the reference (novelty,
-diversity, coverage) are out of scope.  Accumulation dtypes follow the reference (float32 sums
-inside precision/recall/AP/DCG) so results agree to the last digits with its evaluator."""
+"""Hold-out evaluation -- the consumer of the scores (protocol of Base/Evaluation/Evaluator.py:214-414 with the
+accuracy metrics of Base/Evaluation/metrics.py).  The GANMF callers read `results_dic[cutoff][metric]` (early stopping:
+cut-off 5, Utils_.py:64); the reference's beyond-accuracy metrics (novelty, diversity, coverage) are out of scope.
+
+Metric definitions (one user, a ranked list `L` cut at c, test items `T` with ratings `w`, hit flags `h_i = [L_i in T]`):
+  PRECISION = sum(h)/|L|      PRECISION_RECALL_MIN_DEN = sum(h)/min(|T|,|L|)      RECALL = sum(h)/|T|
+  HIT_RATE = sum(h)           MRR = 1/rank of the first hit        ARHR = sum_i h_i/i
+  MAP = sum_i h_i * (hits up to i)/i / min(|T|,|L|)
+  ROC_AUC = share of (hit, miss) pairs of the list ranked in the right order (1 when the list has no miss)
+  NDCG = DCG(L)/DCG(best |L| of T),  DCG = sum_i (2^{w_i}-1)/ln(i+1)
+  RMSE over the test items whose score is finite (seen items carry -inf and do not count)
+Every user contributes the same weight; values are means over the evaluated users; F1 is formed from the means.
+
+`RankedListMetrics` computes all of them for one list in one pass over the hit positions.  Where the reference's
+evaluator works in float32 (hit counts divided in float32, the DCG sums, and therefore its running sums) this one
+does too, so that the two agree to the last digits on the reference's golden outputs (tests/test_evaluator.py)."""
 import numpy as np
 import scipy.sparse as sps
 
 METRICS = ("ROC_AUC", "PRECISION", "PRECISION_RECALL_MIN_DEN", "RECALL", "MAP", "MRR", "NDCG", "F1",
            "HIT_RATE", "ARHR", "RMSE")
-
-
-def roc_auc(is_relevant):
-    ranks = np.arange(len(is_relevant))
-    pos_ranks = ranks[is_relevant]
-    neg_ranks = ranks[~is_relevant]
-    auc_score = 0.0
-    if len(neg_ranks) == 0:
-        return 1.0
-    if len(pos_ranks) > 0:
-        for pos_pred in pos_ranks:
-            auc_score += np.sum(pos_pred < neg_ranks, dtype=np.float32)
-        auc_score /= (pos_ranks.shape[0] * neg_ranks.shape[0])
-    return auc_score
-
-
-def precision(is_relevant):
-    if len(is_relevant) == 0:
-        return 0.0
-    return np.sum(is_relevant, dtype=np.float32) / len(is_relevant)
-
-
-def precision_recall_min_denominator(is_relevant, n_test_items):
-    if len(is_relevant) == 0:
-        return 0.0
-    return np.sum(is_relevant, dtype=np.float32) / min(n_test_items, len(is_relevant))
-
-
-def recall(is_relevant, pos_items):
-    return np.sum(is_relevant, dtype=np.float32) / pos_items.shape[0]
-
-
-def rr(is_relevant):
-    ranks = np.arange(1, len(is_relevant) + 1)[is_relevant]
-    return 1. / ranks[0] if len(ranks) > 0 else 0.0
-
-
-def arhr(is_relevant):
-    p_reciprocal = 1 / np.arange(1, len(is_relevant) + 1, 1.0, dtype=np.float64)
-    return is_relevant.dot(p_reciprocal)
-
-
-def average_precision(is_relevant, pos_items):
-    if len(is_relevant) == 0:
-        return 0.0
-    p_at_k = is_relevant * np.cumsum(is_relevant, dtype=np.float32) / (1 + np.arange(is_relevant.shape[0]))
-    return np.sum(p_at_k) / np.min([pos_items.shape[0], is_relevant.shape[0]])
-
-
-def dcg(scores):
-    return np.sum(np.divide(np.power(2, scores) - 1, np.log(np.arange(scores.shape[0], dtype=np.float32) + 2)),
-                  dtype=np.float32)
-
-
-def ndcg(ranked_list, pos_items, relevance=None, at=None):
-    if relevance is None:
-        relevance = np.ones_like(pos_items)
-    it2rel = {it: r for it, r in zip(pos_items, relevance)}
-    rank_scores = np.asarray([it2rel.get(it, 0.0) for it in ranked_list[:at]], dtype=np.float32)
-    ideal_dcg = dcg(np.sort(relevance)[::-1][:len(ranked_list)])
-    rank_dcg = dcg(rank_scores)
-    if rank_dcg == 0.0:
-        return 0.0
-    return rank_dcg / ideal_dcg
-
-
-def rmse(all_items_predicted_ratings, relevant_items, relevant_items_rating):
-    err = (all_items_predicted_ratings[relevant_items] - relevant_items_rating) ** 2
-    finite = np.isfinite(err)
-    if finite.sum() == 0:
-        return np.nan
-    return np.sqrt(np.sum(err[finite]) / finite.sum())
+_SUMMED = tuple(m for m in METRICS if m != "F1")
 
 
 def get_result_string(results_run, n_decimals=7):
-    out = ""
-    for cutoff, res in results_run.items():
-        out += "CUTOFF: {} - ".format(cutoff)
-        for metric, value in res.items():
-            out += "{}: {:.{n}f}, ".format(metric, value, n=n_decimals)
-        out += "\n"
-    return out
+    """'CUTOFF: c - NAME: value, NAME: value, \n' per cut-off, the line format the reference's drivers log."""
+    lines = []
+    for cutoff, per_metric in results_run.items():
+        fields = "".join("%s: %.*f, " % (name, n_decimals, value) for name, value in per_metric.items())
+        lines.append("CUTOFF: %s - %s\n" % (cutoff, fields))
+    return "".join(lines)
+
+
+class RankedListMetrics(object):
+    """Accuracy metrics of one user's ranked list against that user's test items.
+
+    `test_items` / `test_ratings`: the stored entries of the user's URM_test row.  `__call__(recommended, c)` returns a
+    dict over the metric names for the list cut at c."""
+
+    def __init__(self, test_items, test_ratings, max_cutoff):
+        order = np.argsort(test_items, kind="stable")
+        self._items = np.asarray(test_items)[order]
+        self._ratings = np.asarray(test_ratings)[order]
+        self.n_test = int(self._items.shape[0])
+        # DCG discounts ln(rank + 1), rank = 1..max_cutoff, and the user's best possible gains, both float32
+        self._ln_rank = np.log(np.arange(max_cutoff, dtype=np.float32) + 2)
+        best_first = np.sort(np.asarray(test_ratings))[::-1][:max_cutoff]
+        self._ideal_terms = (np.power(2, best_first.astype(np.float32)) - 1) / self._ln_rank[:best_first.shape[0]]
+
+    def match(self, recommended):
+        """(hit flags, rating of each hit else 0) for the ranked ids."""
+        recommended = np.asarray(recommended, dtype=self._items.dtype if self.n_test else np.int64)
+        if self.n_test == 0 or recommended.shape[0] == 0:
+            return np.zeros(recommended.shape[0], dtype=bool), np.zeros(recommended.shape[0], dtype=np.float32)
+        slot = np.minimum(np.searchsorted(self._items, recommended), self.n_test - 1)
+        hit = self._items[slot] == recommended
+        return hit, np.where(hit, self._ratings[slot], 0).astype(np.float32)
+
+    def __call__(self, hit, gain, c):
+        hit, gain = hit[:c], gain[:c]
+        n = int(hit.shape[0])
+        at = np.flatnonzero(hit)                       # 0-based ranks of the hits
+        n_hit = int(at.shape[0])
+        hits32 = np.float32(n_hit)
+        out = dict.fromkeys(_SUMMED, 0.0)
+        out["HIT_RATE"] = n_hit
+        out["RECALL"] = hits32 / self.n_test
+        if n:
+            out["PRECISION"] = hits32 / n
+            out["PRECISION_RECALL_MIN_DEN"] = hits32 / min(self.n_test, n)
+        n_miss = n - n_hit
+        if n_miss == 0:
+            out["ROC_AUC"] = 1.0
+        elif n_hit:
+            # misses ranked below hit j (the j-th hit at rank at[j]): the (n-1-at[j]) later entries minus the later hits
+            ordered_pairs = int(((n - 1 - at) - (n_hit - 1 - np.arange(n_hit))).sum())
+            out["ROC_AUC"] = np.float32(ordered_pairs) / (n_hit * n_miss)
+        if n_hit:
+            rank = at + 1.0
+            out["MRR"] = 1.0 / rank[0]
+            out["ARHR"] = float((1.0 / rank).sum())
+            precision_at_hit = np.arange(1, n_hit + 1, dtype=np.float32) / rank
+            out["MAP"] = precision_at_hit.sum() / min(self.n_test, n)
+            dcg = np.sum((np.power(2, gain) - 1) / self._ln_rank[:n], dtype=np.float32)
+            if dcg != 0.0:
+                out["NDCG"] = dcg / np.sum(self._ideal_terms[:n], dtype=np.float32)
+        return out
+
+
+def rmse_on_test_items(score_row, test_items, test_ratings):
+    """Root mean squared error over the test items with a finite score; NaN when there is none."""
+    sq = (score_row[test_items] - test_ratings) ** 2
+    usable = np.isfinite(sq)
+    count = usable.sum()
+    return np.sqrt(np.sum(sq[usable]) / count) if count else np.nan
+
+
+def _finish(sums, n_eval, cutoffs):
+    """Means over the evaluated users + F1 of the mean precision / recall (0 when both are 0)."""
+    results = {}
+    for c in cutoffs:
+        r = {name: sums[c][name] / n_eval for name in _SUMMED}
+        p, rc = r["PRECISION"], r["RECALL"]
+        r["F1"] = 2 * (p * rc) / (p + rc) if p + rc != 0 else 0.0
+        results[c] = r
+    return results
 
 
 class EvaluatorHoldout(object):
@@ -114,51 +128,33 @@ class EvaluatorHoldout(object):
         return self.URM_test.data[self.URM_test.indptr[user_id]:self.URM_test.indptr[user_id + 1]]
 
     def evaluateRecommender(self, recommender_object):
-        block_size = min(1000, int(1e8 / self.n_items))       # Evaluator.py:237-238
-        results = {c: {m: 0.0 for m in METRICS if m != "F1"} for c in self.cutoff_list}
-        n_eval = 0
-        users = self.usersToEvaluate
-        start = 0
-        while start < len(users):
-            end = min(start + block_size, len(users))
-            batch = np.array(users[start:end])
-            start = end
+        """(results[cutoff][metric], text).  Users are scored in blocks of min(1000, 1e8/n_items) through
+        `recommender.recommend(..., return_scores=True)` (Evaluator.py:237-277)."""
+        block_size = min(1000, int(1e8 / self.n_items))
+        sums = {c: dict.fromkeys(_SUMMED, 0.0) for c in self.cutoff_list}
+        users = np.asarray(self.usersToEvaluate, dtype=np.int64)
+        for lo in range(0, len(users), max(block_size, 1)):
+            batch = users[lo:lo + block_size]
             rec_lists, scores_batch = recommender_object.recommend(
                 batch, remove_seen_flag=self.exclude_seen, cutoff=self.max_cutoff, remove_top_pop_flag=False,
                 remove_CustomItems_flag=False, return_scores=True)
             assert len(rec_lists) == len(batch) and scores_batch.shape == (len(batch), self.n_items)
-            for bi in range(len(batch)):
-                user = batch[bi]
-                relevant = self.get_user_relevant_items(user)
-                ratings = self.get_user_test_ratings(user)
-                user_rmse = rmse(scores_batch[bi], relevant, ratings)
-                recommended = rec_lists[bi]
-                is_relevant = np.isin(recommended, relevant, assume_unique=True)
-                n_eval += 1
+            for user, recommended, score_row in zip(batch, rec_lists, scores_batch):
+                test_items, test_ratings = self.get_user_relevant_items(user), self.get_user_test_ratings(user)
+                scorer = RankedListMetrics(test_items, test_ratings, self.max_cutoff)
+                hit, gain = scorer.match(recommended)
+                user_rmse = rmse_on_test_items(score_row, test_items, test_ratings)
                 for c in self.cutoff_list:
-                    r = results[c]
-                    rel_c = is_relevant[0:c]
-                    rec_c = recommended[0:c]
-                    r["ROC_AUC"] += roc_auc(rel_c)
-                    r["PRECISION"] += precision(rel_c)
-                    r["PRECISION_RECALL_MIN_DEN"] += precision_recall_min_denominator(rel_c, len(relevant))
-                    r["RECALL"] += recall(rel_c, relevant)
-                    r["NDCG"] += ndcg(rec_c, relevant, relevance=ratings, at=c)
-                    r["HIT_RATE"] += rel_c.sum()
-                    r["ARHR"] += arhr(rel_c)
-                    r["RMSE"] += user_rmse
-                    r["MRR"] += rr(rel_c)
-                    r["MAP"] += average_precision(rel_c, relevant)
-        if n_eval > 0:
-            for c in self.cutoff_list:
-                r = results[c]
-                for key in list(r.keys()):
-                    r[key] = r[key] / n_eval
-                p, rc = r["PRECISION"], r["RECALL"]
-                if p + rc != 0:
-                    r["F1"] = 2 * (p * rc) / (p + rc)
-        else:
+                    acc = sums[c]
+                    for name, value in scorer(hit, gain, c).items():
+                        acc[name] += value
+                    acc["RMSE"] += user_rmse
+        n_eval = len(users)
+        if n_eval == 0:
             print("WARNING: No users had a sufficient number of relevant items")
+            results = {c: dict.fromkeys(METRICS, 0.0) for c in self.cutoff_list}
+        else:
+            results = _finish(sums, n_eval, self.cutoff_list)
         return results, get_result_string(results)
 
 
@@ -204,7 +200,7 @@ class EvaluatorHoldoutFast(EvaluatorHoldout):
     def evaluateRecommender(self, recommender_object):
         K = self.max_cutoff
         block_size = max(1, min(4096, int(1e8 / self.n_items)))
-        names = [m for m in METRICS if m != "F1"]
+        names = _SUMMED
         sums = {c: {m: 0.0 for m in names} for c in self.cutoff_list}
         n_eval = len(self._users)
         inv_rank = 1.0 / np.arange(1, K + 1, dtype=np.float64)
@@ -248,16 +244,12 @@ class EvaluatorHoldoutFast(EvaluatorHoldout):
                 r["MRR"] += np.where(hits > 0, inv_rank[first], 0.0).sum()
                 p_at_k = rel * np.cumsum(rel, axis=1) * inv_rank[:c]
                 r["MAP"] += np.where(len_c > 0, p_at_k.sum(axis=1) / np.maximum(np.minimum(n_test, len_c), 1.0), 0.0).sum()
-        results = {c: {} for c in self.cutoff_list}
         if n_eval > 0:
+            results = _finish(sums, n_eval, self.cutoff_list)
             for c in self.cutoff_list:
-                for m in names:
-                    results[c][m] = float(sums[c][m] / n_eval)
+                results[c] = {m: float(v) for m, v in results[c].items()}
                 results[c]["RMSE"] = float("nan")
-                p, rc = results[c]["PRECISION"], results[c]["RECALL"]
-                if p + rc != 0:
-                    results[c]["F1"] = 2 * (p * rc) / (p + rc)
         else:
-            results = {c: {m: 0.0 for m in names} for c in self.cutoff_list}
+            results = {c: dict.fromkeys(METRICS, 0.0) for c in self.cutoff_list}
             print("WARNING: No users had a sufficient number of relevant items")
         return results, get_result_string(results)

@@ -17,6 +17,7 @@ import json
 import multiprocessing as mp
 import os
 import pickle
+import queue
 import time
 from collections import OrderedDict
 
@@ -93,7 +94,7 @@ def run_trial(spec, params, device):
             "seconds": time.time() - t0}
 
 
-def _worker(spec, device, tasks, results):
+def _worker(spec, device, tasks, results, worker_id=0):
     try:
         if spec.get("visible_devices") is not None:      # one physical GPU per worker, seen as device 0
             os.environ["HIP_VISIBLE_DEVICES"] = str(spec["visible_devices"][device])
@@ -103,6 +104,7 @@ def _worker(spec, device, tasks, results):
             if item is None:
                 return
             idx, params = item
+            results.put(("start", worker_id, idx))        # lets the driver attribute a hard crash to this trial
             try:
                 out = run_trial(spec, params, device)
             except MemoryError as e:                      # the reference maps OOM to fitness 0 (RecSysExp.py:290-291)
@@ -110,7 +112,7 @@ def _worker(spec, device, tasks, results):
             except Exception as e:                        # a failed trial must not take the search down
                 out = {"fitness": 0.0, "fit_params": dict(params), "results_string": "trial failed: %r\n" % (e,), "seconds": 0.0,
                        "error": repr(e)}
-            results.put((idx, params, out))
+            results.put(("done", worker_id, idx, params, out))
     except KeyboardInterrupt:
         return
 
@@ -143,6 +145,8 @@ class TrialParallelTuner(object):
                      "visible_devices": self.devices if isolate_devices else None}
         self.x_iters, self.func_vals = [], []
         self.best_res, self.best_params = None, None
+        self.poll_seconds = 2.0      # how often the driver looks for dead workers while waiting for results
+        self.max_respawns = 16       # hard worker deaths tolerated before tune() raises
 
     # -- bookkeeping (results.txt / best_params.* / checkpoint.pkl as the reference leaves them)
     def _checkpoint_path(self):
@@ -202,12 +206,29 @@ class TrialParallelTuner(object):
         t_start = time.time()
         ctx = mp.get_context("spawn")             # never fork a process that has touched the GPU
         tasks, results = ctx.Queue(), ctx.Queue()
-        workers = [ctx.Process(target=_worker, args=(self.spec, i % len(self.devices) if self.spec["visible_devices"] is not None
-                                                       else self.devices[i % len(self.devices)], tasks, results), daemon=True)
-                   for i in range(self.n_workers)]
-        for w in workers:
+
+        def spawn(i):
+            dev = i % len(self.devices) if self.spec["visible_devices"] is not None else self.devices[i % len(self.devices)]
+            w = ctx.Process(target=_worker, args=(self.spec, dev, tasks, results, i), daemon=True)
             w.start()
+            return w
+
+        workers = {i: spawn(i) for i in range(self.n_workers)}
+        running = {}                              # worker id -> trial index it announced
         pending, issued, done = {}, len(self.func_vals), len(self.func_vals)
+        respawns = 0
+
+        def finish(idx, params, out):
+            nonlocal done
+            if pending.pop(idx, None) is None:
+                return                            # already recorded (a crash report raced the worker's own result)
+            self._record(params, out)
+            done += 1
+            if verbose:
+                print("trial %d/%d: %s@%d = %.6f in %.1f s%s" % (done, evals, self.metric, self.at, -out["fitness"],
+                                                                 out["seconds"], "  [%s]" % out["error"] if "error" in out else ""),
+                      flush=True)
+
         try:
             while done < evals:
                 while issued < evals and len(pending) < self.n_workers:
@@ -215,18 +236,43 @@ class TrialParallelTuner(object):
                     pending[issued] = params
                     tasks.put((issued, params))
                     issued += 1
-                idx, params, out = results.get()
-                pending.pop(idx, None)
-                self._record(params, out)
-                done += 1
-                if verbose:
-                    print("trial %d/%d: %s@%d = %.6f in %.1f s%s" % (done, evals, self.metric, self.at, -out["fitness"],
-                                                                     out["seconds"], "  [%s]" % out["error"] if "error" in out else ""),
-                          flush=True)
+                try:
+                    msg = results.get(timeout=self.poll_seconds)
+                except queue.Empty:
+                    msg = None
+                if msg is not None and msg[0] == "start":
+                    running[msg[1]] = msg[2]
+                    continue
+                if msg is not None:
+                    _, wid, idx, params, out = msg
+                    if running.get(wid) == idx:
+                        del running[wid]
+                    finish(idx, params, out)
+                    continue
+                # nothing arrived: a worker that died hard (HIP abort, GPU fault, OOM kill) never reports.  Its trial
+                # is recorded as failed with fitness 0 (what the reference does for an out-of-memory trial,
+                # RecSysExp.py:290-291) and a fresh child process takes its place.
+                for wid, w in list(workers.items()):
+                    if w.is_alive():
+                        continue
+                    idx = running.pop(wid, None)
+                    if idx is not None and idx in pending:
+                        p_dead = pending[idx]
+                        finish(idx, p_dead, {"fitness": 0.0, "fit_params": dict(p_dead), "seconds": 0.0,
+                                             "results_string": "worker %d died (exit code %s)\n" % (wid, w.exitcode),
+                                             "error": "worker died, exit code %s" % w.exitcode})
+                    respawns += 1
+                    if respawns > self.max_respawns:
+                        raise RuntimeError("TrialParallelTuner: %d worker processes died; giving up" % respawns)
+                    workers[wid] = spawn(wid)
+                if not running and pending and all(w.is_alive() for w in workers.values()) and tasks.empty():
+                    # a worker died between taking a task and announcing it: re-issue what nobody is running
+                    for idx, params in pending.items():
+                        tasks.put((idx, params))
         finally:
             for _ in workers:
                 tasks.put(None)
-            for w in workers:
+            for w in workers.values():
                 w.join(timeout=30)
                 if w.is_alive():
                     w.terminate()

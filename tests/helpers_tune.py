@@ -31,3 +31,14 @@ class StubGAN(BaseRecommender):
         pop = np.asarray(self.URM_train.sum(axis=0)).ravel().astype(np.float32)
         noise = rng.rand(len(user_id_array), self.n_items).astype(np.float32) * pop.max()
         return self.quality * pop[None, :] + (1 - self.quality) * noise
+
+
+class CrashingGAN(StubGAN):
+    """Dies the way a HIP abort / GPU fault / OOM kill does -- no Python exception, the process is gone -- on every
+    trial whose num_factors is a multiple of 5."""
+
+    def fit(self, **kw):
+        if kw.get("num_factors", 10) % 5 == 0:
+            import os
+            os._exit(134)
+        return super().fit(**kw)

@@ -117,3 +117,18 @@ def test_early_stopping_protocol():
         es(ep)
     # improvements at epochs 1, 2; worse (<=) at 3, 4 -> counter 2 -> 0; epoch 5 worse with none left -> stop + restore
     assert (m.saved, m.stopped, m.loaded) == (2, 1, 1)
+
+
+def test_all_miss_recommender_scores_zero_f1():
+    """A recommender that never hits: every accuracy metric is 0 and the F1 key exists (the reference's empty
+    metrics dict keeps F1 = 0.0), so early stopping on 'F1' does not raise."""
+    from ganmf_amd.evaluation import EvaluatorHoldoutFast
+    n_users, n_items = 9, 20
+    test = sps.csr_matrix((np.ones(n_users, dtype=np.float32), (np.arange(n_users), np.zeros(n_users, dtype=int))),
+                          shape=(n_users, n_items))
+    train = sps.csr_matrix((n_users, n_items), dtype=np.float32)
+    # item 0 (the only test item) always gets the lowest score -> never inside the top 5
+    rec = _Factors(train, np.ones((n_users, 1), dtype=np.float32), np.arange(n_items, dtype=np.float32)[:, None])
+    for cls in (EvaluatorHoldout, EvaluatorHoldoutFast):
+        res, _ = cls(test, [5]).evaluateRecommender(rec)
+        assert res[5]["F1"] == 0.0 and res[5]["MAP"] == 0.0 and res[5]["PRECISION"] == 0.0, (cls, res)

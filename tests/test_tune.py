@@ -94,3 +94,26 @@ def test_failed_and_oom_trials_score_zero(tmp_path, monkeypatch):
     params["num_factors"] = 12
     out = tune.run_trial(spec_tuner.spec, params, 0)
     assert out["fitness"] <= 0 and out["fit_params"]["epochs"] == 40 + (12 % 7) * 5 - 25
+
+
+def test_search_survives_hard_worker_death(tmp_path, monkeypatch):
+    """A worker that dies without raising (os._exit stands in for a HIP abort / OOM kill): its trial is recorded as
+    failed with fitness 0, a fresh child takes its place and the search finishes instead of hanging."""
+    monkeypatch.setenv("PYTHONPATH", HERE + os.pathsep + os.path.dirname(HERE) + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    sys.path.insert(0, HERE)
+    from helpers_tune import CrashingGAN
+    from ganmf_amd.evaluation import EvaluatorHoldoutFast
+    train, early, val = _data(2)
+    logs = str(tmp_path / "crash")
+    t = tune.TrialParallelTuner(CrashingGAN, train, early, val, logs, seed=11, method="random", n_workers=2, devices=[0],
+                                evaluator_class=EvaluatorHoldoutFast)
+    t.poll_seconds = 0.2
+    t.max_respawns = 64
+    best, _ = t.tune(evals=12, verbose=False)
+    assert len(t.func_vals) == 12
+    crashed = [x for x in t.x_iters if x["num_factors"] % 5 == 0]
+    assert crashed, "the seed must draw at least one crashing trial for this test to mean anything"
+    for x, f in zip(t.x_iters, t.func_vals):
+        assert (f == 0.0) == (x["num_factors"] % 5 == 0 or x["num_factors"] == 13), (x, f)
+    assert open(os.path.join(logs, "results.txt")).read().count("died (exit code 134)") == len(crashed)
+    assert best < 0
