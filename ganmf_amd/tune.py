@@ -205,29 +205,50 @@ class TrialParallelTuner(object):
             [d.sample(rng) for d in self.dims]
         t_start = time.time()
         ctx = mp.get_context("spawn")             # never fork a process that has touched the GPU
-        tasks, results = ctx.Queue(), ctx.Queue()
+        # results travel on a SimpleQueue: its put() writes to the pipe before returning (a Queue hands the item to a
+        # feeder thread, and a worker that dies right after announcing a trial would take the announcement with it)
+        tasks, results = ctx.Queue(), ctx.SimpleQueue()
+        workers, reaped, running = {}, set(), {}      # worker id -> process; ids of dead workers; worker id -> trial index
+        next_wid = [0]
 
-        def spawn(i):
-            dev = i % len(self.devices) if self.spec["visible_devices"] is not None else self.devices[i % len(self.devices)]
-            w = ctx.Process(target=_worker, args=(self.spec, dev, tasks, results, i), daemon=True)
-            w.start()
-            return w
+        def spawn():
+            wid = next_wid[0]
+            next_wid[0] += 1
+            slot = wid % len(self.devices)
+            dev = slot if self.spec["visible_devices"] is not None else self.devices[slot]
+            workers[wid] = ctx.Process(target=_worker, args=(self.spec, dev, tasks, results, wid), daemon=True)
+            workers[wid].start()
 
-        workers = {i: spawn(i) for i in range(self.n_workers)}
-        running = {}                              # worker id -> trial index it announced
+        for _ in range(self.n_workers):
+            spawn()
         pending, issued, done = {}, len(self.func_vals), len(self.func_vals)
-        respawns = 0
+        idle_polls = 0
 
         def finish(idx, params, out):
             nonlocal done
             if pending.pop(idx, None) is None:
-                return                            # already recorded (a crash report raced the worker's own result)
+                return                            # already recorded (a re-issued trial can report twice)
             self._record(params, out)
             done += 1
             if verbose:
                 print("trial %d/%d: %s@%d = %.6f in %.1f s%s" % (done, evals, self.metric, self.at, -out["fitness"],
                                                                  out["seconds"], "  [%s]" % out["error"] if "error" in out else ""),
                       flush=True)
+
+        def crashed(idx, wid, exitcode):
+            if idx in pending:
+                p_dead = pending[idx]
+                finish(idx, p_dead, {"fitness": 0.0, "fit_params": dict(p_dead), "seconds": 0.0,
+                                     "results_string": "worker %d died (exit code %s)\n" % (wid, exitcode),
+                                     "error": "worker died, exit code %s" % exitcode})
+
+        def next_message():
+            deadline = time.time() + self.poll_seconds
+            while results.empty():
+                if time.time() >= deadline:
+                    return None
+                time.sleep(0.02)
+            return results.get()
 
         try:
             while done < evals:
@@ -236,39 +257,43 @@ class TrialParallelTuner(object):
                     pending[issued] = params
                     tasks.put((issued, params))
                     issued += 1
-                try:
-                    msg = results.get(timeout=self.poll_seconds)
-                except queue.Empty:
-                    msg = None
+                msg = next_message()
                 if msg is not None and msg[0] == "start":
-                    running[msg[1]] = msg[2]
+                    _, wid, idx = msg
+                    if wid in reaped:             # announced, died and was replaced before the announcement was read
+                        crashed(idx, wid, "unknown")
+                    else:
+                        running[wid] = idx
+                    idle_polls = 0
                     continue
                 if msg is not None:
                     _, wid, idx, params, out = msg
                     if running.get(wid) == idx:
                         del running[wid]
                     finish(idx, params, out)
+                    idle_polls = 0
                     continue
-                # nothing arrived: a worker that died hard (HIP abort, GPU fault, OOM kill) never reports.  Its trial
-                # is recorded as failed with fitness 0 (what the reference does for an out-of-memory trial,
-                # RecSysExp.py:290-291) and a fresh child process takes its place.
+                # Nothing arrived for poll_seconds.  A worker that died hard (HIP abort, GPU fault, OOM kill) never
+                # reports: the trial it announced is recorded as failed with fitness 0 (what the reference does for an
+                # out-of-memory trial, RecSysExp.py:290-291) and a fresh child process takes its place.
                 for wid, w in list(workers.items()):
                     if w.is_alive():
                         continue
-                    idx = running.pop(wid, None)
-                    if idx is not None and idx in pending:
-                        p_dead = pending[idx]
-                        finish(idx, p_dead, {"fitness": 0.0, "fit_params": dict(p_dead), "seconds": 0.0,
-                                             "results_string": "worker %d died (exit code %s)\n" % (wid, w.exitcode),
-                                             "error": "worker died, exit code %s" % w.exitcode})
-                    respawns += 1
-                    if respawns > self.max_respawns:
-                        raise RuntimeError("TrialParallelTuner: %d worker processes died; giving up" % respawns)
-                    workers[wid] = spawn(wid)
-                if not running and pending and all(w.is_alive() for w in workers.values()) and tasks.empty():
-                    # a worker died between taking a task and announcing it: re-issue what nobody is running
-                    for idx, params in pending.items():
-                        tasks.put((idx, params))
+                    del workers[wid]
+                    reaped.add(wid)
+                    if wid in running:
+                        crashed(running.pop(wid), wid, w.exitcode)
+                    if len(reaped) > self.max_respawns:
+                        raise RuntimeError("TrialParallelTuner: %d worker processes died; giving up" % len(reaped))
+                    spawn()
+                # safety net: a trial nobody announced and nobody holds (its worker died between taking the task and
+                # announcing it) is issued again; a duplicate result is ignored by finish()
+                orphans = [i for i in pending if i not in running.values()]
+                idle_polls = idle_polls + 1 if (orphans and tasks.empty()) else 0
+                if idle_polls >= 3:
+                    for i in orphans:
+                        tasks.put((i, pending[i]))
+                    idle_polls = 0
         finally:
             for _ in workers:
                 tasks.put(None)

@@ -2,7 +2,7 @@
 # Profiles the default bench run on the GPU box; usage: tools/profile_round.sh [tag]   (outputs in gpurun_out/<tag>)
 set -eux
 R="$(cd "$(dirname "$0")/.." && pwd)"
-test -f ""$R"/bench.py"
+test -f "$R/bench.py"
 TAG="${1:-r02}"
 O="$R/gpurun_out/$TAG"
 cd /tmp && export TMPDIR=/tmp
