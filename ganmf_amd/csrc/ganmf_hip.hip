@@ -34,6 +34,7 @@
 #include "../../include/ganmf_hip.h"
 #include "gemm_f32.hpp"
 #include "gemm_bf16s.hpp"
+#include "gemm_persist.hpp"
 #include "kernels.hpp"
 
 using namespace ganmf;
@@ -377,8 +378,9 @@ int run_gemm(ganmf_handle* h, int tag_gemm, int tag_red, GemmP g, bool akm, bool
   if (g.nbatch < 1) g.nbatch = 1;
   g.zero_page = h->zero_page;
   hipStream_t st = lane ? h->st2 : h->st;
-  const GemmPlan pl = gemm_plan(g.M, g.N, g.K, g.nbatch, g.epi.sq_partials != nullptr, force ? *force : h->tune,
-                                g.epi.kind == EPI_ADAM);
+  const GemmTune& tn = force ? *force : h->tune;
+  GemmPlan pl = gemm_plan(g.M, g.N, g.K, g.nbatch, g.epi.sq_partials != nullptr, tn, g.epi.kind == EPI_ADAM);
+  pl.persist = gemm_persist_eligible(g, akm, bkm, pl, tn.persist) ? (tn.persist >= 2 ? tn.persist : 1) : 0;
   if (pl.nsplit > 1) TRY(ensure_slab(h, gemm_slab_elems(pl, g.M, g.ldc, g.nbatch), lane));
   float* slab = lane ? h->slab2 : h->slab;
   const size_t slab_elems = lane ? h->slab2_elems : h->slab_elems;
@@ -397,7 +399,8 @@ int run_gemm(ganmf_handle* h, int tag_gemm, int tag_red, GemmP g, bool akm, bool
       fprintf(stderr, "[ganmf plan] %-28s M=%d N=%d K=%d batch=%d -> tile %d ring %d nsplit %d (kps %d) mfma %s wgs %d est %.1f us%s\n",
               kTagName[tag_gemm], g.M, g.N, g.K, g.nbatch, pl.tile, pl.ring, pl.nsplit, pl.kps,
               pl.mode == MFMA_BF16X3 ? "bf16x3" : pl.mode == MFMA_BF16 ? "bf16" : "f32",
-              pl.tiles_m * pl.tiles_n * pl.nsplit * g.nbatch, pl.est_us, in_launch ? " (in-launch reduce)" : "");
+              pl.tiles_m * pl.tiles_n * pl.nsplit * g.nbatch, pl.est_us,
+              pl.persist ? " (persistent tile walk)" : in_launch ? " (in-launch reduce)" : "");
     }
   }
   const double fl = g.nbatch * gemm_flops(g.M, g.N, g.K), by = gemm_bytes((double)g.nbatch * g.M, g.N, g.K) + extra_bytes;
@@ -1020,6 +1023,7 @@ static int create_impl(const ganmf_cfg* cfg, ganmf_handle* h) {
   if (h->tune.ring != 0 && h->tune.ring != 2 && h->tune.ring != 3 && h->tune.ring != 4) h->tune.ring = 0;
   h->tune.nsplit = std::max(0, env_int("GANMF_NSPLIT", 0));
   h->tune.mode = env_mfma_mode((cfg->flags & GANMF_FLAG_MFMA_BF16) ? MFMA_BF16 : (cfg->flags & GANMF_FLAG_MFMA_F32) ? MFMA_F32 : MFMA_DEFAULT);
+  h->tune.persist = env_int("GANMF_PERSIST", -1);
   h->debug_plan = env_int("GANMF_DEBUG_PLAN", 0) != 0;
   h->fused_mode = env_int("GANMF_FUSED_X3", 1) ? MFMA_BF16X3 : MFMA_F32;
   HIP_TRY(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
@@ -1368,7 +1372,7 @@ static int scores_device(ganmf_handle* h, const int* ids_dev, int64_t n, int tra
   HIP_TRY(hipGetLastError());
   GemmP g{};
   g.A = h->sc_rows; g.lda = h->ldk; g.B = colsT.p; g.ldb = h->ldk;
-  g.C = h->sc_out; g.ldc = ldw; g.M = (int)n; g.N = W; g.K = h->k; g.epi.kind = EPI_STORE;
+  g.C = h->sc_out; g.ldc = ldw; g.M = (int)n; g.N = W; g.K = h->k; g.epi.kind = EPI_STORE; g.c_pad_writable = 1;
   TRY(run_gemm(h, T_SCORE_GEMM, T_RED_SCORE, g, false, false));
   *out_dev = h->sc_out; *width = W; *ld_out = ldw;
   return 0;
@@ -1490,7 +1494,7 @@ int ganmf_bench_scores(ganmf_handle* h, int64_t n, int transposed, int32_t iters
   Tensor& colsT = transposed ? h->Ue : h->V;
   GemmP g{};
   g.A = h->sc_rows; g.lda = h->ldk; g.B = colsT.p; g.ldb = h->ldk;
-  g.C = h->sc_out; g.ldc = ldw; g.M = (int)n; g.N = W; g.K = h->k; g.epi.kind = EPI_STORE;
+  g.C = h->sc_out; g.ldc = ldw; g.M = (int)n; g.N = W; g.K = h->k; g.epi.kind = EPI_STORE; g.c_pad_writable = 1;
   hipEvent_t a, b;
   hipEventCreate(&a); hipEventCreate(&b);
   const bool was = h->prof;
@@ -1574,13 +1578,15 @@ int ganmf_gemm_f32(int device, const float* A, const float* B, float* C, int64_t
   HIP_TRY(hipMemcpy2D(dB, (size_t)ldb * 4, B, (size_t)bc * 4, (size_t)bc * 4, br, hipMemcpyHostToDevice));
   GemmP g{};
   g.A = dA; g.lda = lda; g.B = dB; g.ldb = ldb; g.C = dC; g.ldc = ldc;
-  g.M = (int)M; g.N = (int)N; g.K = (int)K; g.nbatch = 1; g.epi.kind = EPI_STORE; g.zero_page = zp;
+  g.M = (int)M; g.N = (int)N; g.K = (int)K; g.nbatch = 1; g.epi.kind = EPI_STORE; g.zero_page = zp; g.c_pad_writable = 1;
   GemmTune tune;
   tune.tile = tile; tune.nsplit = nsplit;
   tune.mode = env_mfma_mode(MFMA_DEFAULT);
   tune.ring = env_int("GANMF_RING", 0);
   if (tune.ring != 0 && tune.ring != 2 && tune.ring != 3 && tune.ring != 4) tune.ring = 0;
-  const GemmPlan pl = gemm_plan(g.M, g.N, g.K, 1, false, tune);
+  tune.persist = env_int("GANMF_PERSIST", -1);
+  GemmPlan pl = gemm_plan(g.M, g.N, g.K, 1, false, tune);
+  pl.persist = gemm_persist_eligible(g, a_kmajor, b_kmajor, pl, tune.persist) ? (tune.persist >= 2 ? tune.persist : 1) : 0;
   const size_t slab_elems = gemm_slab_elems(pl, g.M, ldc, 1);
   if (slab_elems) TRY(dalloc(&slab, slab_elems));
   unsigned* counters = nullptr;

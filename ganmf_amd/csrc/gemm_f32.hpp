@@ -205,19 +205,20 @@ struct GemmP {
   unsigned* counters;      // [nbatch * tiles]; zero between launches (the reducer re-zeroes its word)
   float* Cf;               // final output [M, ldc] per batch
   long long cf_batch_stride;
+  int c_pad_writable;           // columns N .. ldc-1 of C hold nothing the caller needs (gemm_persist.hpp writes zeros there)
 };
 
 #define GANMF_WAIT_VMCNT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
 
-// One operand's share of a K-tile: R rows (M or N side) x BK k's, staged by 256 threads.
-template <int R, int BK, bool KM>
+// One operand's share of a K-tile: R rows (M or N side) x BK k's, staged by NTHR threads.
+template <int R, int BK, bool KM, int NTHR = 256>
 struct Stage {
   static constexpr int F4 = R * BK / 4;          // float4 per tile
-  static constexpr int NP = F4 / 256;            // glds per thread per tile
+  static constexpr int NP = F4 / NTHR;           // glds per thread per tile
   static constexpr int SZ = R * BK;              // floats in LDS (unpadded)
   static constexpr int S = BK / 4;               // K-contig: 16-byte slots per row
   static constexpr int RC4 = R / 4;              // K-major: 16-byte slots per k-row
-  static_assert(F4 % 256 == 0 && NP >= 1, "tile too small for 256 threads");
+  static_assert(F4 % NTHR == 0 && NP >= 1, "tile too small for the workgroup");
   static_assert(BK == 32 || BK == 64, "BK must be 32 or 64");
 
   // rows that share a 64-dword LDS bank row differ in bit 0 (BK=32) or not at all (BK=64)
@@ -233,7 +234,7 @@ struct Stage {
     zp = zero;
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
-      const int pos = j * 256 + tid;
+      const int pos = j * NTHR + tid;
       if constexpr (!KM) {
         const int row = pos / S, slot = pos % S;
         const int c4 = slot ^ swz(row);
@@ -262,8 +263,36 @@ struct Stage {
       ptr[J] += (size_t)BK * ld;
     }
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)(s + (J * 256 + wave * 64) * 4),
+                                     (__attribute__((address_space(3))) void*)(s + (J * NTHR + wave * 64) * 4),
                                      16, 0, 0);
+  }
+  // The same piece issued from inline asm (recipe: cdna guide, inline-asm section, `glds16_asm`).  hipcc models the
+  // builtin as a FLAT instruction that may touch both VMEM and LDS; while one is pending, every lgkmcnt dependency is
+  // waited for with lgkmcnt(0) (SIInsertWaitcnts "pending flat"), so the double-buffered fragment reads of the K loop lose
+  // their lead: the reads issued for the NEXT chunk are waited for before THIS chunk's MFMAs.  An asm statement is
+  // invisible to that pass: fragment waits become counted again; the vmcnt side is counted by hand in these kernels anyway.
+  template <int J>
+  __device__ inline void issue_piece_asm(float* s, int ld, int kleft, int wave) {
+    const float* src;
+    if constexpr (!KM) {
+      src = kleft > 0 ? ptr[J] : zp;
+      ptr[J] += aux[J];
+    } else {
+      src = (aux[J] >= 0 && aux[J] < kleft) ? ptr[J] : zp;
+      ptr[J] += (size_t)BK * ld;
+    }
+    const unsigned dst = __builtin_amdgcn_readfirstlane(
+        (unsigned)(size_t)(__attribute__((address_space(3))) void*)(s + (J * NTHR + wave * 64) * 4));
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+  }
+  template <int J0, int J1>
+  __device__ inline void issue_range_asm(float* s, int ld, int kleft, int wave) {
+    if constexpr (J0 < J1) {
+      issue_piece_asm<J0>(s, ld, kleft, wave);
+      issue_range_asm<J0 + 1, J1>(s, ld, kleft, wave);
+    }
   }
   template <int J0, int J1>
   __device__ inline void issue_range(float* s, int ld, int kleft, int wave) {
@@ -646,6 +675,7 @@ struct GemmPlan {
   int tile = 128, ring = 2, nsplit = 1, kps = 0;
   int mode = MFMA_F32;       // MfmaMode of the K loop
   int tiles_m = 0, tiles_n = 0;
+  int persist = 0;           // 1: gemm_persist.hpp (one workgroup per CU walks a list of output tiles)
   int sq_count = 0;          // sq partial entries per batch this plan produces
   double est_us = 0;
 };
@@ -653,6 +683,7 @@ struct GemmPlan {
 struct GemmTune {            // overrides (0 = automatic), settable from the environment
   int tile = 0, ring = 0, nsplit = 0;
   int mode = MFMA_AUTO;      // MfmaMode of every plan; MFMA_AUTO: chosen per GEMM by gemm_plan
+  int persist = -1;          // persistent tile-walking kernel: -1 automatic, 0 never, 1 whenever the GEMM is eligible
 };
 
 inline void split_plan(int K, int want, int& nsplit, int& kps) {
@@ -762,7 +793,10 @@ inline hipError_t gemm_run(hipStream_t st, GemmP p, bool akm, bool bkm, const Ge
 // staged bf16 kernels (gemm_bf16s.hpp, included by the translation unit after this header)
 inline hipError_t gemm_dispatch_staged(hipStream_t st, const GemmP& p, bool akm, bool bkm, const GemmPlan& pl);
 
+inline hipError_t gemm_dispatch_persist(hipStream_t st, const GemmP& p, bool akm, bool bkm, const GemmPlan& pl);
+
 inline hipError_t gemm_dispatch(hipStream_t st, const GemmP& p, bool akm, bool bkm, const GemmPlan& pl) {
+  if (pl.persist) return gemm_dispatch_persist(st, p, akm, bkm, pl);
   if (pl.mode == MFMA_BF16 || pl.mode == MFMA_BF16X3) return gemm_dispatch_staged(st, p, akm, bkm, pl);
   if (pl.tile == 128) return pl.ring >= 3 ? gemm_launch_t<128, 128, 32, 3>(st, p, akm, bkm) : gemm_launch_t<128, 128, 32, 2>(st, p, akm, bkm);
   if (pl.ring == 4) return gemm_launch_t<64, 64, 64, 4>(st, p, akm, bkm);   // 128 KiB ring: three K-tiles (96 KiB) in flight

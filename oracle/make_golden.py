@@ -231,6 +231,39 @@ def statistical_fixture():
         print("statistical fixture DisGANMF ML-1M %s: published MAP@5 =" % mode, pub[5]["MAP"])
 
 
+def trial_logs():
+    """The reference's own hyper-parameter search logs as known answers for the training path + the trial objective
+    (RecSysExp.py:246-311): experiments/{GANMF,DisGANMF}_{user,item}_1M/results.txt hold 50 trials each as
+    {fit parameters as JSON}\n{metric line of the validation evaluation}.  `epochs` in a logged line is the
+    early-stop-corrected value `last_epoch - allow_worse*freq` (RecSysExp.py:272-276; 300 when early stopping never fired).
+    Data only: the parameter dicts, the metrics @5 and the three splits a trial reads (train_small / early_stop /
+    validation)."""
+    import re
+    for split in ("train_small", "early_stop", "validation"):
+        shutil.copyfile(os.path.join(REF, "experiments/datasets/Movielens1M_URM_%s.npz" % split),
+                        os.path.join(OUT, "Movielens1M_URM_%s.npz" % split))
+    keep = ("MAP", "NDCG", "PRECISION", "RECALL", "MRR", "HIT_RATE", "ROC_AUC", "F1", "ARHR")
+    out = {}
+    for model in ("GANMF", "DisGANMF"):
+        for mode in ("user", "item"):
+            lines = open(os.path.join(REF, "experiments/%s_%s_1M/results.txt" % (model, mode))).read().split("\n")
+            trials = []
+            for i, line in enumerate(lines):
+                if not line.startswith("{"):
+                    continue
+                m = re.match(r"CUTOFF: 5 - (.*)", lines[i + 1])
+                metrics = dict(f.split(": ") for f in m.group(1).strip().rstrip(",").split(", "))
+                trials.append({"params": json.loads(line), "validation_at5": {k: float(metrics[k]) for k in keep}})
+            assert len(trials) == 50
+            best = json.load(open(os.path.join(REF, "experiments/%s_%s_1M/best_params.txt" % (model, mode))))
+            out["%s_%s_1M" % (model, mode)] = {"trials": trials, "best_params": best}
+            print("trial log %s %s: 50 trials, logged MAP@5 in [%.4f, %.4f]" % (
+                model, mode, min(t["validation_at5"]["MAP"] for t in trials), max(t["validation_at5"]["MAP"] for t in trials)))
+    json.dump({"source": "experiments/<model>_<mode>_1M/results.txt", "early_stopping": {"allow_worse": 5, "freq": 5},
+               "metric": "MAP", "at": 5, "experiments": out},
+              open(os.path.join(OUT, "trial_logs_ml1m.json"), "w"), indent=0)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     BR, EH = _import_reference()
@@ -239,3 +272,4 @@ if __name__ == "__main__":
     evaluator_golden(BR, EH)
     tiny_trajectories()
     statistical_fixture()
+    trial_logs()

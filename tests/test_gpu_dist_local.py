@@ -125,6 +125,57 @@ def test_disganmf_sharded_epoch_equals_union_batch():
         eng.close()
 
 
+@pytest.mark.slow
+def test_c4_width_world8_step_equals_union_batch():
+    """BASELINE configs[3] geometry as a MULTI-RANK run: 50 000 items, k = 250, emb_dim = 1024, B = 128 per rank, users
+    sharded over 8 ranks (ragged: 1000 users -> 125 rows per rank, so the global batch is 1000 rows and every scale uses
+    it), one discriminator + one generator update through the library's data-parallel path on the loopback communicator
+    (world 8 on one GPU), against the single-process oracle on the union batch.  Replicated tensors must be bitwise
+    identical on all 8 ranks."""
+    from ganmf_amd.engine import Engine
+    world, U, N, k, e, B = 8, 1000, 50000, 250, 1024, 128
+    rng = np.random.RandomState(4)
+    nnz_per_row = 500                                   # 1 % density (SURVEY 8d: C4)
+    cols = np.concatenate([rng.choice(N, nnz_per_row, replace=False) for _ in range(U)])
+    rows = np.repeat(np.arange(U), nnz_per_row)
+    urm = sps.csr_matrix((np.ones(len(cols), np.float32), (rows, cols)), shape=(U, N))
+    hp = dict(d_lr=1e-4, g_lr=1e-3, d_reg=1e-5, g_reg=0.0, m=10.0, recon_coefficient=0.2)
+    o = GANMFOracle(U, N, k, e, dtype=np.float64, seed=5, **hp)
+    p0 = o.get_params()
+    bounds = shard_bounds(U, world)
+    perms = [rng.permutation(b - a) for a, b in bounds]
+
+    def make_engine(r):
+        lo, hi = bounds[r]
+        eng = Engine(hi - lo, N, k, e, B, world_size=world, rank=r, row_offset=lo, **hp)
+        eng.set_urm(urm[lo:hi])
+        for n, tid in (("We", 0), ("be", 1), ("Wd", 2), ("bd", 3), ("V", 101)):
+            eng.set_tensor(tid, p0[n])
+        eng.set_tensor(100, p0["U"][lo:hi])
+        return eng
+
+    engines, out, steps = _run_ranks(world, make_engine, bounds, perms, B, group=808)
+    assert steps == 1
+    union = np.concatenate([bounds[r][0] + perms[r][:B] for r in range(world)])
+    X = urm[union].toarray()
+    dl_ref, gl_ref = o.d_step(union, X), o.g_step(union, X)
+    for r in range(world):
+        np.testing.assert_allclose(out[r][0], [dl_ref], rtol=1e-4, atol=1e-7)
+        np.testing.assert_allclose(out[r][1], [gl_ref], rtol=1e-4, atol=1e-7)
+    for n, tid in (("We", 0), ("be", 1), ("Wd", 2), ("bd", 3), ("V", 101)):
+        t0 = engines[0].get_tensor(tid)
+        # one Adam step moves every element by ~lr whatever the gradient: compare the UPDATE, normalised by its own scale
+        upd, upd_ref = t0.astype(np.float64).reshape(p0[n].shape) - p0[n], o.p[n] - p0[n]
+        assert np.max(np.abs(upd - upd_ref)) <= 2e-3 * np.max(np.abs(upd_ref)) + 1e-12, n
+        assert _err(t0, o.p[n]) <= 1e-4, n
+        for r in range(1, world):
+            assert np.array_equal(engines[r].get_tensor(tid), t0), (n, r)
+    for r, (lo, hi) in enumerate(bounds):
+        assert _err(engines[r].get_tensor(100), o.p["U"][lo:hi]) <= 1e-4, r
+    for eng in engines:
+        eng.close()
+
+
 def test_local_group_errors():
     from ganmf_amd import _lib as L
     from ganmf_amd.engine import Engine

@@ -64,3 +64,23 @@ def test_gemm_deterministic():
     o1, _ = gemm_f32(A, B, False, True, nsplit=8)
     o2, _ = gemm_f32(A, B, False, True, nsplit=8)
     np.testing.assert_array_equal(o1, o2)
+
+
+@pytest.mark.parametrize("shape", [(128, 128, 32), (1, 1, 1), (700, 900, 250), (1300, 1500, 70), (3000, 260, 33),
+                                   (129, 4100, 250), (5000, 131, 8)])
+@pytest.mark.parametrize("waves", ["1", "2", "3"])  # GANMF_PERSIST: 1 = two 4-wave workgroups per CU (default), 2 / 3 = one 4- / 8-wave workgroup
+def test_gemm_persistent_tile_walk(shape, waves, monkeypatch):
+    """gemm_persist.hpp (one workgroup per CU walks a list of output tiles, stores deferred under the next tile's
+    K loop) against fp64 and, bit for bit, against the one-tile-per-workgroup kernel: same K order, same MFMA chain."""
+    from ganmf_amd.engine import gemm_f32
+    M, N, K = shape
+    rng = np.random.RandomState(M + 3 * N + 7 * K)
+    A, B, ref, bound = _mk(rng, M, N, K, False, False)
+    monkeypatch.setenv("GANMF_MFMA", "f32")
+    monkeypatch.setenv("GANMF_PERSIST", waves)
+    out, _ = gemm_f32(A, B, False, False, tile=128)
+    err = np.abs(out - ref)
+    assert np.all(err <= 4e-7 * bound * np.sqrt(K) + 1e-30), float((err / (bound + 1e-30)).max())
+    monkeypatch.setenv("GANMF_PERSIST", "0")
+    plain, _ = gemm_f32(A, B, False, False, tile=128)
+    np.testing.assert_array_equal(out, plain)

@@ -72,27 +72,74 @@ def test_lastfm_hetrec_full_training_reaches_published_map(golden_dir, case):
 @pytest.mark.parametrize("mode", ["user", "item"])
 def test_disganmf_ml1m_full_training(golden_dir, mode):
     """BASELINE configs[4]: DisGANMF on ML-1M with the reference's tuned hyper-parameters
-    (experiments/DisGANMF_{user,item}_1M/best_params.txt) vs test_results/DisGANMF_*_1M/test_results.txt:1.
+    (experiments/DisGANMF_{user,item}_1M/best_params.txt) vs test_results/DisGANMF_*_1M/test_results.txt:1, as a
+    DISTRIBUTION over eight initialisations instead of one seed inside a wide band.
+
     The binary-discriminator GAN is far more init-sensitive than GANMF (its generator *minimises* loss_fake as the
-    reference writes it, DisGANMF.py:132-136) and the published row is the run the epoch count was early-stopped
-    on: over seeds 1-5 and 1337 this build gives MAP@5 0.118-0.149 (user, published 0.148) and 0.176-0.196 (item,
-    published 0.2075), so the band is +-0.035 and the seed is fixed."""
+    reference writes it, DisGANMF.py:132-136; the raw float(uid) column drives layer 0 with inputs up to 6040).  The
+    numpy oracle shows the same spread (oracle/run_end_to_end.py: 0.1353 at seed 1337; SURVEY F12's probe 0.1509 with
+    another init stream).  The published row is ONE run of the configuration that won a 50-trial search, so it is
+    expected in the upper part of the distribution, not at its mean:
+      * the published MAP@5 must lie inside [min - 0.012, max + 0.012] of the eight runs;
+      * the mean may sit below it by no more than 0.025 and above it by no more than 0.01.
+    What pins the DisGANMF arithmetic tightly is tests/test_gpu_trial_logs.py: the reference's 100 logged DisGANMF
+    trials (all four activations, 1-5 layers) replayed with rho 0.83-0.89 and the mean MAP@5 within 3 %."""
     from ganmf_amd.DisGANMF import DisGANMF
     from ganmf_amd.evaluation import EvaluatorHoldoutFast
     kat = json.load(open(os.path.join(golden_dir, "statistical_kat_disganmf_ml1m_%s.json" % mode)))
     train = sps.load_npz(os.path.join(golden_dir, "Movielens1M_URM_train.npz")).tocsr()
     test = sps.load_npz(os.path.join(golden_dir, "Movielens1M_URM_test.npz")).tocsr()
-    np.random.seed(1337)
-    model = DisGANMF(train, mode=mode, seed=1337, is_experiment=True)
-    t0 = time.time()
-    model.fit(validation_set=None, sample_every=None, validation_evaluator=None, **kat["best_params"])
-    train_s = time.time() - t0
-    res, _ = EvaluatorHoldoutFast(test, [5]).evaluateRecommender(model)
-    pub = kat["published"]
-    steps = kat["best_params"]["epochs"] * 2 * -(-model.num_users // kat["best_params"]["batch_size"])
-    print("ML-1M DisGANMF-%s: %d updates in %.2f s (%.0f steps/s); MAP@5 %.4f (published %.4f) NDCG@5 %.4f (%.4f)"
-          % (mode, steps, train_s, steps / train_s, res[5]["MAP"], pub["5"]["MAP"], res[5]["NDCG"], pub["5"]["NDCG"]))
-    assert abs(res[5]["MAP"] - pub["5"]["MAP"]) <= 0.035, (mode, res[5]["MAP"], pub["5"]["MAP"])
+    ev = EvaluatorHoldoutFast(test, [5])
+    pub = kat["published"]["5"]["MAP"]
+    vals = []
+    for seed in (1337, 1, 2, 3, 4, 5, 6, 7):
+        np.random.seed(seed)
+        model = DisGANMF(train, mode=mode, seed=seed, is_experiment=True)
+        model.fit(validation_set=None, sample_every=None, validation_evaluator=None, **kat["best_params"])
+        vals.append(ev.evaluateRecommender(model)[0][5]["MAP"])
+        model.engine.close()
+    vals = np.array(vals)
+    print("ML-1M DisGANMF-%s MAP@5 over 8 seeds: min %.4f mean %.4f max %.4f (published %.4f)  %s"
+          % (mode, vals.min(), vals.mean(), vals.max(), pub, np.round(vals, 4)))
+    assert vals.min() - 0.012 <= pub <= vals.max() + 0.012, (vals, pub)
+    assert -0.025 <= vals.mean() - pub <= 0.01, (vals.mean(), pub)
+
+
+@pytest.mark.parametrize("case", ["ganmf_ml1m_user", "disganmf_ml1m_user", "ganmf_hetrec_item", "ganmf_lastfm_user"])
+def test_hip_matches_oracle_end_to_end(golden_dir, case):
+    """The HIP path against the numpy oracle's OWN full training run (oracle/run_end_to_end.py, committed as
+    tests/golden/oracle_end_to_end.json): same hyper-parameters, same initial weights (RandomState(1337) draws in the
+    same tensor order), same minibatch schedule.  Per-step agreement is tested elsewhere at 1e-4; over 10^4 chaotic
+    updates the two fp32 trajectories separate, so the end-to-end comparison is on the metrics and the factor norms:
+    GANMF within 0.004 on every metric @5 and on MAP@10/20/50 (the published row sits inside the same band), DisGANMF
+    within the seed-to-seed spread (0.02)."""
+    fx = json.load(open(os.path.join(golden_dir, "oracle_end_to_end.json")))
+    if case not in fx:
+        pytest.skip("oracle run %s not committed" % case)
+    o = fx[case]
+    from ganmf_amd.DisGANMF import DisGANMF
+    from ganmf_amd.GANMF import GANMF
+    from ganmf_amd.evaluation import EvaluatorHoldoutFast
+    train = sps.load_npz(os.path.join(golden_dir, "%s_URM_train.npz" % o["dataset"])).tocsr()
+    test = sps.load_npz(os.path.join(golden_dir, "%s_URM_test.npz" % o["dataset"])).tocsr()
+    np.random.seed(o["seed"])
+    cls = GANMF if o["model"] == "GANMF" else DisGANMF
+    model = cls(train, mode=o["mode"], seed=o["seed"], is_experiment=True)
+    model.fit(validation_set=None, sample_every=None, validation_evaluator=None, **o["best_params"])
+    res, _ = EvaluatorHoldoutFast(test, [5, 10, 20, 50]).evaluateRecommender(model)
+    tol = 0.004 if o["model"] == "GANMF" else 0.02
+    ref = o["oracle_metrics"]
+    print("%s: HIP MAP@5 %.4f NDCG@5 %.4f | oracle %.4f %.4f | published %.4f %.4f" % (
+        case, res[5]["MAP"], res[5]["NDCG"], ref["5"]["MAP"], ref["5"]["NDCG"], o["published_at5"]["MAP"], o["published_at5"]["NDCG"]))
+    for metric in ("MAP", "NDCG", "PRECISION", "RECALL"):
+        assert abs(res[5][metric] - ref["5"][metric]) <= tol, (metric, res[5][metric], ref["5"][metric])
+    for c in (10, 20, 50):
+        assert abs(res[c]["MAP"] - ref[str(c)]["MAP"]) <= tol, (c, res[c]["MAP"], ref[str(c)]["MAP"])
+    norm_tol = 0.01 if o["model"] == "GANMF" else 0.06
+    for name, got in (("U", model.user_factors()), ("V", model.item_factors())):
+        want = o["factor_norms"][name]
+        assert abs(np.linalg.norm(got.astype(np.float64)) - want) <= norm_tol * want, (name, np.linalg.norm(got), want)
+    model.engine.close()
 
 
 def test_ml1m_user_feature_matching_ablation(golden_dir):
