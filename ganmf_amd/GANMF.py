@@ -85,7 +85,7 @@ class GANMF(BaseRecommender):
         self.items_to_ignore_ID = np.array([], dtype=int)
         self.filterTopPop = False
         self.filterTopPop_ItemsID = np.array([], dtype=int)
-        self.mfma = None                # None | "f32" | "bf16": arithmetic of the GEMM K loops (engine.Engine)
+        self.mfma = None                # None | "f32" | "bf16" | "f16": arithmetic of the GEMM K loops (engine.Engine)
         self.initial_weights = None     # optional dict {We,be,Wd,bd,U,V}: explicit init (parity tests)
         self.engine = None
         self.params = None

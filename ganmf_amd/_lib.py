@@ -9,8 +9,8 @@ _lib = None
 
 ABI_VERSION = 1
 MODEL_GANMF, MODEL_DISGANMF = 0, 1
-FLAG_MFMA_F32, FLAG_MFMA_BF16 = 1, 2     # include/ganmf_hip.h GANMF_FLAG_*
-MFMA_FLAGS = {None: 0, "auto": 0, "f32": FLAG_MFMA_F32, "bf16": FLAG_MFMA_BF16}
+FLAG_MFMA_F32, FLAG_MFMA_BF16, FLAG_MFMA_F16 = 1, 2, 4     # include/ganmf_hip.h GANMF_FLAG_*
+MFMA_FLAGS = {None: 0, "auto": 0, "f32": FLAG_MFMA_F32, "bf16": FLAG_MFMA_BF16, "f16": FLAG_MFMA_F16}
 ACT = {"linear": 0, "tanh": 1, "relu": 2, "sigmoid": 3}
 T_USER_EMB, T_ITEM_EMB = 100, 101
 SLOT_PARAM, SLOT_ADAM_M, SLOT_ADAM_V, SLOT_BEST = 0, 1, 2, 3

@@ -85,6 +85,7 @@ int env_mfma_mode(int dflt) {
   if (!strcmp(v, "f32")) return MFMA_F32;
   if (!strcmp(v, "bf16x3")) return MFMA_BF16X3;
   if (!strcmp(v, "bf16")) return MFMA_BF16;
+  if (!strcmp(v, "f16")) return MFMA_F16;
   return dflt;
 }
 
@@ -307,6 +308,15 @@ float* slot_ptr(Tensor* t, int slot) {
   }
 }
 
+// MFMA_F16: power of two that brings an operand carrying the loss gradient's 1/(B.N) (GANMF: mean over B.N reconstruction
+// errors) or 1/B (DisGANMF: mean over B cross-entropies, times an output weight of ~2^-5) into fp16's normal range
+inline float grad_scale(const ganmf_handle* h, int b_global) {
+  if (h->tune.mode != MFMA_F16) return 0.f;
+  const float lg = h->cfg.model == GANMF_MODEL_GANMF ? log2f((float)b_global * (float)h->N) : log2f((float)b_global) + 6.f;
+  return exp2f(roundf(lg));
+}
+inline bool low_precision(const ganmf_handle* h) { return h->tune.mode == MFMA_F16 || h->tune.mode == MFMA_BF16; }
+
 inline double gemm_flops(double M, double N, double K) { return 2.0 * M * N * K; }
 inline double gemm_bytes(double M, double N, double K) { return 4.0 * (M * K + N * K + M * N); }
 
@@ -398,7 +408,7 @@ int run_gemm(ganmf_handle* h, int tag_gemm, int tag_red, GemmP g, bool akm, bool
       h->seen_plans.push_back(key);
       fprintf(stderr, "[ganmf plan] %-28s M=%d N=%d K=%d batch=%d -> tile %d ring %d nsplit %d (kps %d) mfma %s wgs %d est %.1f us%s\n",
               kTagName[tag_gemm], g.M, g.N, g.K, g.nbatch, pl.tile, pl.ring, pl.nsplit, pl.kps,
-              pl.mode == MFMA_BF16X3 ? "bf16x3" : pl.mode == MFMA_BF16 ? "bf16" : "f32",
+              pl.mode == MFMA_BF16X3 ? "bf16x3" : pl.mode == MFMA_BF16 ? "bf16" : pl.mode == MFMA_F16 ? "f16" : "f32",
               pl.tiles_m * pl.tiles_n * pl.nsplit * g.nbatch, pl.est_us,
               pl.persist ? " (persistent tile walk)" : in_launch ? " (in-launch reduce)" : "");
     }
@@ -538,6 +548,7 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
       GemmP g{};
       g.A = h->Es; g.lda = h->lde; g.B = h->Dl; g.ldb = h->ldN;
       g.C = h->Wd.g; g.ldc = h->ldN; g.M = e + 1; g.N = N; g.K = 2 * nb; g.epi.kind = EPI_STORE;
+      g.a_scale = grad_scale(h, b_global);     // Es = rs (.) E carries the 2/(B.N) of the loss gradient
       if (fused) {
         g.epi.kind = EPI_ADAM; g.epi.adam_theta = h->Wd.p; g.epi.adam_m = h->Wd.m; g.epi.adam_v = h->Wd.v;
         g.epi.adam_alpha = h->scal + S_ALPHA_D; g.epi.adam_reg = h->cfg.d_reg;
@@ -567,6 +578,7 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
       GemmP g{};
       g.A = h->XF; g.lda = h->ldN; g.B = h->dE; g.ldb = h->lde;
       g.C = h->We.g; g.ldc = h->lde; g.M = N + 1; g.N = e; g.K = 2 * nb; g.epi.kind = EPI_STORE;
+      g.b_scale = grad_scale(h, b_global);     // dE
       if (fused) {
         g.epi.kind = EPI_ADAM; g.epi.adam_theta = h->We.p; g.epi.adam_m = h->We.m; g.epi.adam_v = h->We.v;
         g.epi.adam_alpha = h->scal + S_ALPHA_D; g.epi.adam_reg = h->cfg.d_reg;
@@ -595,7 +607,7 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
 // Generator parameter update shared by GANMF and DisGANMF: gUb = dF.V (reads the OLD V), gV = dF^T.Ub,
 // Adam on V (fused into the gV GEMM epilogue on a single GPU) and the all-rows Adam on U.
 // *regn_v = number of sum(V^2) partials written (when g_reg != 0).
-int gen_update(ganmf_handle* h, int nb, int start, int* regn_v, float* reg_u, float* reg_v) {
+int gen_update(ganmf_handle* h, int nb, int start, int b_global, int* regn_v, float* reg_u, float* reg_v) {
   const int N = h->N, k = h->k;
   const bool reg = h->cfg.g_reg != 0.f;
   const bool dist = h->has_comm;
@@ -605,12 +617,14 @@ int gen_update(ganmf_handle* h, int nb, int start, int* regn_v, float* reg_u, fl
     GemmP g{};
     g.A = h->dF; g.lda = h->ldN; g.B = h->V.p; g.ldb = h->ldk;
     g.C = h->gUb; g.ldc = h->ldk; g.M = nb; g.N = k; g.K = N; g.epi.kind = EPI_STORE;
+    g.a_scale = grad_scale(h, b_global);      // dF
     return run_gemm(h, T_GEMM_GUB, T_RED_GUB, g, false, true);
   };
   auto gemm_gV = [&]() -> int {   // gV = dF^T . Ub
     GemmP g{};
     g.A = h->dF; g.lda = h->ldN; g.B = h->Ub; g.ldb = h->ldk;
     g.C = h->V.g; g.ldc = h->ldk; g.M = N; g.N = k; g.K = nb; g.epi.kind = EPI_STORE;
+    g.a_scale = grad_scale(h, b_global);      // dF
     if (fused) {
       g.epi.kind = EPI_ADAM; g.epi.adam_theta = h->V.p; g.epi.adam_m = h->V.m; g.epi.adam_v = h->V.v;
       g.epi.adam_alpha = h->scal + S_ALPHA_G; g.epi.adam_reg = h->cfg.g_reg;
@@ -682,6 +696,7 @@ int g_step(ganmf_handle* h, const int* rows_dev, int nb, int start, int b_global
       g.A = h->dE; g.lda = h->lde; g.B = h->We.p; g.ldb = h->lde;
       g.C = h->dF; g.ldc = h->ldN; g.M = nb; g.N = N; g.K = e;
       g.epi.kind = EPI_SUB_SCALED_AUX; g.epi.c = rsv; g.epi.aux = h->Dl; g.epi.ldaux = h->ldN;
+      g.a_scale = grad_scale(h, b_global);     // dE
       TRY(run_gemm(h, T_GEMM_DF, T_RED_DF, g, false, false, nullptr, 4.0 * nb * N));
     }
   } else {
@@ -690,7 +705,7 @@ int g_step(ganmf_handle* h, const int* rows_dev, int nb, int start, int b_global
   }
   const bool reg = h->cfg.g_reg != 0.f;
   int regn_v = ADAM_GRID;
-  TRY(gen_update(h, nb, start, &regn_v, arena + 2 * cap, arena + 3 * cap));
+  TRY(gen_update(h, nb, start, b_global, &regn_v, arena + 2 * cap, arena + 3 * cap));
   (void)parts; (void)reg; (void)sqn; (void)fmn;
   return 0;
 }
@@ -723,13 +738,21 @@ int dis_forward(ganmf_handle* h, const int* rows_dev, int nb, int which) {
     g.B = h->Wl[l].p; g.ldb = h->lde;
     g.C = h->Al[l]; g.ldc = h->lde; g.M = 2 * nb; g.N = e; g.K = l == 0 ? N + 2 : e + 1;
     g.epi.kind = EPI_ACT; g.epi.act = h->act;
+    if (l == 0 && low_precision(h)) {
+      // float(uid) (up to 6039: not representable in 8 or 11 bits) stays fp32: column N+1 of the input leaves the K range
+      // and comes back as a rank-1 term of the epilogue, uid[m] * W_0_ext[N+1, n]
+      g.K = N + 1;
+      g.epi.r1_u = h->XF + (N + 1); g.epi.r1_ld = h->ldN;
+      g.epi.r1_w = h->Wl[0].p + (size_t)(N + 1) * h->lde;
+    }
     TRY(run_gemm(h, T_DIS_FWD, T_RED_DIS_FWD, g, false, true));
   }
   return 0;
 }
 
 // dz_{l-1} = (dz_l . W_l[0:e]^T) * act'(a_{l-1}) for rows [row0, row0+nrows); returns the dz_0 buffer
-int dis_backprop_hidden(ganmf_handle* h, int row0, int nrows, bool param_grads, float** dz0_out) {
+int dis_backprop_hidden(ganmf_handle* h, int row0, int nrows, bool param_grads, int b_global, float** dz0_out) {
+  const float gsc = grad_scale(h, b_global);     // dz carries the 1/B of the mean cross-entropy times an output weight
   const int N = h->N, e = h->e;
   float* cur = h->dz0;   // dz_{L-1} was written here by dis_dz_top_kernel
   float* nxt = h->dz1;
@@ -740,7 +763,15 @@ int dis_backprop_hidden(ganmf_handle* h, int row0, int nrows, bool param_grads, 
       g.B = cur; g.ldb = h->lde;
       g.C = h->Wl[l].g; g.ldc = h->lde; g.M = l == 0 ? N + 2 : e + 1; g.N = e; g.K = nrows;
       g.epi.kind = EPI_STORE;
+      g.b_scale = gsc;
+      const bool uid_apart = l == 0 && low_precision(h);
+      if (uid_apart) g.M = N + 1;      // the float(uid) row of W_0_ext gets its gradient from the fp32 reduction below
       TRY(run_gemm(h, T_DIS_GW, T_RED_DIS_GW, g, true, true));
+      if (uid_apart) {
+        hipLaunchKernelGGL(dis_uid_grad_kernel, dim3((e + 255) / 256), dim3(256), 0, h->st, h->XF, h->ldN, N + 1, cur, h->lde,
+                           nrows, e, h->Wl[0].g + (size_t)(N + 1) * h->lde);
+        HIP_TRY(hipGetLastError());
+      }
     }
     if (l > 0) {
       GemmP g{};
@@ -748,6 +779,7 @@ int dis_backprop_hidden(ganmf_handle* h, int row0, int nrows, bool param_grads, 
       g.C = nxt + (size_t)row0 * h->lde; g.ldc = h->lde; g.M = nrows; g.N = e; g.K = e;
       g.epi.kind = EPI_MUL_ACTGRAD; g.epi.act = h->act;
       g.epi.aux = h->Al[l - 1] + (size_t)row0 * h->lde; g.epi.ldaux = h->lde;
+      g.a_scale = gsc;
       TRY(run_gemm(h, T_DIS_BWD, T_RED_DIS_BWD, g, false, false));
       std::swap(cur, nxt);
     }
@@ -771,7 +803,7 @@ int dis_d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float
       HIP_TRY(hipGetLastError());
     }
     float* dz0;
-    TRY(dis_backprop_hidden(h, 0, 2 * nb, true, &dz0));
+    TRY(dis_backprop_hidden(h, 0, 2 * nb, true, b_global, &dz0));
   } else {
     hipLaunchKernelGGL(open_step_kernel, dim3(1), dim3(64), 0, h->st, h->scal, 0, h->cfg.d_lr);
     HIP_TRY(hipGetLastError());
@@ -824,11 +856,12 @@ int dis_g_step(ganmf_handle* h, const int* rows_dev, int nb, int start, int b_gl
       HIP_TRY(hipGetLastError());
     }
     float* dz0;
-    TRY(dis_backprop_hidden(h, nb, nb, false, &dz0));
+    TRY(dis_backprop_hidden(h, nb, nb, false, b_global, &dz0));
     {  // dF = dz_0 . W_0[profile rows]^T     (the uid column of the input is dropped, DisGANMF.py:59)
       GemmP g{};
       g.A = dz0 + (size_t)nb * h->lde; g.lda = h->lde; g.B = h->Wl[0].p; g.ldb = h->lde;
       g.C = h->dF; g.ldc = h->ldN; g.M = nb; g.N = N; g.K = e; g.epi.kind = EPI_STORE;
+      g.a_scale = grad_scale(h, b_global);
       TRY(run_gemm(h, T_GEMM_DF, T_RED_DF, g, false, false));
     }
   } else {
@@ -837,7 +870,7 @@ int dis_g_step(ganmf_handle* h, const int* rows_dev, int nb, int start, int b_gl
   }
   const bool reg = h->cfg.g_reg != 0.f;
   int regn_v = ADAM_GRID;
-  TRY(gen_update(h, nb, start, &regn_v, h->regp + 2 * h->reg_cap, h->regp + 3 * h->reg_cap));
+  TRY(gen_update(h, nb, start, b_global, &regn_v, h->regp + 2 * h->reg_cap, h->regp + 3 * h->reg_cap));
   {  // parts = {sum sce(fake), sum (feat_f - feat_r)^2, sum U^2, sum V^2}
     MultiRed mr{};
     mr.out = parts;
@@ -1022,7 +1055,7 @@ static int create_impl(const ganmf_cfg* cfg, ganmf_handle* h) {
   h->tune.ring = env_int("GANMF_RING", 0);
   if (h->tune.ring != 0 && h->tune.ring != 2 && h->tune.ring != 3 && h->tune.ring != 4) h->tune.ring = 0;
   h->tune.nsplit = std::max(0, env_int("GANMF_NSPLIT", 0));
-  h->tune.mode = env_mfma_mode((cfg->flags & GANMF_FLAG_MFMA_BF16) ? MFMA_BF16 : (cfg->flags & GANMF_FLAG_MFMA_F32) ? MFMA_F32 : MFMA_DEFAULT);
+  h->tune.mode = env_mfma_mode((cfg->flags & GANMF_FLAG_MFMA_F16) ? MFMA_F16 : (cfg->flags & GANMF_FLAG_MFMA_BF16) ? MFMA_BF16 : (cfg->flags & GANMF_FLAG_MFMA_F32) ? MFMA_F32 : MFMA_DEFAULT);
   h->tune.persist = env_int("GANMF_PERSIST", -1);
   h->debug_plan = env_int("GANMF_DEBUG_PLAN", 0) != 0;
   h->fused_mode = env_int("GANMF_FUSED_X3", 1) ? MFMA_BF16X3 : MFMA_F32;

@@ -18,7 +18,8 @@
 //       K-major operand       [k/2][R], the row index XOR 32 on odd groups of four k-pairs
 //                             -> four conflict-free ds_read_b32 per piece and fragment.
 //     A lane (i = lane & 31, h = lane >> 5) holds k = 16c + 8h + 0..7 of MFMA step c for both operands.
-//   * NPIECE = 1 rounds each operand to a single bf16 (RNE): the mixed-precision mode.
+//   * NPIECE = 1 rounds each operand to a single bf16 (RNE), or with F16 = true to a single fp16 after an exact
+//     power-of-two scale and a clamp to the fp16 range: the mixed-precision modes (MFMA_BF16 / MFMA_F16).
 #pragma once
 #include "gemm_f32.hpp"
 
@@ -83,8 +84,8 @@ struct SplitStage {
   }
 
   // split / round and write the pieces to the planes at `planes` (piece q at planes + q * PLANE)
-  template <int NPIECE>
-  __device__ inline void store(unsigned* __restrict__ planes, const float4 (&v)[NI][2]) const {
+  template <int NPIECE, bool F16 = false>
+  __device__ inline void store(unsigned* __restrict__ planes, const float4 (&v)[NI][2], float scale = 1.f) const {
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
       // the four (k, k+1) pairs of this item: 8 consecutive k of one row, or two k-rows of four consecutive rows
@@ -97,6 +98,8 @@ struct SplitStage {
           unsigned h, m, l;
           split_bf16x3(x0, x1, h, m, l);
           pc[0][q] = h; pc[1][q] = m; pc[2][q] = l;
+        } else if constexpr (F16) {
+          pc[0][q] = cvt_pk_f16(x0 * scale, x1 * scale);
         } else {
           pc[0][q] = cvt_pk_bf16(x0, x1);
         }
@@ -126,8 +129,12 @@ struct SplitStage {
   }
 };
 
-template <int BM, int BN, int BK, bool AKM, bool BKM, int NPIECE>
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+template <int BM, int BN, int BK, bool AKM, bool BKM, int NPIECE, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void gemm_bf16s_mfma(const GemmP p) {
+  static_assert(!F16 || NPIECE == 1, "fp16 pieces only in the single-piece (mixed precision) mode");
+  const float sa = (F16 && p.a_scale != 0.f) ? p.a_scale : 1.f, sb = (F16 && p.b_scale != 0.f) ? p.b_scale : 1.f;
   using SA = SplitStage<BM, BK, AKM>;
   using SB = SplitStage<BN, BK, BKM>;
   constexpr int WM = BM / 2, WN = BN / 2;
@@ -175,8 +182,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16s_mfma(const GemmP p) {
   la.load(ra, p.lda, kleft);
   lb.load(rb, p.ldb, kleft);
   kleft -= BK;
-  la.template store<NPIECE>(planes_a, ra);
-  lb.template store<NPIECE>(planes_b, rb);
+  la.template store<NPIECE, F16>(planes_a, ra, sa);
+  lb.template store<NPIECE, F16>(planes_b, rb, sb);
   __syncthreads();
 
   u32x4 pa[2][TM][NPIECE], pb[2][TN][NPIECE];
@@ -219,6 +226,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16s_mfma(const GemmP p) {
           if (NT == 6 && t6 < 5)
             accl[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pa[set][a][ia]),
                                                                  __builtin_bit_cast(bf16x8, pb[set][b][ib]), accl[a][b], 0, 0, 0);
+          else if constexpr (F16)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, pa[set][a][ia]),
+                                                               __builtin_bit_cast(f16x8, pb[set][b][ib]), acc[a][b], 0, 0, 0);
           else
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pa[set][a][ia]),
                                                                 __builtin_bit_cast(bf16x8, pb[set][b][ib]), acc[a][b], 0, 0, 0);
@@ -240,8 +250,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16s_mfma(const GemmP p) {
     }
     __syncthreads();                 // every wave has read its fragments: the planes may be overwritten
     if (more) {
-      la.template store<NPIECE>(planes_a, ra);
-      lb.template store<NPIECE>(planes_b, rb);
+      la.template store<NPIECE, F16>(planes_a, ra, sa);
+      lb.template store<NPIECE, F16>(planes_b, rb, sb);
       __syncthreads();
     }
   }
@@ -251,21 +261,32 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16s_mfma(const GemmP p) {
 #pragma unroll
       for (int b = 0; b < TN; ++b) acc[a][b] += accl[a][b];
   }
+  if constexpr (F16) {
+    if (sa != 1.f || sb != 1.f) {      // undo the operand scaling in fp32 (powers of two: exact)
+      const float un = 1.f / (sa * sb);
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[a][b] *= un;
+    }
+  }
   gemm_epilogue<BM, BN, TM, TN>(p, acc, smem, TileCoord{tm, tn, sp, bz, m0, n0});
 }
 
-template <int BM, int BN, int BK, int NPIECE>
+template <int BM, int BN, int BK, int NPIECE, bool F16 = false>
 inline hipError_t gemm_bf16s_launch(hipStream_t st, const GemmP& p, bool akm, bool bkm) {
   const int grid = p.tiles_m * p.tiles_n * p.nsplit * p.nbatch;
   if (grid <= 0) return hipSuccess;
-  if (!akm && !bkm) hipLaunchKernelGGL((gemm_bf16s_mfma<BM, BN, BK, false, false, NPIECE>), dim3(grid), dim3(256), 0, st, p);
-  else if (!akm && bkm) hipLaunchKernelGGL((gemm_bf16s_mfma<BM, BN, BK, false, true, NPIECE>), dim3(grid), dim3(256), 0, st, p);
-  else if (akm && bkm) hipLaunchKernelGGL((gemm_bf16s_mfma<BM, BN, BK, true, true, NPIECE>), dim3(grid), dim3(256), 0, st, p);
+  if (!akm && !bkm) hipLaunchKernelGGL((gemm_bf16s_mfma<BM, BN, BK, false, false, NPIECE, F16>), dim3(grid), dim3(256), 0, st, p);
+  else if (!akm && bkm) hipLaunchKernelGGL((gemm_bf16s_mfma<BM, BN, BK, false, true, NPIECE, F16>), dim3(grid), dim3(256), 0, st, p);
+  else if (akm && bkm) hipLaunchKernelGGL((gemm_bf16s_mfma<BM, BN, BK, true, true, NPIECE, F16>), dim3(grid), dim3(256), 0, st, p);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }
 
 inline hipError_t gemm_dispatch_staged(hipStream_t st, const GemmP& p, bool akm, bool bkm, const GemmPlan& pl) {
+  if (pl.mode == MFMA_F16)
+    return pl.tile == 128 ? gemm_bf16s_launch<128, 128, 32, 1, true>(st, p, akm, bkm) : gemm_bf16s_launch<64, 64, 64, 1, true>(st, p, akm, bkm);
   if (pl.mode == MFMA_BF16X3)
     return pl.tile == 128 ? gemm_bf16s_launch<128, 128, 32, 3>(st, p, akm, bkm) : gemm_bf16s_launch<64, 64, 64, 3>(st, p, akm, bkm);
   return pl.tile == 128 ? gemm_bf16s_launch<128, 128, 32, 1>(st, p, akm, bkm) : gemm_bf16s_launch<64, 64, 64, 1>(st, p, akm, bkm);

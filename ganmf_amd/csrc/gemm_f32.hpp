@@ -50,9 +50,14 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 //               piece products of weight >= 2^-18 (hi.hi, hi.mid, mid.hi, hi.lo, lo.hi, mid.mid) on
 //               v_mfma_f32_32x32x16_bf16 (4096 FLOP/clk/CU): 6/16 of the fp32 MFMA time; the three dropped
 //               products sum to <= 2^-26 |a||b|, below one fp32 rounding of the product, and are unbiased.
-//   MFMA_BF16   gemm_bf16s.hpp: operands rounded to one bf16 (round to nearest even), fp32 accumulate: the
-//               mixed-precision variant BASELINE configs[4] asks for (master weights and Adam stay fp32).
-enum MfmaMode : int { MFMA_AUTO = -1, MFMA_F32 = 0, MFMA_BF16 = 1, MFMA_BF16X3 = 3 };
+//   MFMA_BF16   gemm_bf16s.hpp: operands rounded to one bf16 (round to nearest even), fp32 accumulate (master weights and
+//               Adam stay fp32).
+//   MFMA_F16    gemm_bf16s.hpp: operands rounded to one IEEE fp16 (v_cvt_pk_f16_f32, RNE) for v_mfma_f32_32x32x16_f16,
+//               fp32 accumulate: the mixed-precision variant BASELINE configs[4] names.  fp16 has 11 significant bits
+//               (bf16: 8) but a 5-bit exponent: operands that carry the 1/(B.N) of the loss gradients are multiplied by a
+//               power of two when they are converted (GemmP::a_scale / b_scale, exact) and the accumulator is scaled back
+//               in fp32 before the epilogue -- static loss scaling per GEMM; converted values are clamped to +-65504.
+enum MfmaMode : int { MFMA_AUTO = -1, MFMA_F32 = 0, MFMA_BF16 = 1, MFMA_F16 = 2, MFMA_BF16X3 = 3 };
 
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
@@ -62,6 +67,16 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 __device__ inline unsigned cvt_pk_bf16(float x0, float x1) {
   unsigned r;
   asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(x0), "v"(x1));
+  return r;
+}
+
+// two fp32 -> two IEEE fp16 in one dword (x0 in the low half), round to nearest even, clamped to the finite fp16 range
+// (an overflow would otherwise become an infinity and poison the accumulators)
+__device__ inline unsigned cvt_pk_f16(float x0, float x1) {
+  unsigned r;
+  x0 = __builtin_amdgcn_fmed3f(x0, -65504.f, 65504.f);
+  x1 = __builtin_amdgcn_fmed3f(x1, -65504.f, 65504.f);
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(x0), "v"(x1));
   return r;
 }
 
@@ -139,6 +154,9 @@ struct EpiD {
   float* sq_partials;      // [nbatch][sq_stride]
   int sq_stride;
   int act;                 // ActKind for EPI_ACT / EPI_MUL_ACTGRAD
+  const float* r1_u;       // EPI_ACT: optional fp32 rank-1 term  acc += r1_u[m * r1_ld] * r1_w[n]  before the activation
+  const float* r1_w;       //          (DisGANMF's float(uid) input column kept OUT of a low-precision K loop)
+  int r1_ld;
   float* adam_theta;       // EPI_ADAM: parameter and moments, same [M, ldc] geometry as C
   float* adam_m;
   float* adam_v;
@@ -176,6 +194,7 @@ __device__ inline float epi_apply(const EpiD& e, float v, int row, int col, int 
       break;
     }
     case EPI_ACT:
+      if (e.r1_u) v += e.r1_u[(size_t)row * e.r1_ld] * e.r1_w[col];
       v = act_apply(e.act, v);
       break;
     case EPI_MUL_ACTGRAD:
@@ -206,6 +225,7 @@ struct GemmP {
   float* Cf;               // final output [M, ldc] per batch
   long long cf_batch_stride;
   int c_pad_writable;           // columns N .. ldc-1 of C hold nothing the caller needs (gemm_persist.hpp writes zeros there)
+  float a_scale, b_scale;       // MFMA_F16: powers of two applied to the operands at conversion (0 = 1); acc *= 1 / (a_scale * b_scale)
 };
 
 #define GANMF_WAIT_VMCNT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
@@ -797,7 +817,7 @@ inline hipError_t gemm_dispatch_persist(hipStream_t st, const GemmP& p, bool akm
 
 inline hipError_t gemm_dispatch(hipStream_t st, const GemmP& p, bool akm, bool bkm, const GemmPlan& pl) {
   if (pl.persist) return gemm_dispatch_persist(st, p, akm, bkm, pl);
-  if (pl.mode == MFMA_BF16 || pl.mode == MFMA_BF16X3) return gemm_dispatch_staged(st, p, akm, bkm, pl);
+  if (pl.mode == MFMA_BF16 || pl.mode == MFMA_BF16X3 || pl.mode == MFMA_F16) return gemm_dispatch_staged(st, p, akm, bkm, pl);
   if (pl.tile == 128) return pl.ring >= 3 ? gemm_launch_t<128, 128, 32, 3>(st, p, akm, bkm) : gemm_launch_t<128, 128, 32, 2>(st, p, akm, bkm);
   if (pl.ring == 4) return gemm_launch_t<64, 64, 64, 4>(st, p, akm, bkm);   // 128 KiB ring: three K-tiles (96 KiB) in flight
   return pl.ring == 3 ? gemm_launch_t<64, 64, 64, 3>(st, p, akm, bkm) : gemm_launch_t<64, 64, 64, 2>(st, p, akm, bkm);

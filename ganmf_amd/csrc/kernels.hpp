@@ -330,6 +330,19 @@ __global__ __launch_bounds__(256) void dis_dz_top_kernel(const float* __restrict
   }
 }
 
+// DisGANMF with a low-precision K loop: the float(uid) input column stays in fp32 OUTSIDE the MFMA.  Forward:
+// rank-1 term in the layer-0 epilogue (EpiD::r1_*).  Backward: this kernel, the gradient of that column's weight row,
+//   out[n] = sum_m X[m, uid_col] * dz[m, n]     (rows m < rows; fixed summation order)
+__global__ __launch_bounds__(256) void dis_uid_grad_kernel(const float* __restrict__ X, int ldx, int uid_col,
+                                                           const float* __restrict__ dz, int lddz, int rows, int e,
+                                                           float* __restrict__ out) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= e) return;
+  float s = 0.f;
+  for (int m = 0; m < rows; ++m) s += X[(size_t)m * ldx + uid_col] * dz[(size_t)m * lddz + n];
+  out[n] = s;
+}
+
 // ---- recommend(): seen items -> -inf, then top-k by score (Base/BaseRecommender.py:189-234) ---------
 // One workgroup per score row.  The row is staged in LDS when it fits (lds_cap floats), otherwise the
 // selection works in place on the (private) score buffer.  k rounds of a block-wide arg-max with

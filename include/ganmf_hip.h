@@ -72,11 +72,18 @@ typedef struct ganmf_cfg {
  *                    split exactly into three bf16 pieces and six piece products accumulated in fp32 (chosen by
  *                    the planner from the grid size; both pass every parity test)
  *   GANMF_FLAG_MFMA_F32   force v_mfma_f32_32x32x2_f32 on the fp32 operands
- *   GANMF_FLAG_MFMA_BF16  operands rounded to ONE bf16 (RNE), fp32 accumulate, fp32 master weights and Adam:
- *                    the mixed-precision variant of BASELINE configs[4] (bf16 instead of fp16: same MFMA rate
- *                    on gfx950 and no loss scaling for the ~1e-6 gradients). */
+ *   GANMF_FLAG_MFMA_BF16  operands rounded to ONE bf16 (RNE), fp32 accumulate, fp32 master weights and Adam
+ *                    (8 significant bits, fp32's exponent range: no scaling needed).
+ *   GANMF_FLAG_MFMA_F16   BASELINE configs[4] as written: operands rounded to ONE IEEE fp16 for
+ *                    v_mfma_f32_32x32x16_f16 (same matrix-core rate as bf16, 11 significant bits), fp32 accumulate,
+ *                    fp32 master weights and Adam.  Gradient-carrying operands are scaled by a power of two at
+ *                    conversion and the sum scaled back in fp32 (static loss scaling per GEMM).
+ *   In both low-precision modes DisGANMF's float(uid) input column (DisGANMF.py:59,110-111) does NOT go through
+ *   the low-precision K loop: its forward term is added in fp32 in the layer-0 epilogue and its weight-row
+ *   gradient is an fp32 reduction of its own. */
 #define GANMF_FLAG_MFMA_F32 1u
 #define GANMF_FLAG_MFMA_BF16 2u
+#define GANMF_FLAG_MFMA_F16 4u
 
 /* Replaces: tf.reset_default_graph + build() + optimizers + Session + initialize_all_variables
  * (GANMF.py:97-105,146-149).  Parameters start at zero; the host uploads initial values with

@@ -109,18 +109,23 @@ def test_ganmf_steps_all_modes_vs_oracle():
         eng.close()
 
 
-def test_c5_disganmf_mixed_precision():
-    """BASELINE configs[4]: DisGANMF at ML-1M shape with low-precision MFMA inputs and fp32 Adam accumulators.
-    bf16 stands in for fp16 (same matrix-core rate on gfx950; fp16's 5-bit exponent would need loss scaling for
-    the ~1e-6 gradients).  The raw float(uid) feature (DisGANMF.py:110) is rounded to 8 bits as well, so logits of
-    O(100) move by O(0.5): losses agree to 3 %, first-moment (gradient) tensors to 5 % of their scale."""
+@pytest.mark.parametrize("mfma,loss_tol,m_tol", [("f16", 2e-5, 2e-3), ("bf16", 2e-5, 1.2e-2)])
+def test_c5_disganmf_mixed_precision(mfma, loss_tol, m_tol):
+    """BASELINE configs[4]: DisGANMF at ML-1M shape, k = 250, fp16 MFMA inputs (v_mfma_f32_32x32x16_f16) with fp32
+    accumulation, fp32 master weights and fp32 Adam accumulators.  fp16 carries 11 significant bits; operands that carry
+    the 1/B of the loss gradient are scaled by a power of two at conversion (static loss scaling per GEMM).  The raw
+    float(uid) feature (DisGANMF.py:59,110-111; values up to 6039) is kept in fp32 outside the low-precision K loop, as
+    SURVEY 7 prescribes: rank-1 epilogue term forward, fp32 reduction for its weight-row gradient.  Losses agree with
+    the fp64 oracle to 2e-5 (measured 3e-8 / 7e-7: the logits are dominated by the fp32 uid term), first-moment
+    (= gradient) tensors to 2e-3 of their scale (measured <= 6.4e-4).  The bf16 variant (8 significant bits, same uid
+    handling) is held to 2e-5 / 1.2e-2 (measured 8e-7 / 5.5e-3).  Round 1 rounded the uid column too: 3e-2 / 5e-2."""
     from ganmf_amd import _lib as L
     from ganmf_amd.engine import Engine
     U, N, k, e, B = 6040, 3706, 250, 1024, 128
     hp = dict(d_lr=1e-4, g_lr=5.665e-4, d_reg=3.002e-5, g_reg=0.0, recon_coefficient=0.5)
     urm = synthetic_urm(U, N, 0.035, seed=12)
     o = DisGANMFOracle(U, N, k, d_layers=1, d_nodes=e, d_hidden_act="linear", dtype=np.float64, seed=7, **hp)
-    eng = Engine(U, N, k, e, B, model=L.MODEL_DISGANMF, d_layers=1, d_act="linear", m=0.0, mfma="bf16", **hp)
+    eng = Engine(U, N, k, e, B, model=L.MODEL_DISGANMF, d_layers=1, d_act="linear", m=0.0, mfma=mfma, **hp)
     eng.set_urm(urm)
     ids = {"W0": 0, "b0": 1, "Wo": 2, "bo": 3, "U": 100, "V": 101}
     for n, tid in ids.items():
@@ -130,15 +135,19 @@ def test_c5_disganmf_mixed_precision():
     X = urm[uids].toarray()
     ld_ref, ld = o.d_step(uids, X), eng.train_step(0, uids)
     lg_ref, lg = o.g_step(uids, X), eng.train_step(1, uids)
-    assert abs(ld - ld_ref) <= 3e-2 * abs(ld_ref), (ld, ld_ref)
-    assert abs(lg - lg_ref) <= 3e-2 * abs(lg_ref), (lg, lg_ref)
+    print("%s: dloss %.6f (oracle %.6f, rel %.1e)  gloss %.6f (oracle %.6f, rel %.1e)" % (
+        mfma, ld, ld_ref, abs(ld - ld_ref) / abs(ld_ref), lg, lg_ref, abs(lg - lg_ref) / abs(lg_ref)))
+    assert abs(ld - ld_ref) <= loss_tol * abs(ld_ref), (ld, ld_ref)
+    assert abs(lg - lg_ref) <= loss_tol * abs(lg_ref), (lg, lg_ref)
     for n, tid in ids.items():
         m_ref = (o.opt_d.slots[n] if n in o.opt_d.slots else o.opt_g.slots[n])[0]
-        assert _err(eng.get_tensor(tid, slot=L.SLOT_ADAM_M), m_ref) <= 5e-2, n
+        err = _err(eng.get_tensor(tid, slot=L.SLOT_ADAM_M), m_ref)
+        print("   first moment %-3s error %.2e of its scale" % (n, err))
+        assert err <= m_tol, (n, err)
         lr = hp["g_lr"] if n in ("U", "V") else hp["d_lr"]
         assert _err(eng.get_tensor(tid), o.p[n]) <= 2.2 * lr / np.max(np.abs(o.p[n])) + 1e-3, n   # <= 2 lr per update
     # master weights and moments are float32: a second identical engine reproduces them bit for bit
-    eng2 = Engine(U, N, k, e, B, model=L.MODEL_DISGANMF, d_layers=1, d_act="linear", m=0.0, mfma="bf16", **hp)
+    eng2 = Engine(U, N, k, e, B, model=L.MODEL_DISGANMF, d_layers=1, d_act="linear", m=0.0, mfma=mfma, **hp)
     eng2.set_urm(urm)
     o2 = DisGANMFOracle(U, N, k, d_layers=1, d_nodes=e, d_hidden_act="linear", dtype=np.float64, seed=7, **hp)
     for n, tid in ids.items():
@@ -147,3 +156,66 @@ def test_c5_disganmf_mixed_precision():
     for n, tid in ids.items():
         assert np.array_equal(eng.get_tensor(tid), eng2.get_tensor(tid)), n
     eng.close(); eng2.close()
+
+
+@pytest.mark.parametrize("act,layers", [("tanh", 2), ("relu", 3), ("sigmoid", 1)])
+def test_disganmf_f16_hidden_layers(act, layers):
+    """fp16 mode through non-linear hidden layers and depth > 1 (the scaled backward GEMMs dz_l . W_l^T and the
+    activation-gradient epilogue), small enough for a 3-step trajectory against the fp64 oracle."""
+    from ganmf_amd import _lib as L
+    from ganmf_amd.engine import Engine
+    U, N, k, e, B = 300, 500, 16, 96, 64
+    hp = dict(d_lr=1e-3, g_lr=1e-3, d_reg=1e-4, g_reg=0.0, recon_coefficient=0.3)
+    urm = synthetic_urm(U, N, 0.05, seed=3)
+    o = DisGANMFOracle(U, N, k, d_layers=layers, d_nodes=e, d_hidden_act=act, dtype=np.float64, seed=4, **hp)
+    eng = Engine(U, N, k, e, B, model=L.MODEL_DISGANMF, d_layers=layers, d_act=act, m=0.0, mfma="f16", **hp)
+    eng.set_urm(urm)
+    ids = {}
+    for l in range(layers):
+        ids["W%d" % l], ids["b%d" % l] = 2 * l, 2 * l + 1
+    ids.update({"Wo": 2 * layers, "bo": 2 * layers + 1, "U": 100, "V": 101})
+    for n, tid in ids.items():
+        eng.set_tensor(tid, o.p[n])
+    perm = np.random.RandomState(2).permutation(U)
+    for t in range(3):
+        uids = perm[t * B:(t + 1) * B]
+        X = urm[uids].toarray()
+        ld_ref, ld = o.d_step(uids, X), eng.train_step(0, uids)
+        lg_ref, lg = o.g_step(uids, X), eng.train_step(1, uids)
+        assert abs(ld - ld_ref) <= 5e-3 * abs(ld_ref) + 1e-5, (act, t, ld, ld_ref)
+        assert abs(lg - lg_ref) <= 5e-3 * abs(lg_ref) + 1e-5, (act, t, lg, lg_ref)
+    for n, tid in ids.items():
+        m_ref = (o.opt_d.slots[n] if n in o.opt_d.slots else o.opt_g.slots[n])[0]
+        # (relu: a pre-activation within rounding distance of zero flips its unit on or off, a discrete change of the
+        # gradient that three Adam steps carry into the moments)
+        assert _err(eng.get_tensor(tid, slot=L.SLOT_ADAM_M), m_ref) <= (0.12 if act == "relu" else 2e-2), n
+    eng.close()
+
+
+def test_ganmf_f16_step_vs_oracle():
+    """GANMF (autoencoder discriminator) in fp16 mode: the operands that carry the 2/(B.N) of the MSE gradients (Es, dE,
+    dF) are scaled by 2^round(log2(B.N)) at conversion; one D + one G update against the fp64 oracle."""
+    from ganmf_amd.engine import Engine
+    U, N, k, e, B = 2000, 3706, 250, 992, 128
+    hp = dict(d_lr=1e-4, g_lr=1e-3, d_reg=1e-5, g_reg=0.0, m=10.0, recon_coefficient=0.2)
+    urm = synthetic_urm(U, N, 0.035, seed=5)
+    from oracle.ganmf_oracle import GANMFOracle
+    o = GANMFOracle(U, N, k, e, dtype=np.float64, seed=6, **hp)
+    eng = Engine(U, N, k, e, B, mfma="f16", **hp)
+    eng.set_urm(urm)
+    ids = {"We": 0, "be": 1, "Wd": 2, "bd": 3, "U": 100, "V": 101}
+    for n, tid in ids.items():
+        eng.set_tensor(tid, o.p[n])
+    uids = np.random.RandomState(3).permutation(U)[:B]
+    X = urm[uids].toarray()
+    ld_ref, ld = o.d_step(uids, X), eng.train_step(0, uids)
+    lg_ref, lg = o.g_step(uids, X), eng.train_step(1, uids)
+    assert abs(ld - ld_ref) <= 2e-3 * abs(ld_ref), (ld, ld_ref)
+    assert abs(lg - lg_ref) <= 2e-3 * abs(lg_ref), (lg, lg_ref)
+    from ganmf_amd import _lib as L
+    for n, tid in ids.items():
+        m_ref = (o.opt_d.slots[n] if n in o.opt_d.slots else o.opt_g.slots[n])[0]
+        err = _err(eng.get_tensor(tid, slot=L.SLOT_ADAM_M), m_ref)
+        print("   GANMF f16 first moment %-3s error %.2e of its scale" % (n, err))
+        assert err <= 1e-2, (n, err)
+    eng.close()
