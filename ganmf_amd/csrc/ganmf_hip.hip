@@ -163,6 +163,7 @@ struct ganmf_handle {
   float* data = nullptr;
   long long nnz = 0;
   bool has_urm = false;
+  bool sparse_g = false;   // generator steps take the real rows' encodings from a CSR row-sum (no densify of X)
   // epoch schedule
   int* perm = nullptr;
   int* pos = nullptr;
@@ -466,6 +467,30 @@ int adam_dense(ganmf_handle* h, int tag, Tensor& t, const float* g, int alpha_id
 // ---- shared front of both steps: X rows (+ones column), Ub, F, E = [X;F|1].We_ext ----------------
 int step_front(ganmf_handle* h, const int* rows_dev, int nb, int which) {
   const int N = h->N, k = h->k, e = h->e;
+  if (which == 1 && h->sparse_g) {
+    // sparse regime, generator step: Er from the CSR rows, X never materialised, the encode GEMM runs on the generated
+    // half only
+    {
+      Scope s(h, T_DENSIFY, 0, 4.0 * nb * (2 * k + e) + 4.0 * (double)h->nnz / std::max(h->U, 1) * nb * e);
+      hipLaunchKernelGGL(sparse_front_kernel, dim3(nb), dim3(256), 0, h->st, h->indptr, h->indices, h->data, rows_dev, nb, N,
+                         h->XF, h->ldN, h->Ue.p, h->ldk, h->Ub, h->scal, which, h->cfg.g_lr, h->We.p, h->lde, e, h->E);
+      HIP_TRY(hipGetLastError());
+    }
+    {
+      GemmP g{};
+      g.A = h->Ub; g.lda = h->ldk; g.B = h->V.p; g.ldb = h->ldk;
+      g.C = h->XF + (size_t)nb * h->ldN; g.ldc = h->ldN;
+      g.M = nb; g.N = N; g.K = k; g.epi.kind = EPI_STORE;
+      TRY(run_gemm(h, T_GEMM_GEN, T_RED_GEN, g, false, false));
+    }
+    {
+      GemmP g{};
+      g.A = h->XF + (size_t)nb * h->ldN; g.lda = h->ldN; g.B = h->We.p; g.ldb = h->lde;
+      g.C = h->E + (size_t)nb * h->lde; g.ldc = h->lde; g.M = nb; g.N = e; g.K = N + 1; g.epi.kind = EPI_STORE;
+      TRY(run_gemm(h, T_GEMM_ENC, T_RED_ENC, g, false, true));
+    }
+    return 0;
+  }
   {
     Scope s(h, T_DENSIFY, 0, 4.0 * nb * (N + 2 * k));
     hipLaunchKernelGGL(densify_rows_kernel, dim3(nb), dim3(256), 0, h->st, h->indptr, h->indices, h->data,
@@ -1233,6 +1258,11 @@ int ganmf_set_urm_csr(ganmf_handle* h, const int64_t* indptr, const int32_t* ind
   }
   h->nnz = nnz;
   h->has_urm = true;
+  // below 0.5 % density (LastFM: 0.22 %) the generator step reads the real rows as CSR (GANMF only;
+  // DisGANMF feeds the rows themselves to its discriminator).  GANMF_SPARSE = 0 / 1 overrides.
+  const double density = (double)nnz / ((double)n_rows * (double)n_cols);
+  const int force = env_int("GANMF_SPARSE", -1);
+  h->sparse_g = h->cfg.model == GANMF_MODEL_GANMF && (force >= 0 ? force != 0 : density < 0.005);
   return 0;
 }
 

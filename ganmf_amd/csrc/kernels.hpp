@@ -75,6 +75,70 @@ __global__ __launch_bounds__(256) void densify_rows_kernel(const long long* __re
   }
 }
 
+// SURVEY 8(f)-3, sparse-aware real path of the GENERATOR step.  In a G update the real rows X are needed for ONE thing:
+// their encodings Er = X.We + be in the feature-matching term (GANMF.py:134); nothing else reads X.  For a sparse
+// binary-ish URM that is a CSR row-sum, so the [B, N] densify of X and the real half of the encode GEMM both go away.
+// Block b = batch row b:  Er[b, :] = be + sum_j data[j] * We[idx[j], :]  (CSR order inside a group, groups summed in
+// index order: deterministic), the embedding gather Ub[b, :] = U[rows[b], :], the ones column of the generated row
+// (F = rows nb.. of XF) and -- block 0 -- the opening of the optimizer step, i.e. everything densify_rows_kernel does
+// except writing X.  256 threads = G groups x C4 float4 columns; group g takes the stored entries j = g, g + G, ...
+__global__ __launch_bounds__(256) void sparse_front_kernel(const long long* __restrict__ indptr,
+                                                           const int* __restrict__ indices,
+                                                           const float* __restrict__ data,
+                                                           const int* __restrict__ rows, int nb, int ncols,
+                                                           float* __restrict__ XF, int ldx,
+                                                           const float* __restrict__ Uemb, int ldk,
+                                                           float* __restrict__ Ub, float* __restrict__ scal, int which,
+                                                           float lr, const float* __restrict__ We, int lde, int e,
+                                                           float* __restrict__ E) {
+  __shared__ float4 part[256];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (b == 0 && tid == 0) {
+    const int o = which ? S_B1P_G : S_B1P_D;
+    const float b1p = scal[o], b2p = scal[o + 1];
+    scal[which ? S_ALPHA_G : S_ALPHA_D] = lr * sqrtf(1.f - b2p) / (1.f - b1p);
+    scal[o] = b1p * ADAM_B1;
+    scal[o + 1] = b2p * ADAM_B2;
+  }
+  const int r = rows[b];
+  const float4* us = reinterpret_cast<const float4*>(Uemb + (size_t)r * ldk);
+  float4* ud = reinterpret_cast<float4*>(Ub + (size_t)b * ldk);
+  for (int c = tid; c < ldk / 4; c += 256) ud[c] = us[c];
+  if (tid == 0) XF[(size_t)(nb + b) * ldx + ncols] = 1.0f;
+  const long long s = indptr[r], en = indptr[r + 1];
+  const int c4n = (e + 3) / 4;                       // float4 columns that hold encodings (We rows are zero-padded to lde)
+  const float* bias = We + (size_t)ncols * lde;      // encoder bias = row N of We_ext
+  for (int c0 = 0; c0 < c4n; c0 += 256) {
+    const int width = min(256, c4n - c0);
+    const int G = 256 / width, g = tid / width, c = c0 + tid % width;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g < G) {
+      for (long long j = s + g; j < en; j += G) {
+        const float w = data[j];
+        const float4 a = *reinterpret_cast<const float4*>(We + (size_t)indices[j] * lde + 4 * c);
+        acc.x += w * a.x; acc.y += w * a.y; acc.z += w * a.z; acc.w += w * a.w;
+      }
+    }
+    part[tid] = acc;
+    __syncthreads();
+    if (tid < width) {
+      float4 t = *reinterpret_cast<const float4*>(bias + 4 * c);
+      for (int q = 0; q < G; ++q) {
+        const float4 a = part[q * width + tid];
+        t.x += a.x; t.y += a.y; t.z += a.z; t.w += a.w;
+      }
+      float* dst = E + (size_t)b * lde + 4 * c;     // never the ones column E[:, e]
+      if (4 * c + 3 < e) *reinterpret_cast<float4*>(dst) = t;
+      else {
+        dst[0] = t.x;
+        if (4 * c + 1 < e) dst[1] = t.y;
+        if (4 * c + 2 < e) dst[2] = t.z;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // Opens an optimizer step without any rows (a data-parallel rank that ran out of rows).
 __global__ void open_step_kernel(float* __restrict__ scal, int which, float lr) {
   if (blockIdx.x == 0 && threadIdx.x == 0) {

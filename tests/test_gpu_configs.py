@@ -139,3 +139,41 @@ def test_edge_shapes(U, N, k, e, B):
     for n, tid in NAME2ID.items():
         assert _err(eng.get_tensor(tid), o.p[n]) <= 1e-4, n
     eng.close()
+
+
+@pytest.mark.parametrize("k,e,B", [(10, 32, 32), (16, 100, 256)])
+def test_c1_sparse_generator_path(golden_dir, monkeypatch, k, e, B):
+    """SURVEY 8(f)-3 at BASELINE configs[0] (LastFM 1884 x 17632, 0.22 % dense; the reference's default k / emb_dim /
+    batch and a wider one): generator steps take the real rows' encodings from a CSR row-sum and never densify X.
+    One epoch (59 / 8 D + G updates, ragged last batch) with the sparse path, the dense path and the planner's own choice
+    (which must BE the sparse path at this density) against the fp64 oracle."""
+    import os
+    from ganmf_amd.engine import Engine
+    urm = sps.load_npz(os.path.join(golden_dir, "LastFM_URM_train.npz")).tocsr().astype(np.float32)
+    U, N = urm.shape
+    assert urm.nnz / (U * N) < 0.005
+    hp = dict(d_lr=1e-3, g_lr=1e-3, d_reg=1e-4, g_reg=1e-5, m=5.0, recon_coefficient=0.3)
+    o = GANMFOracle(U, N, k, e, dtype=np.float64, seed=3, **hp)
+    p0 = o.get_params()
+    perm = np.random.RandomState(4).permutation(U)
+    dl_ref, gl_ref = o.train_epoch(urm, perm, B, 1, 1)
+    got = {}
+    for mode in ("1", "0", None):
+        if mode is None:
+            monkeypatch.delenv("GANMF_SPARSE", raising=False)
+        else:
+            monkeypatch.setenv("GANMF_SPARSE", mode)
+        eng = Engine(U, N, k, e, B, **hp)
+        eng.set_urm(urm)
+        for n, tid in NAME2ID.items():
+            eng.set_tensor(tid, p0[n])
+        dl, gl = eng.train_epoch(perm, 1, 1)
+        np.testing.assert_allclose(dl, dl_ref, rtol=1e-4, atol=1e-7)
+        np.testing.assert_allclose(gl, gl_ref, rtol=1e-4, atol=1e-7)
+        got[mode] = {n: eng.get_tensor(tid) for n, tid in NAME2ID.items()}
+        for n in NAME2ID:
+            assert _err(got[mode][n], o.p[n]) <= 1e-4, (mode, n)
+        eng.close()
+    for n in NAME2ID:
+        assert np.array_equal(got[None][n], got["1"][n]), n          # the planner chose the sparse path
+    assert any(not np.array_equal(got["0"][n], got["1"][n]) for n in NAME2ID)   # ... which is a different summation order
