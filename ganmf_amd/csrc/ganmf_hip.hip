@@ -96,6 +96,7 @@ constexpr int COUNTER_CAP = 1 << 16;
 struct Tensor {
   int rows = 0, cols = 0, ld = 0;
   float *p = nullptr, *m = nullptr, *v = nullptr, *best = nullptr, *g = nullptr;
+  size_t cap = 0;          // allocated elements: padded() rounded up to world_size equal slices of a multiple of 64 floats
   size_t padded() const { return (size_t)rows * ld; }
   size_t count() const { return (size_t)rows * cols; }
 };
@@ -123,11 +124,20 @@ struct ProfRec { int tag; hipEvent_t a, b; double flops, bytes; };
 // ---- in-process loopback communicator: group state (see allreduce_local) ----
 constexpr int LOCAL_MAX_WORLD = 8;
 struct LocalPtrs { float* p[LOCAL_MAX_WORLD]; };
-__global__ void local_allreduce_kernel(LocalPtrs b, int world, size_t count) {
+enum LocalOp : int { LOCAL_ALLREDUCE = 0, LOCAL_REDUCE_SCATTER = 1, LOCAL_ALLGATHER = 2 };
+// count = elements of the whole buffer (world slices for the scatter / gather forms); sums run in rank order
+__global__ void local_collective_kernel(LocalPtrs b, int world, size_t count, int op) {
+  const size_t slice = count / (size_t)world;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+    if (op == LOCAL_ALLGATHER) {
+      const float v = b.p[i / slice][i];           // the owner's copy of its slice
+      for (int r = 0; r < world; ++r) b.p[r][i] = v;
+      continue;
+    }
     float s = b.p[0][i];
     for (int r = 1; r < world; ++r) s += b.p[r][i];
-    for (int r = 0; r < world; ++r) b.p[r][i] = s;
+    if (op == LOCAL_ALLREDUCE) { for (int r = 0; r < world; ++r) b.p[r][i] = s; }
+    else b.p[i / slice][i] = s;                    // reduce-scatter: only the owner of the slice receives the sum
   }
 }
 struct LocalGroup {
@@ -136,6 +146,7 @@ struct LocalGroup {
   int world = 0, dev = -1, arrived = 0, joined = 0;
   long long generation = 0;
   size_t count = 0;
+  int op = 0;
   bool failed = false;
   LocalPtrs bufs{};
 };
@@ -186,6 +197,7 @@ struct ganmf_handle {
   int reg_cap = 0;
   bool fuse_adam = true;  // single GPU: Adam runs in the epilogue of the weight-gradient GEMMs
   float *d_parts = nullptr, *g_parts = nullptr;  // [cap][4]
+  float* colbuf = nullptr;                       // [cap] one column of d_parts on its way through an all-reduce
   float *d_arena = nullptr, *g_arena = nullptr;  // [cap][4][reg_cap] per-step block partials (GANMF), reduced once per epoch
   int64_t parts_cap = 0;
   // recommend(): URM_train in evaluation orientation for the seen-item mask, top-k outputs
@@ -204,6 +216,8 @@ struct ganmf_handle {
   ncclComm_t comm = nullptr;
   bool has_comm = false;
   std::shared_ptr<LocalGroup> local;   // in-process loopback communicator (ganmf_comm_init_local)
+  int d_alpha = S_ALPHA_D;             // scalar slot holding lr_t of the discriminator step in flight (alternates in data-parallel runs)
+  bool side_pending = false;           // data-parallel: the side lane still updates replicated tensors (dp_join before their next use)
   // tuning knobs (environment: GANMF_TILE, GANMF_RING, GANMF_NSPLIT; 0 = cost model decides)
   GemmTune tune;
   bool debug_plan = false;
@@ -242,13 +256,17 @@ int dalloc(float** p, size_t elems) {
   return 0;
 }
 
-int alloc_tensor(Tensor& t, int rows, int cols, bool grad_separate, int ld = 0) {
+int alloc_tensor(Tensor& t, int rows, int cols, bool grad_separate, int world, int ld = 0) {
   t.rows = rows; t.cols = cols; t.ld = ld ? ld : round_up(cols + 1, LD_ALIGN);
-  TRY(dalloc(&t.p, t.padded()));
-  TRY(dalloc(&t.m, t.padded()));
-  TRY(dalloc(&t.v, t.padded()));
-  TRY(dalloc(&t.best, t.padded()));
-  if (grad_separate) TRY(dalloc(&t.g, t.padded()));
+  // data-parallel runs reduce-scatter the gradient, update one slice per rank and all-gather the parameter: every
+  // buffer holds world equal slices (the tail past padded() is zero and stays zero: Adam's fixed point)
+  const size_t w = (size_t)std::max(world, 1);
+  t.cap = ((t.padded() + w - 1) / w + 63) / 64 * 64 * w;
+  TRY(dalloc(&t.p, t.cap));
+  TRY(dalloc(&t.m, t.cap));
+  TRY(dalloc(&t.v, t.cap));
+  TRY(dalloc(&t.best, t.cap));
+  if (grad_separate) TRY(dalloc(&t.g, t.cap));
   return 0;
 }
 
@@ -330,17 +348,17 @@ inline double gemm_bytes(double M, double N, double K) { return 4.0 * (M * K + N
 static std::mutex g_local_mu;
 static std::map<int, std::shared_ptr<LocalGroup>> g_local_groups;
 
-int allreduce_local(ganmf_handle* h, float* buf, size_t count, hipStream_t st) {
+int collective_local(ganmf_handle* h, float* buf, size_t count, hipStream_t st, int op) {
   LocalGroup& g = *h->local;
   HIP_TRY(hipStreamSynchronize(st));                    // this member's contribution is complete
   std::unique_lock<std::mutex> lk(g.mu);
   if (g.failed) return fail(-3, "local communicator: a peer failed");
-  if (g.arrived == 0) g.count = count;
-  else if (g.count != count) { g.failed = true; g.cv.notify_all(); return fail(-3, "local communicator: members disagree on the element count"); }
+  if (g.arrived == 0) { g.count = count; g.op = op; }
+  else if (g.count != count || g.op != op) { g.failed = true; g.cv.notify_all(); return fail(-3, "local communicator: members disagree on the collective"); }
   g.bufs.p[h->cfg.rank] = buf;
   if (++g.arrived == g.world) {
     const int grid = (int)std::min<size_t>(1024, (count + 255) / 256);
-    hipLaunchKernelGGL(local_allreduce_kernel, dim3(std::max(grid, 1)), dim3(256), 0, st, g.bufs, g.world, count);
+    hipLaunchKernelGGL(local_collective_kernel, dim3(std::max(grid, 1)), dim3(256), 0, st, g.bufs, g.world, count, op);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     g.arrived = 0;
@@ -363,8 +381,29 @@ int allreduce(ganmf_handle* h, float* buf, size_t count, int lane = 0) {
   if (!h->has_comm) return 0;
   hipStream_t st = lane ? h->st2 : h->st;
   Scope s(h, T_ALLREDUCE, 0, 4.0 * count, st);
-  if (h->local) return allreduce_local(h, buf, count, st);
+  if (h->local) return collective_local(h, buf, count, st, LOCAL_ALLREDUCE);
   NCCL_TRY(ncclAllReduce(buf, buf, count, ncclFloat, ncclSum, h->comm, st));
+  return 0;
+}
+
+// In place over a buffer of world equal slices: after the reduce-scatter rank r holds the sum of slice r (the other
+// slices of its buffer are unspecified); the all-gather fills every slice from its owner.
+int reduce_scatter(ganmf_handle* h, float* buf, size_t total, int lane) {
+  if (h->cfg.world_size == 1) return 0;     // one slice, already in place
+  hipStream_t st = lane ? h->st2 : h->st;
+  const size_t slice = total / (size_t)h->cfg.world_size;
+  Scope s(h, T_ALLREDUCE, 0, 4.0 * total, st);
+  if (h->local) return collective_local(h, buf, total, st, LOCAL_REDUCE_SCATTER);
+  NCCL_TRY(ncclReduceScatter(buf, buf + (size_t)h->cfg.rank * slice, slice, ncclFloat, ncclSum, h->comm, st));
+  return 0;
+}
+int all_gather(ganmf_handle* h, float* buf, size_t total, int lane) {
+  if (h->cfg.world_size == 1) return 0;
+  hipStream_t st = lane ? h->st2 : h->st;
+  const size_t slice = total / (size_t)h->cfg.world_size;
+  Scope s(h, T_ALLREDUCE, 0, 4.0 * total, st);
+  if (h->local) return collective_local(h, buf, total, st, LOCAL_ALLGATHER);
+  NCCL_TRY(ncclAllGather(buf + (size_t)h->cfg.rank * slice, buf, slice, ncclFloat, h->comm, st));
   return 0;
 }
 
@@ -454,26 +493,50 @@ int lane_join(ganmf_handle* h) {
   return 0;
 }
 
-int adam_dense(ganmf_handle* h, int tag, Tensor& t, const float* g, int alpha_idx, float reg, float* sq, int lane = 0) {
-  const long long n4 = (long long)t.padded() / 4;
+// the main lane may not touch We / Wd / V again before the side lane's reduce-scatter / Adam / all-gather are done
+int dp_join(ganmf_handle* h) {
+  if (!h->side_pending) return 0;
+  h->side_pending = false;
+  return lane_join(h);
+}
+
+int adam_dense(ganmf_handle* h, int tag, Tensor& t, const float* g, int alpha_idx, float reg, float* sq, int lane = 0,
+               size_t off = 0, size_t count = 0) {
+  if (count == 0) count = t.padded() - off;
+  const long long n4 = (long long)count / 4;
   hipStream_t st = lane ? h->st2 : h->st;
-  Scope s(h, tag, 0, 28.0 * t.count(), st);
-  hipLaunchKernelGGL(adam_dense_kernel, dim3(ADAM_GRID), dim3(256), 0, st, t.p, t.m, t.v, g, n4, h->scal,
+  Scope s(h, tag, 0, 28.0 * count, st);
+  hipLaunchKernelGGL(adam_dense_kernel, dim3(ADAM_GRID), dim3(256), 0, st, t.p + off, t.m + off, t.v + off, g + off, n4, h->scal,
                      alpha_idx, reg, sq);
   HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// Data-parallel update of a replicated tensor whose local gradient is complete in t.g: reduce-scatter the
+// gradient, TF-Adam on this rank's slice only (parameter and moment slices; the moments of a replicated tensor live
+// sharded across the ranks), all-gather the parameter.  Same bytes on the links as an all-reduce, 1 / world of the Adam
+// traffic, and every rank ends with bitwise identical parameters (each slice has exactly one writer).  The sum(theta^2)
+// partials cover the slice only: the loss parts are all-reduced once per epoch.
+int dp_update(ganmf_handle* h, int tag, Tensor& t, int alpha_idx, float reg, float* sq, int lane) {
+  const size_t slice = t.cap / (size_t)h->cfg.world_size, off = (size_t)h->cfg.rank * slice;
+  TRY(reduce_scatter(h, t.g, t.cap, lane));
+  TRY(adam_dense(h, tag, t, t.g, alpha_idx, reg, sq, lane, off, slice));
+  TRY(all_gather(h, t.p, t.cap, lane));
   return 0;
 }
 
 // ---- shared front of both steps: X rows (+ones column), Ub, F, E = [X;F|1].We_ext ----------------
 int step_front(ganmf_handle* h, const int* rows_dev, int nb, int which) {
   const int N = h->N, k = h->k, e = h->e;
+  const int aslot = which ? S_ALPHA_G : h->d_alpha;
   if (which == 1 && h->sparse_g) {
     // sparse regime, generator step: Er from the CSR rows, X never materialised, the encode GEMM runs on the generated
     // half only
+    TRY(dp_join(h));
     {
       Scope s(h, T_DENSIFY, 0, 4.0 * nb * (2 * k + e) + 4.0 * (double)h->nnz / std::max(h->U, 1) * nb * e);
       hipLaunchKernelGGL(sparse_front_kernel, dim3(nb), dim3(256), 0, h->st, h->indptr, h->indices, h->data, rows_dev, nb, N,
-                         h->XF, h->ldN, h->Ue.p, h->ldk, h->Ub, h->scal, which, h->cfg.g_lr, h->We.p, h->lde, e, h->E);
+                         h->XF, h->ldN, h->Ue.p, h->ldk, h->Ub, h->scal, which, aslot, h->cfg.g_lr, h->We.p, h->lde, e, h->E);
       HIP_TRY(hipGetLastError());
     }
     {
@@ -484,6 +547,7 @@ int step_front(ganmf_handle* h, const int* rows_dev, int nb, int which) {
       TRY(run_gemm(h, T_GEMM_GEN, T_RED_GEN, g, false, false));
     }
     {
+      TRY(dp_join(h));
       GemmP g{};
       g.A = h->XF + (size_t)nb * h->ldN; g.lda = h->ldN; g.B = h->We.p; g.ldb = h->lde;
       g.C = h->E + (size_t)nb * h->lde; g.ldc = h->lde; g.M = nb; g.N = e; g.K = N + 1; g.epi.kind = EPI_STORE;
@@ -494,7 +558,7 @@ int step_front(ganmf_handle* h, const int* rows_dev, int nb, int which) {
   {
     Scope s(h, T_DENSIFY, 0, 4.0 * nb * (N + 2 * k));
     hipLaunchKernelGGL(densify_rows_kernel, dim3(nb), dim3(256), 0, h->st, h->indptr, h->indices, h->data,
-                       rows_dev, nb, N, h->XF, h->ldN, h->Ue.p, h->ldk, h->Ub, h->scal, which,
+                       rows_dev, nb, N, h->XF, h->ldN, h->Ue.p, h->ldk, h->Ub, h->scal, which, aslot,
                        which ? h->cfg.g_lr : h->cfg.d_lr, -1, 0);
     HIP_TRY(hipGetLastError());
   }
@@ -506,6 +570,7 @@ int step_front(ganmf_handle* h, const int* rows_dev, int nb, int which) {
     TRY(run_gemm(h, T_GEMM_GEN, T_RED_GEN, g, false, false));
   }
   {  // E = [X;F | 1] . We_ext  (bias = row N); the ones column E[:, e] is never overwritten  (GANMF.py:64-65)
+    TRY(dp_join(h));     // (data-parallel: the previous step's encoder update ran on the side lane under densify + generator GEMM)
     GemmP g{};
     g.A = h->XF; g.lda = h->ldN; g.B = h->We.p; g.ldb = h->lde;
     g.C = h->E; g.ldc = h->lde; g.M = 2 * nb; g.N = e; g.K = N + 1; g.epi.kind = EPI_STORE;
@@ -520,6 +585,8 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
   float* regWd = arena + 3 * (size_t)h->reg_cap;
   const int N = h->N, e = h->e;
   const bool dist = h->has_comm;
+  if (dist) h->d_alpha = h->d_alpha == S_ALPHA_D ? S_ALPHA_D_ALT : S_ALPHA_D;
+  const int aslot = h->d_alpha;
   const float inv_bn = 1.0f / ((float)b_global * (float)N);
   int sqn = 0;
   bool fused = false;
@@ -537,7 +604,7 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
     }
   } else {
     // rank out of rows: still open the optimizer step and contribute zeros to the collectives
-    hipLaunchKernelGGL(open_step_kernel, dim3(1), dim3(64), 0, h->st, h->scal, 0, h->cfg.d_lr);
+    hipLaunchKernelGGL(open_step_kernel, dim3(1), dim3(64), 0, h->st, h->scal, 0, aslot, h->cfg.d_lr);
     HIP_TRY(hipGetLastError());
   }
   if (dist) {
@@ -576,17 +643,17 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
       g.a_scale = grad_scale(h, b_global);     // Es = rs (.) E carries the 2/(B.N) of the loss gradient
       if (fused) {
         g.epi.kind = EPI_ADAM; g.epi.adam_theta = h->Wd.p; g.epi.adam_m = h->Wd.m; g.epi.adam_v = h->Wd.v;
-        g.epi.adam_alpha = h->scal + S_ALPHA_D; g.epi.adam_reg = h->cfg.d_reg;
+        g.epi.adam_alpha = h->scal + aslot; g.epi.adam_reg = h->cfg.d_reg;
         g.epi.sq_partials = regD ? regWd : nullptr;
       }
       return run_gemm(h, T_GEMM_GWD, T_RED_GWD, g, true, true, &regn[1], fused ? 24.0 * h->Wd.count() : 0, 0, wg_tune);
     };
-    // Data-parallel: the decoder gradient is produced first and its all-reduce runs on the side
-    // lane under the dE and gWe_ext GEMMs (xGMI transfer hidden behind MFMA work).
+    // Data-parallel: the decoder gradient is produced first; its reduce-scatter runs on the side lane under the dE GEMM,
+    // its Adam slice + all-gather (which overwrite Wd) under the gWe_ext GEMM, once dE has read the old decoder.
     if (dist) {
       TRY(gemm_gWd());
       TRY(lane_fork(h));
-      TRY(allreduce(h, h->Wd.g, h->Wd.padded(), 1));
+      TRY(reduce_scatter(h, h->Wd.g, h->Wd.cap, 1));
     }
     {  // dE = rs * (Delta . Wd^T)          (bias row e of Wd_ext is not part of this product; reads the OLD Wd)
       GemmP g{};
@@ -597,7 +664,13 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
     }
     // Weight-gradient GEMMs.  Single GPU: the gradient tile never leaves the CU -- the epilogue
     // applies TF-Adam to theta/m/v in place (after dE, which reads the old decoder).
-    // Data-parallel: the gradients are stored, all-reduced and a separate Adam kernel follows.
+    // Data-parallel: the gradients are stored, reduce-scattered, and each rank updates its slice (dp_update).
+    if (dist) {
+      const size_t slice = h->Wd.cap / (size_t)h->cfg.world_size, off = (size_t)h->cfg.rank * slice;
+      TRY(lane_fork(h));       // the side lane waits for dE
+      TRY(adam_dense(h, T_ADAM_D, h->Wd, h->Wd.g, aslot, h->cfg.d_reg, regD ? regWd : nullptr, 1, off, slice));
+      TRY(all_gather(h, h->Wd.p, h->Wd.cap, 1));
+    }
     if (!dist) TRY(gemm_gWd());
     {  // gWe_ext = [X;F | 1]^T . dE       -> rows 0..N-1 = gWe, row N = gbe
       GemmP g{};
@@ -606,7 +679,7 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
       g.b_scale = grad_scale(h, b_global);     // dE
       if (fused) {
         g.epi.kind = EPI_ADAM; g.epi.adam_theta = h->We.p; g.epi.adam_m = h->We.m; g.epi.adam_v = h->We.v;
-        g.epi.adam_alpha = h->scal + S_ALPHA_D; g.epi.adam_reg = h->cfg.d_reg;
+        g.epi.adam_alpha = h->scal + aslot; g.epi.adam_reg = h->cfg.d_reg;
         g.epi.sq_partials = regD ? regWe : nullptr;
       }
       TRY(run_gemm(h, T_GEMM_GWE, T_RED_GWE, g, true, true, &regn[0], fused ? 24.0 * h->We.count() : 0, 0, wg_tune));
@@ -615,15 +688,19 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
     HIP_TRY(hipMemsetAsync(h->gD, 0, h->gD_elems * sizeof(float), h->st));
     if (dist) {   // same collective order as the ranks that have rows
       TRY(lane_fork(h));
-      TRY(allreduce(h, h->Wd.g, h->Wd.padded(), 1));
+      TRY(dp_update(h, T_ADAM_D, h->Wd, aslot, h->cfg.d_reg, h->cfg.d_reg != 0.f ? regWd : nullptr, 1));
     }
   }
   const bool reg = h->cfg.d_reg != 0.f;
-  if (!fused) {
-    if (dist) TRY(allreduce(h, h->We.g, h->We.padded()));
-    TRY(adam_dense(h, T_ADAM_D, h->We, h->We.g, S_ALPHA_D, h->cfg.d_reg, reg ? regWe : nullptr));
-    if (dist) TRY(lane_join(h));
-    TRY(adam_dense(h, T_ADAM_D, h->Wd, h->Wd.g, S_ALPHA_D, h->cfg.d_reg, reg ? regWd : nullptr));
+  if (dist) {
+    // encoder: behind the decoder's collectives on the side lane; the main lane goes on with the next step's densify
+    // and generator GEMM (they read neither We nor Wd) and joins before its encode GEMM (dp_join)
+    TRY(lane_fork(h));
+    TRY(dp_update(h, T_ADAM_D, h->We, aslot, h->cfg.d_reg, reg ? regWe : nullptr, 1));
+    h->side_pending = true;
+  } else if (!fused) {
+    TRY(adam_dense(h, T_ADAM_D, h->We, h->We.g, aslot, h->cfg.d_reg, reg ? regWe : nullptr));
+    TRY(adam_dense(h, T_ADAM_D, h->Wd, h->Wd.g, aslot, h->cfg.d_reg, reg ? regWd : nullptr));
   }
   (void)regn; (void)parts;
   return 0;   // the sum(theta^2) partials are reduced once per epoch (finish_parts_kernel)
@@ -660,12 +737,18 @@ int gen_update(ganmf_handle* h, int nb, int start, int b_global, int* regn_v, fl
     return 0;
   };
   if (dist) {
-    // data-parallel: gV first, its all-reduce runs on the side lane under gUb and the Adam pass over U
+    // data-parallel: gV first; its reduce-scatter runs on the side lane under gUb (which reads the OLD V), the Adam slice
+    // and the all-gather of V under the all-rows Adam pass over U
+    TRY(dp_join(h));
     if (nb > 0) TRY(gemm_gV());
-    else HIP_TRY(hipMemsetAsync(h->V.g, 0, h->V.padded() * sizeof(float), h->st));
+    else HIP_TRY(hipMemsetAsync(h->V.g, 0, h->V.cap * sizeof(float), h->st));
     TRY(lane_fork(h));
-    TRY(allreduce(h, h->V.g, h->V.padded(), 1));
+    TRY(reduce_scatter(h, h->V.g, h->V.cap, 1));
     if (nb > 0) TRY(gemm_gUb());
+    TRY(lane_fork(h));
+    const size_t slice = h->V.cap / (size_t)h->cfg.world_size, off = (size_t)h->cfg.rank * slice;
+    TRY(adam_dense(h, T_ADAM_V, h->V, h->V.g, S_ALPHA_G, h->cfg.g_reg, reg ? reg_v : nullptr, 1, off, slice));
+    TRY(all_gather(h, h->V.p, h->V.cap, 1));
   } else if (nb > 0) {
     TRY(gemm_gUb());
     TRY(gemm_gV());      // fused: Adam(V) in the epilogue, after gUb has read the old V
@@ -679,10 +762,8 @@ int gen_update(ganmf_handle* h, int nb, int start, int b_global, int* regn_v, fl
                        reg ? reg_u : nullptr);
     HIP_TRY(hipGetLastError());
   }
-  if (!fused) {
-    if (dist) TRY(lane_join(h));
-    TRY(adam_dense(h, T_ADAM_V, h->V, h->V.g, S_ALPHA_G, h->cfg.g_reg, reg ? reg_v : nullptr));
-  }
+  if (dist) TRY(lane_join(h));      // V is read by the very next kernel of the next step (generator GEMM)
+  else if (!fused) TRY(adam_dense(h, T_ADAM_V, h->V, h->V.g, S_ALPHA_G, h->cfg.g_reg, reg ? reg_v : nullptr));
   return 0;
 }
 
@@ -725,7 +806,7 @@ int g_step(ganmf_handle* h, const int* rows_dev, int nb, int start, int b_global
       TRY(run_gemm(h, T_GEMM_DF, T_RED_DF, g, false, false, nullptr, 4.0 * nb * N));
     }
   } else {
-    hipLaunchKernelGGL(open_step_kernel, dim3(1), dim3(64), 0, h->st, h->scal, 1, h->cfg.g_lr);
+    hipLaunchKernelGGL(open_step_kernel, dim3(1), dim3(64), 0, h->st, h->scal, 1, S_ALPHA_G, h->cfg.g_lr);
     HIP_TRY(hipGetLastError());
   }
   const bool reg = h->cfg.g_reg != 0.f;
@@ -746,7 +827,7 @@ int dis_forward(ganmf_handle* h, const int* rows_dev, int nb, int which) {
   {
     Scope s(h, T_DENSIFY, 0, 4.0 * nb * (N + 2 * k));
     hipLaunchKernelGGL(densify_rows_kernel, dim3(nb), dim3(256), 0, h->st, h->indptr, h->indices, h->data,
-                       rows_dev, nb, N, h->XF, h->ldN, h->Ue.p, h->ldk, h->Ub, h->scal, which,
+                       rows_dev, nb, N, h->XF, h->ldN, h->Ue.p, h->ldk, h->Ub, h->scal, which, which ? S_ALPHA_G : S_ALPHA_D,
                        which ? h->cfg.g_lr : h->cfg.d_lr, N + 1, (int)h->cfg.row_offset);
     HIP_TRY(hipGetLastError());
   }
@@ -830,16 +911,21 @@ int dis_d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float
     float* dz0;
     TRY(dis_backprop_hidden(h, 0, 2 * nb, true, b_global, &dz0));
   } else {
-    hipLaunchKernelGGL(open_step_kernel, dim3(1), dim3(64), 0, h->st, h->scal, 0, h->cfg.d_lr);
+    hipLaunchKernelGGL(open_step_kernel, dim3(1), dim3(64), 0, h->st, h->scal, 0, S_ALPHA_D, h->cfg.d_lr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemsetAsync(h->gD, 0, h->gD_elems * sizeof(float), h->st));
     HIP_TRY(hipMemsetAsync(h->lossrow, 0, (size_t)2 * h->B * sizeof(float), h->st));
   }
-  TRY(allreduce(h, h->gD, h->gD_elems));
   const bool reg = h->cfg.d_reg != 0.f;
-  for (int l = 0; l < h->L; ++l)
-    TRY(adam_dense(h, T_ADAM_D, h->Wl[l], h->Wl[l].g, S_ALPHA_D, h->cfg.d_reg, reg ? h->regp + (4 + l) * h->reg_cap : nullptr));
-  TRY(adam_dense(h, T_ADAM_D, h->Wo, h->Wo.g, S_ALPHA_D, h->cfg.d_reg, reg ? h->regp + (4 + h->L) * h->reg_cap : nullptr));
+  if (h->has_comm) {
+    for (int l = 0; l < h->L; ++l)
+      TRY(dp_update(h, T_ADAM_D, h->Wl[l], S_ALPHA_D, h->cfg.d_reg, reg ? h->regp + (4 + l) * h->reg_cap : nullptr, 0));
+    TRY(dp_update(h, T_ADAM_D, h->Wo, S_ALPHA_D, h->cfg.d_reg, reg ? h->regp + (4 + h->L) * h->reg_cap : nullptr, 0));
+  } else {
+    for (int l = 0; l < h->L; ++l)
+      TRY(adam_dense(h, T_ADAM_D, h->Wl[l], h->Wl[l].g, S_ALPHA_D, h->cfg.d_reg, reg ? h->regp + (4 + l) * h->reg_cap : nullptr));
+    TRY(adam_dense(h, T_ADAM_D, h->Wo, h->Wo.g, S_ALPHA_D, h->cfg.d_reg, reg ? h->regp + (4 + h->L) * h->reg_cap : nullptr));
+  }
   {  // parts = {sum sce(real), sum sce(fake), sum theta_D^2}
     MultiRed mr{};
     mr.out = parts;
@@ -890,7 +976,7 @@ int dis_g_step(ganmf_handle* h, const int* rows_dev, int nb, int start, int b_gl
       TRY(run_gemm(h, T_GEMM_DF, T_RED_DF, g, false, false));
     }
   } else {
-    hipLaunchKernelGGL(open_step_kernel, dim3(1), dim3(64), 0, h->st, h->scal, 1, h->cfg.g_lr);
+    hipLaunchKernelGGL(open_step_kernel, dim3(1), dim3(64), 0, h->st, h->scal, 1, S_ALPHA_G, h->cfg.g_lr);
     HIP_TRY(hipGetLastError());
   }
   const bool reg = h->cfg.g_reg != 0.f;
@@ -947,12 +1033,13 @@ int ensure_parts(ganmf_handle* h, int64_t steps) {
   HIP_TRY(hipStreamSynchronize(h->st));
   // capacity is only published once every buffer of the new size exists: a failing dalloc leaves cap 0 and null
   // pointers, so the next call allocates again instead of running on freed memory
-  hipFree(h->d_parts); hipFree(h->g_parts); hipFree(h->d_arena); hipFree(h->g_arena);
-  h->d_parts = h->g_parts = h->d_arena = h->g_arena = nullptr;
+  hipFree(h->d_parts); hipFree(h->g_parts); hipFree(h->d_arena); hipFree(h->g_arena); hipFree(h->colbuf);
+  h->d_parts = h->g_parts = h->d_arena = h->g_arena = h->colbuf = nullptr;
   h->parts_cap = 0;
   const int64_t cap = steps + 64;
   TRY(dalloc(&h->d_parts, (size_t)cap * 4));
   TRY(dalloc(&h->g_parts, (size_t)cap * 4));
+  TRY(dalloc(&h->colbuf, (size_t)cap));
   if (h->cfg.model == GANMF_MODEL_GANMF) {
     TRY(dalloc(&h->d_arena, (size_t)cap * 4 * h->reg_cap));
     TRY(dalloc(&h->g_arena, (size_t)cap * 4 * h->reg_cap));
@@ -969,14 +1056,12 @@ void finish_losses(const ganmf_handle* h, const std::vector<float>& dp, const st
   if (h->cfg.model == GANMF_MODEL_DISGANMF) {
     for (int64_t i = 0; i < nd && d_losses; ++i) {
       const float bg = (float)bglob[i % per_pass];
-      float sq = dp[4 * i + 2];
-      if (h->has_comm && h->cfg.world_size > 1) sq /= (float)h->cfg.world_size;   // replicated tensors: summed world times
+      const float sq = dp[4 * i + 2];     // (data-parallel: every rank summed its own slice; all-reduced = the whole tensor)
       d_losses[i] = (dp[4 * i] / bg + dp[4 * i + 1] / bg) + h->cfg.d_reg * (sq / 2.0f);
     }
     for (int64_t i = 0; i < ng && g_losses; ++i) {
       const float bg = (float)bglob[i % per_pass];
-      float sv = gp[4 * i + 3];
-      if (h->has_comm && h->cfg.world_size > 1) sv /= (float)h->cfg.world_size;
+      const float sv = gp[4 * i + 3];
       g_losses[i] = (gp[4 * i] / bg + alpha * (gp[4 * i + 1] / (bg * (float)h->e))) + h->cfg.g_reg * ((gp[4 * i + 2] + sv) / 2.0f);
     }
     return;
@@ -987,8 +1072,7 @@ void finish_losses(const ganmf_handle* h, const std::vector<float>& dp, const st
     const float bg = (float)bglob[i % per_pass];
     const float Lf = gp[4 * i] / (bg * (float)h->N);
     const float fm = gp[4 * i + 1] / (bg * (float)h->e);
-    float sv = gp[4 * i + 3];
-    if (h->has_comm && h->cfg.world_size > 1) sv /= (float)h->cfg.world_size;  // V is replicated
+    const float sv = gp[4 * i + 3];       // (data-parallel: slices of V, all-reduced)
     g_losses[i] = ((1.0f - alpha) * Lf + alpha * fm) + h->cfg.g_reg * ((gp[4 * i + 2] + sv) / 2.0f);
   }
 }
@@ -1097,28 +1181,29 @@ static int create_impl(const ganmf_cfg* cfg, ganmf_handle* h) {
   const int U = h->U, N = h->N, k = h->k, e = h->e, B = h->B;
   const bool dis = cfg->model == GANMF_MODEL_DISGANMF;
   // parameters; D gradients contiguous for a single all-reduce
-  TRY(alloc_tensor(h->Ue, U, k, false));
-  TRY(alloc_tensor(h->V, N, k, true));
+  const int world = std::max(1, (int)cfg->world_size);
+  TRY(alloc_tensor(h->Ue, U, k, false, 1));      // rows of U belong to their rank: never communicated
+  TRY(alloc_tensor(h->V, N, k, true, world));
   if (!dis) {
-    TRY(alloc_tensor(h->We, N + 1, e, false));   // We_ext: row N = encoder bias
-    TRY(alloc_tensor(h->Wd, e + 1, N, false, h->ldN));   // Wd_ext: row e = decoder bias; shares the leading dimension of the [.., N] work buffers
-    h->gD_elems = h->We.padded() + h->Wd.padded();
+    TRY(alloc_tensor(h->We, N + 1, e, false, world));   // We_ext: row N = encoder bias
+    TRY(alloc_tensor(h->Wd, e + 1, N, false, world, h->ldN));   // Wd_ext: row e = decoder bias; shares the leading dimension of the [.., N] work buffers
+    h->gD_elems = h->We.cap + h->Wd.cap;
     TRY(dalloc(&h->gD, h->gD_elems));
     h->We.g = h->gD;
-    h->Wd.g = h->We.g + h->We.padded();
+    h->Wd.g = h->We.g + h->We.cap;
   } else {
     h->L = cfg->d_layers; h->act = cfg->d_act;
     h->Wl.resize(h->L);
     h->gD_elems = 0;
     for (int l = 0; l < h->L; ++l) {
-      TRY(alloc_tensor(h->Wl[l], l == 0 ? N + 2 : e + 1, e, false));
-      h->gD_elems += h->Wl[l].padded();
+      TRY(alloc_tensor(h->Wl[l], l == 0 ? N + 2 : e + 1, e, false, world));
+      h->gD_elems += h->Wl[l].cap;
     }
-    TRY(alloc_tensor(h->Wo, 1, e + 1, false));
-    h->gD_elems += h->Wo.padded();
+    TRY(alloc_tensor(h->Wo, 1, e + 1, false, world));
+    h->gD_elems += h->Wo.cap;
     TRY(dalloc(&h->gD, h->gD_elems));
     float* gp = h->gD;
-    for (int l = 0; l < h->L; ++l) { h->Wl[l].g = gp; gp += h->Wl[l].padded(); }
+    for (int l = 0; l < h->L; ++l) { h->Wl[l].g = gp; gp += h->Wl[l].cap; }
     h->Wo.g = gp;
   }
   TRY(dalloc(&h->zero_page, 2048 + 64));   // 8 KiB: one 32-byte line per lane of a workgroup
@@ -1185,7 +1270,7 @@ int ganmf_destroy(ganmf_handle* h) {
   hipFree(h->XF); hipFree(h->Ub); hipFree(h->E); hipFree(h->Dl); hipFree(h->dE); hipFree(h->dF); hipFree(h->gUb);
   hipFree(h->slab); hipFree(h->rs); hipFree(h->scal); hipFree(h->sqp); hipFree(h->fmp);
   hipFree(h->seen_indptr); hipFree(h->seen_indices); hipFree(h->topk_items); hipFree(h->topk_vals); hipFree(h->sc_ids);
-  hipFree(h->regp); hipFree(h->d_parts); hipFree(h->g_parts); hipFree(h->d_arena); hipFree(h->g_arena); hipFree(h->sc_rows); hipFree(h->sc_out);
+  hipFree(h->regp); hipFree(h->colbuf); hipFree(h->d_parts); hipFree(h->g_parts); hipFree(h->d_arena); hipFree(h->g_arena); hipFree(h->sc_rows); hipFree(h->sc_out);
   for (auto& r : h->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
   if (h->st2) hipStreamSynchronize(h->st2);
   if (h->ev_fork) hipEventDestroy(h->ev_fork);
@@ -1367,10 +1452,22 @@ int ganmf_train_epoch(ganmf_handle* h, const int32_t* perm, int64_t n, int32_t d
       const int nb = (int)std::max<int64_t>(0, std::min<int64_t>(B, n - a));
       TRY(any_g_step(h, h->perm + std::min<int64_t>(a, std::max<int64_t>(n - 1, 0)), nb, (int)a, bglob[i], idx));
     }
+  TRY(dp_join(h));      // the last step's side-lane updates (and their sum(theta^2) partials) are complete
   TRY(arenas_finish(h, nd, ng));
-  // loss parts are sums over this rank's rows: one all-reduce per epoch.  (GANMF's D loss is formed on the device
-  // from the sums that were all-reduced before the hinge and is global already.)
-  if (dist && nd > 0 && h->cfg.model == GANMF_MODEL_DISGANMF) TRY(allreduce(h, h->d_parts, (size_t)nd * 4));
+  // loss parts are sums over this rank's rows / this rank's slices of the replicated tensors: one all-reduce per epoch.
+  // GANMF's D loss itself (column 0) is formed on the device from sums that were all-reduced before the hinge and is
+  // global already: only its sum(theta_D^2) column travels.
+  if (dist && nd > 0) {
+    if (h->cfg.model == GANMF_MODEL_DISGANMF) TRY(allreduce(h, h->d_parts, (size_t)nd * 4));
+    else {
+      const int grid = (int)std::min<int64_t>(256, (nd + 255) / 256);
+      hipLaunchKernelGGL(col_copy_kernel, dim3(grid), dim3(256), 0, h->st, h->d_parts, h->colbuf, (long long)nd, 2, 1);
+      HIP_TRY(hipGetLastError());
+      TRY(allreduce(h, h->colbuf, (size_t)nd));
+      hipLaunchKernelGGL(col_copy_kernel, dim3(grid), dim3(256), 0, h->st, h->d_parts, h->colbuf, (long long)nd, 2, 0);
+      HIP_TRY(hipGetLastError());
+    }
+  }
   if (dist && ng > 0) TRY(allreduce(h, h->g_parts, (size_t)ng * 4));
   std::vector<float> dp((size_t)std::max<int64_t>(nd, 1) * 4), gp((size_t)std::max<int64_t>(ng, 1) * 4);
   HIP_TRY(hipMemcpyAsync(dp.data(), h->d_parts, dp.size() * sizeof(float), hipMemcpyDeviceToHost, h->st));
@@ -1401,6 +1498,7 @@ int ganmf_train_step(ganmf_handle* h, int kind, const int32_t* uids, int32_t n, 
   TRY(arenas_begin(h, kind == 0, kind == 1));
   if (kind == 0) TRY(any_d_step(h, h->perm, n, n, 0));
   else TRY(any_g_step(h, h->perm, n, 0, n, 0));
+  TRY(dp_join(h));
   TRY(arenas_finish(h, kind == 0, kind == 1));
   std::vector<float> dp(4), gp(4);
   HIP_TRY(hipMemcpyAsync(dp.data(), h->d_parts, 4 * sizeof(float), hipMemcpyDeviceToHost, h->st));

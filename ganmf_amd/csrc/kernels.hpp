@@ -13,6 +13,8 @@ namespace ganmf {
 enum Scal : int {
   S_B1P_D = 0, S_B2P_D = 1, S_B1P_G = 2, S_B2P_G = 3,  // Adam beta powers (AdamOptimizer._finish)
   S_ALPHA_D = 4, S_ALPHA_G = 5,                        // lr_t of the step in flight
+  S_ALPHA_D_ALT = 6,                                   // lr_t of odd discriminator steps (data-parallel: step i's encoder update still
+                                                       // reads its lr_t on the side lane while step i+1 opens on the main lane)
   S_SUM_REAL = 8, S_SUM_FAKE = 9, S_SUM_FM = 10,        // sum of squares (local, then all-reduced)
   S_COUNT = 16
 };
@@ -46,12 +48,12 @@ __global__ __launch_bounds__(256) void densify_rows_kernel(const long long* __re
                                                            float* __restrict__ X, int ldx,
                                                            const float* __restrict__ Uemb, int ldk,
                                                            float* __restrict__ Ub, float* __restrict__ scal,
-                                                           int which, float lr, int uid_col, int row_offset) {
+                                                           int which, int alpha_idx, float lr, int uid_col, int row_offset) {
   const int b = blockIdx.x;
   if (b == 0 && threadIdx.x == 0) {
     const int o = which ? S_B1P_G : S_B1P_D;
     const float b1p = scal[o], b2p = scal[o + 1];
-    scal[which ? S_ALPHA_G : S_ALPHA_D] = lr * sqrtf(1.f - b2p) / (1.f - b1p);
+    scal[alpha_idx] = lr * sqrtf(1.f - b2p) / (1.f - b1p);
     scal[o] = b1p * ADAM_B1;
     scal[o + 1] = b2p * ADAM_B2;
   }
@@ -89,14 +91,14 @@ __global__ __launch_bounds__(256) void sparse_front_kernel(const long long* __re
                                                            float* __restrict__ XF, int ldx,
                                                            const float* __restrict__ Uemb, int ldk,
                                                            float* __restrict__ Ub, float* __restrict__ scal, int which,
-                                                           float lr, const float* __restrict__ We, int lde, int e,
-                                                           float* __restrict__ E) {
+                                                           int alpha_idx, float lr, const float* __restrict__ We, int lde,
+                                                           int e, float* __restrict__ E) {
   __shared__ float4 part[256];
   const int b = blockIdx.x, tid = threadIdx.x;
   if (b == 0 && tid == 0) {
     const int o = which ? S_B1P_G : S_B1P_D;
     const float b1p = scal[o], b2p = scal[o + 1];
-    scal[which ? S_ALPHA_G : S_ALPHA_D] = lr * sqrtf(1.f - b2p) / (1.f - b1p);
+    scal[alpha_idx] = lr * sqrtf(1.f - b2p) / (1.f - b1p);
     scal[o] = b1p * ADAM_B1;
     scal[o + 1] = b2p * ADAM_B2;
   }
@@ -140,11 +142,11 @@ __global__ __launch_bounds__(256) void sparse_front_kernel(const long long* __re
 }
 
 // Opens an optimizer step without any rows (a data-parallel rank that ran out of rows).
-__global__ void open_step_kernel(float* __restrict__ scal, int which, float lr) {
+__global__ void open_step_kernel(float* __restrict__ scal, int which, int alpha_idx, float lr) {
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     const int o = which ? S_B1P_G : S_B1P_D;
     const float b1p = scal[o], b2p = scal[o + 1];
-    scal[which ? S_ALPHA_G : S_ALPHA_D] = lr * sqrtf(1.f - b2p) / (1.f - b1p);
+    scal[alpha_idx] = lr * sqrtf(1.f - b2p) / (1.f - b1p);
     scal[o] = b1p * ADAM_B1;
     scal[o + 1] = b2p * ADAM_B2;
   }
@@ -199,6 +201,14 @@ __global__ __launch_bounds__(256) void finish_parts_kernel(const float* __restri
     float* p = parts + (size_t)blockIdx.x * 4;
     if (mode == 0) p[2] = tot[2] + tot[3];
     else { p[0] = tot[0]; p[1] = tot[1]; p[2] = tot[2]; p[3] = tot[3]; }
+  }
+}
+
+// column `col` of a [n][4] parts array <-> a contiguous vector (data-parallel: only the partial-sum columns are all-reduced)
+__global__ void col_copy_kernel(float* __restrict__ parts, float* __restrict__ vec, long long n, int col, int to_vec) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    if (to_vec) vec[i] = parts[4 * i + col];
+    else parts[4 * i + col] = vec[i];
   }
 }
 
