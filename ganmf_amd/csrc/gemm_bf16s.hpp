@@ -287,6 +287,7 @@ inline hipError_t gemm_bf16s_launch(hipStream_t st, const GemmP& p, bool akm, bo
 inline hipError_t gemm_dispatch_staged(hipStream_t st, const GemmP& p, bool akm, bool bkm, const GemmPlan& pl) {
   if (pl.mode == MFMA_F16)
     return pl.tile == 128 ? gemm_bf16s_launch<128, 128, 32, 1, true>(st, p, akm, bkm) : gemm_bf16s_launch<64, 64, 64, 1, true>(st, p, akm, bkm);
+  if (pl.mode == MFMA_BF16X3 && pl.tile == 64 && pl.bk == 32) return gemm_bf16s_launch<64, 64, 32, 3>(st, p, akm, bkm);
   if (pl.mode == MFMA_BF16X3)
     return pl.tile == 128 ? gemm_bf16s_launch<128, 128, 32, 3>(st, p, akm, bkm) : gemm_bf16s_launch<64, 64, 64, 3>(st, p, akm, bkm);
   return pl.tile == 128 ? gemm_bf16s_launch<128, 128, 32, 1>(st, p, akm, bkm) : gemm_bf16s_launch<64, 64, 64, 1>(st, p, akm, bkm);

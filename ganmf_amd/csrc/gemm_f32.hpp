@@ -696,6 +696,7 @@ struct GemmPlan {
   int mode = MFMA_F32;       // MfmaMode of the K loop
   int tiles_m = 0, tiles_n = 0;
   int persist = 0;           // 1: gemm_persist.hpp (one workgroup per CU walks a list of output tiles)
+  int bk = 0;                // staged bf16 kernels, 64 x 64 tiles: 32 = half-depth K-tiles (24 KiB of LDS: six workgroups per CU)
   int sq_count = 0;          // sq partial entries per batch this plan produces
   double est_us = 0;
 };
@@ -704,6 +705,7 @@ struct GemmTune {            // overrides (0 = automatic), settable from the env
   int tile = 0, ring = 0, nsplit = 0;
   int mode = MFMA_AUTO;      // MfmaMode of every plan; MFMA_AUTO: chosen per GEMM by gemm_plan
   int persist = -1;          // persistent tile-walking kernel: -1 automatic, 0 never, 1 whenever the GEMM is eligible
+  int bk = 0;                // GemmPlan::bk
 };
 
 inline void split_plan(int K, int want, int& nsplit, int& kps) {
@@ -758,6 +760,7 @@ inline GemmPlan gemm_plan(int M, int N, int K, int nbatch, bool wants_sq, const 
   // per workgroup that the split-bf16 loop wins on any grid (C4 shard: 955 vs 846 steps/s with every GEMM on it).
   const double gflop = 2.0 * M * (double)N * K * nbatch * 1e-9;
   best.mode = tune.mode != MFMA_AUTO ? tune.mode : (wgs >= 2 * GEMM_CUS || gflop >= 6.0 ? MFMA_BF16X3 : MFMA_F32);
+  best.bk = tune.bk;
   best.sq_count = wants_sq ? best.tiles_m * best.tiles_n : 0;   // (separate reduce kernel: GEMM_RED_GRID, set by gemm_run)
   return best;
 }

@@ -22,7 +22,7 @@ def test_shard_bounds_and_plan():
     assert steps == 48 and rows[0] == 1024 and rows[-1] == 8 * (6040 - 47 * 128)
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, sliced=False):
     import torch.distributed as dist
     import torch
     sys.path.insert(0, ROOT)
@@ -65,9 +65,26 @@ def _worker(rank, world, port, out):
                 dE = dR @ loc.p["Wd"].T
                 g["We"] += inp.T @ dE; g["be"] += dE.sum(0)
         for n in loc.D_NAMES:
-            t = torch.from_numpy(g[n]); dist.all_reduce(t)
-            g[n] = t.numpy() + hp["d_reg"] * loc.p[n]
-            loc.opt_d.apply_dense(n, loc.p[n], g[n])
+            if not sliced:
+                t = torch.from_numpy(g[n]); dist.all_reduce(t)
+                g[n] = t.numpy() + hp["d_reg"] * loc.p[n]
+                loc.opt_d.apply_dense(n, loc.p[n], g[n])
+                continue
+            # the library's form (ganmf_hip.hip dp_update): the summed gradient is only needed on the owner of each slice
+            # (reduce-scatter; gloo has none, an all-reduce of which the rank keeps its slice stands in), TF-Adam on that
+            # slice of the flattened, zero-padded parameter with moments that exist on the owner alone, then an
+            # all-gather of the parameter slices
+            flat = loc.p[n].reshape(-1)
+            slice_n = -(-flat.size // world)
+            gpad = np.zeros(slice_n * world); gpad[:flat.size] = g[n].reshape(-1)
+            ppad = np.zeros(slice_n * world); ppad[:flat.size] = flat
+            t = torch.from_numpy(gpad); dist.all_reduce(t)
+            sl = slice(rank * slice_n, (rank + 1) * slice_n)
+            mine = ppad[sl].copy()
+            loc.opt_d.apply_dense(n, mine, t.numpy()[sl] + hp["d_reg"] * mine)
+            parts = [torch.zeros(slice_n, dtype=torch.float64) for _ in range(world)]
+            dist.all_gather(parts, torch.from_numpy(mine))
+            loc.p[n][...] = torch.cat(parts).numpy()[:flat.size].reshape(loc.p[n].shape)
         loc.opt_d.finish()
         # reference: one oracle D-step on the union batch
         union = np.concatenate([np.arange(a + i * B, min(a + (i + 1) * B, b)) for a, b in bounds])
@@ -79,12 +96,15 @@ def _worker(rank, world, port, out):
     out.put((rank, "ok"))
 
 
-def test_sharded_d_steps_equal_union_batch_gloo():
+@pytest.mark.parametrize("sliced", [False, True])
+def test_sharded_d_steps_equal_union_batch_gloo(sliced):
+    """sliced = False: all-reduce + replicated Adam; True: reduce-scatter / Adam on the rank's slice / all-gather (what the
+    library runs since round 2).  Both must equal the single-process oracle on the union batches."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29500 + (os.getpid() % 2000) + (7 if sliced else 0)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, sliced)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
