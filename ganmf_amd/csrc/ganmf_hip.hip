@@ -447,8 +447,8 @@ int run_gemm(ganmf_handle* h, int tag_gemm, int tag_red, GemmP g, bool akm, bool
     const long long key = ((long long)tag_gemm << 48) ^ ((long long)g.M << 32) ^ ((long long)g.N << 16) ^ g.K;
     if (std::find(h->seen_plans.begin(), h->seen_plans.end(), key) == h->seen_plans.end()) {
       h->seen_plans.push_back(key);
-      fprintf(stderr, "[ganmf plan] %-28s M=%d N=%d K=%d batch=%d -> tile %d ring %d nsplit %d (kps %d) mfma %s wgs %d est %.1f us%s\n",
-              kTagName[tag_gemm], g.M, g.N, g.K, g.nbatch, pl.tile, pl.ring, pl.nsplit, pl.kps,
+      fprintf(stderr, "[ganmf plan] %-28s M=%d N=%d K=%d batch=%d -> tile %d ring %d kg %d nsplit %d (kps %d) mfma %s wgs %d est %.1f us%s\n",
+              kTagName[tag_gemm], g.M, g.N, g.K, g.nbatch, pl.tile, pl.ring, pl.kg, pl.nsplit, pl.kps,
               pl.mode == MFMA_BF16X3 ? "bf16x3" : pl.mode == MFMA_BF16 ? "bf16" : pl.mode == MFMA_F16 ? "f16" : "f32",
               pl.tiles_m * pl.tiles_n * pl.nsplit * g.nbatch, pl.est_us,
               pl.persist ? " (persistent tile walk)" : in_launch ? " (in-launch reduce)" : "");
@@ -1173,6 +1173,8 @@ static int create_impl(const ganmf_cfg* cfg, ganmf_handle* h) {
   h->tune.nsplit = std::max(0, env_int("GANMF_NSPLIT", 0));
   h->tune.mode = env_mfma_mode((cfg->flags & GANMF_FLAG_MFMA_F16) ? MFMA_F16 : (cfg->flags & GANMF_FLAG_MFMA_BF16) ? MFMA_BF16 : (cfg->flags & GANMF_FLAG_MFMA_F32) ? MFMA_F32 : MFMA_DEFAULT);
   h->tune.persist = env_int("GANMF_PERSIST", -1);
+  h->tune.kg = env_int("GANMF_KG", 0);
+  if (h->tune.kg != 0 && h->tune.kg != 1 && h->tune.kg != 2 && h->tune.kg != 4) h->tune.kg = 0;
   h->debug_plan = env_int("GANMF_DEBUG_PLAN", 0) != 0;
   h->fused_mode = env_int("GANMF_FUSED_X3", 1) ? MFMA_BF16X3 : MFMA_F32;
   h->fused_bk = env_int("GANMF_FUSED_BK", 32);   // 24 KiB of LDS per workgroup: six co-resident workgroups hide the
@@ -1755,6 +1757,8 @@ int ganmf_gemm_f32(int device, const float* A, const float* B, float* C, int64_t
   tune.ring = env_int("GANMF_RING", 0);
   if (tune.ring != 0 && tune.ring != 2 && tune.ring != 3 && tune.ring != 4) tune.ring = 0;
   tune.persist = env_int("GANMF_PERSIST", -1);
+  tune.kg = env_int("GANMF_KG", 0);
+  if (tune.kg != 0 && tune.kg != 1 && tune.kg != 2 && tune.kg != 4) tune.kg = 0;
   GemmPlan pl = gemm_plan(g.M, g.N, g.K, 1, false, tune);
   pl.persist = gemm_persist_eligible(g, a_kmajor, b_kmajor, pl, tune.persist) ? (tune.persist >= 2 ? tune.persist : 1) : 0;
   const size_t slab_elems = gemm_slab_elems(pl, g.M, ldc, 1);

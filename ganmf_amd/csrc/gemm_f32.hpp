@@ -347,18 +347,23 @@ __device__ inline int xcd_remap(int bid, int nwg) {
 // row = (reg&3) + 8*(reg>>2) + 4*(lane>>5), i.e. a lane owns a column.  `smem` must hold BM*BN floats and be idle.
 struct TileCoord { int tm, tn, sp, bz, m0, n0; };
 
-template <int BM, int BN, int TM, int TN>
+// KG > 1: the workgroup has KG groups of four waves that each hold a partial sum of the SAME tile (they split the
+// chunks of every K-tile between them, gemm_f32_mfma); group g stages its accumulators at smem + g * BM * BN and the row
+// pass adds the KG images in group order (fixed order: bitwise reproducible).
+template <int BM, int BN, int TM, int TN, int KG = 1>
 __device__ inline void gemm_epilogue(const GemmP& p, const f32x16 (&acc)[TM][TN], float* smem, const TileCoord& tc_) {
   constexpr int WM = BM / 2, WN = BN / 2;
+  constexpr int NTHR = 256 * KG;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 1, wc = wave & 1;
+  const int kg = wave >> 2;
+  const int wr = (wave >> 1) & 1, wc = wave & 1;
   const int li = lane & 31, lh = lane >> 5;
   const int tm = tc_.tm, tn = tc_.tn, sp = tc_.sp, bz = tc_.bz, m0 = tc_.m0, n0 = tc_.n0;
   // Stored straight from registers that is one dword per lane per
   // instruction (measured ~2 TB/s chip-wide on 15-90 MB outputs); instead the tile is staged
   // through the now idle ring as a natural [BM][BN] image and written as whole rows, 16 B per lane.
-  float* __restrict__ ct = smem;
+  float* __restrict__ ct = smem + kg * (BM * BN);
 #pragma unroll
   for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -373,7 +378,9 @@ __device__ inline void gemm_epilogue(const GemmP& p, const f32x16 (&acc)[TM][TN]
   const EpiD& e = p.epi;
   const float* __restrict__ aux = e.aux ? e.aux + (size_t)bz * e.aux_batch_stride : nullptr;
   float sq = 0.f;
-  constexpr int C4 = BN / 4, RPP = 256 / C4;
+  constexpr int C4 = BN / 4, RPP = NTHR / C4;
+  static_assert(BM % RPP == 0, "row pass must cover the tile in whole steps");
+  ct = smem;
   const int tc = tid % C4, tr = tid / C4;
   const int col = n0 + tc * 4;
   const bool adam = !deferred && e.kind == EPI_ADAM;
@@ -385,7 +392,12 @@ __device__ inline void gemm_epilogue(const GemmP& p, const f32x16 (&acc)[TM][TN]
   for (int j = 0; j < BM / RPP; ++j) {
     const int row_l = tr + j * RPP, row = m0 + row_l;
     if (row < p.M && col < p.N) {
-      const float4 v = *reinterpret_cast<const float4*>(ct + row_l * BN + tc * 4);
+      float4 v = *reinterpret_cast<const float4*>(ct + row_l * BN + tc * 4);
+#pragma unroll
+      for (int g = 1; g < KG; ++g) {
+        const float4 w = *reinterpret_cast<const float4*>(ct + g * (BM * BN) + row_l * BN + tc * 4);
+        v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+      }
       float o[4] = {v.x, v.y, v.z, v.w};
       if (adam) {   // the tile is a gradient: update parameter and moments in place (never stored)
         const size_t off = (size_t)row * p.ldc + col;
@@ -484,15 +496,25 @@ __device__ inline void gemm_epilogue(const GemmP& p, const f32x16 (&acc)[TM][TN]
     __syncthreads();   // every wave is done reading the staged tile / the flag
     if (lane == 0) smem[wave] = sq;
     __syncthreads();
-    if (tid == 0)
-      e.sq_partials[(size_t)bz * e.sq_stride + tn * p.tiles_m + tm] = (smem[0] + smem[1]) + (smem[2] + smem[3]);
+    if (tid == 0) {
+      float t = (smem[0] + smem[1]) + (smem[2] + smem[3]);
+#pragma unroll
+      for (int g = 1; g < KG; ++g) t += (smem[4 * g] + smem[4 * g + 1]) + (smem[4 * g + 2] + smem[4 * g + 3]);
+      e.sq_partials[(size_t)bz * e.sq_stride + tn * p.tiles_m + tm] = t;
+    }
   }
 }
 
-template <int BM, int BN, int BK, int NS, bool AKM, bool BKM>
-__global__ __launch_bounds__(256) void gemm_f32_mfma(const GemmP p) {
-  using SA = Stage<BM, BK, AKM>;
-  using SB = Stage<BN, BK, BKM>;
+// KG (1, 2 or 4) groups of four waves share ONE output tile: the groups stage the K-tiles together (every wave issues
+// its share of the LDS-DMA pieces) and split the 8-wide chunks of each K-tile between them, chunk c to group c % KG, so a
+// CU that holds a single workgroup still has KG waves per SIMD -- one wave's fragment reads, piece issue and barrier
+// waits run under another's MFMAs (a single in-order wave per SIMD loses 15-30 % of the MFMA rate to them:
+// profiles/README.md).  The partial sums meet in the epilogue through LDS.
+template <int BM, int BN, int BK, int NS, bool AKM, bool BKM, int KG = 1>
+__global__ __launch_bounds__(256 * KG) void gemm_f32_mfma(const GemmP p) {
+  constexpr int NTHR = 256 * KG;
+  using SA = Stage<BM, BK, AKM, NTHR>;
+  using SB = Stage<BN, BK, BKM, NTHR>;
   constexpr int WM = BM / 2, WN = BN / 2;
   constexpr int TM = WM / 32, TN = WN / 32;
   static_assert(TM >= 1 && TN >= 1, "wave tile must hold at least one 32x32 MFMA block");
@@ -504,7 +526,8 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const GemmP p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 1, wc = wave & 1;
+  const int kg = wave >> 2;                       // K group of this wave
+  const int wr = (wave >> 1) & 1, wc = wave & 1;
   const int li = lane & 31, lh = lane >> 5;
 
   int t = xcd_remap(blockIdx.x, gridDim.x);
@@ -531,9 +554,11 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const GemmP p) {
   la.init(p.A + (size_t)bz * p.a_batch_stride, p.lda, m0, p.M, kbeg, p.zero_page, tid);
   lb.init(p.B, p.ldb, n0, p.N, kbeg, p.zero_page, tid);
 
-  constexpr int NC = BK / 8;   // 8-wide k chunks per tile (even: chunk c uses fragment set c & 1)
+  constexpr int NC = BK / 8 / KG;   // 8-wide k chunks per tile and K group (even: local chunk c uses fragment set c & 1)
+  static_assert((BK / 8) % KG == 0 && NC >= 2 && NC % 2 == 0, "chunks per K group");
   float4 fa[2][TM], fb[2][TN];
-  auto load_frags = [&](int set, const float* __restrict__ tile, int c) {
+  auto load_frags = [&](int set, const float* __restrict__ tile, int cl) {
+    const int c = cl * KG + kg;     // chunk of the K-tile behind this group's local chunk cl
 #pragma unroll
     for (int a = 0; a < TM; ++a) fa[set][a] = SA::frag(tile, wr * WM + a * 32, c, li, lh);
 #pragma unroll
@@ -630,7 +655,8 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const GemmP p) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
-  gemm_epilogue<BM, BN, TM, TN>(p, acc, smem, TileCoord{tm, tn, sp, bz, m0, n0});
+  static_assert(KG * BM * BN <= NS * BUF, "the ring must hold the KG staged partial tiles");
+  gemm_epilogue<BM, BN, TM, TN, KG>(p, acc, smem, TileCoord{tm, tn, sp, bz, m0, n0});
 }
 
 // Reduce split-K slabs and apply the deferred epilogue: out[m,n] = epi(sum_s part[s][m,n]).
@@ -697,6 +723,7 @@ struct GemmPlan {
   int tiles_m = 0, tiles_n = 0;
   int persist = 0;           // 1: gemm_persist.hpp (one workgroup per CU walks a list of output tiles)
   int bk = 0;                // staged bf16 kernels, 64 x 64 tiles: 32 = half-depth K-tiles (24 KiB of LDS: six workgroups per CU)
+  int kg = 1;                // fp32 ring kernel, 64 x 64 tiles: K groups of four waves per workgroup (1, 2 or 4)
   int sq_count = 0;          // sq partial entries per batch this plan produces
   double est_us = 0;
 };
@@ -706,6 +733,7 @@ struct GemmTune {            // overrides (0 = automatic), settable from the env
   int mode = MFMA_AUTO;      // MfmaMode of every plan; MFMA_AUTO: chosen per GEMM by gemm_plan
   int persist = -1;          // persistent tile-walking kernel: -1 automatic, 0 never, 1 whenever the GEMM is eligible
   int bk = 0;                // GemmPlan::bk
+  int kg = 0;                // GemmPlan::kg (0 = automatic)
 };
 
 inline void split_plan(int K, int want, int& nsplit, int& kps) {
@@ -720,18 +748,27 @@ inline void split_plan(int K, int want, int& nsplit, int& kps) {
 // Cost model (cycles at ~2.1 GHz under fp32 MFMA load).  Every GEMM of the step is small
 // (<= 1.9 GFLOP, >= 12 us at the MFMA roof), so the plan is about filling 256 CUs evenly and
 // keeping each workgroup's serial K-walk short; split-K pays a slab round trip + one launch.
+// Tile shapes of the fp32 ring kernel: code -> BM x BN x BK, measured cycles per K-tile and fixed cycles per workgroup.
+// (A tall 128 x 64 x 64 tile -- 48 KiB slots, 25 % fewer operand bytes per FLOP than 64 x 64 x 64 -- was built and measured
+// in round 2: 5900 cycles per 4096-cycle K-tile, the same 70 % as the 64 x 64 tile, and its coarser K split costs more
+// slabs: 31.9 vs 28.7 us on the encode GEMM.  Not kept.)
+struct TileShape { int code, bm, bn, bk; double cyc_tile, fixed; };
+constexpr TileShape kTileShapes[2] = {
+    {128, 128, 128, 32, 4800.0, 9000.0},   // measured 2.4 us per K-tile
+    {64, 64, 64, 64, 2900.0, 6000.0},      // measured 1.25 us per K-tile: 16 B/clk/CU through L2 -> LDS
+};
+
 inline GemmPlan gemm_plan(int M, int N, int K, int nbatch, bool wants_sq, const GemmTune& tune, bool no_split = false) {
   GemmPlan best;
   best.est_us = 1e30;
-  const int tiles[2] = {128, 64};
-  for (int ti = 0; ti < 2; ++ti) {
-    const int tile = tiles[ti];
+  const double gflop = 2.0 * M * (double)N * K * nbatch * 1e-9;
+  for (const TileShape& ts : kTileShapes) {
+    const int tile = ts.code;
     if (tune.tile && tune.tile != tile) continue;
-    const int tm = (M + tile - 1) / tile, tn = (N + tile - 1) / tile;
+    const int tm = (M + ts.bm - 1) / ts.bm, tn = (N + ts.bn - 1) / ts.bn;
     const long long T = (long long)tm * tn * nbatch;
-    const int bk = tile == 128 ? 32 : 64;
-    // 64x64 tiles move 16 B/clk/CU through L2 -> LDS, above what L2/MALL sustains chip-wide
-    const double cyc_tile = tile == 128 ? 4800.0 : 2900.0;   // measured 2.4 / 1.25 us per K-tile
+    const int bk = ts.bk;
+    const double cyc_tile = ts.cyc_tile;
     const int max_split = no_split ? 1 : std::max(1, (K + GEMM_K_ALIGN - 1) / GEMM_K_ALIGN);
     for (int want = 1; want <= max_split; want = want < 4 ? want + 1 : want + (want + 3) / 4) {
       if (tune.nsplit) want = std::min(tune.nsplit, max_split);   // forced: evaluate exactly this one
@@ -739,7 +776,7 @@ inline GemmPlan gemm_plan(int M, int N, int K, int nbatch, bool wants_sq, const 
       split_plan(K, want, ns, kps);
       const long long wgs = T * ns;
       const double k_tiles = std::ceil((double)std::min(kps, K) / bk);
-      const double per_wg = (tile == 128 ? 9000.0 : 6000.0) + k_tiles * cyc_tile;   // prologue + epilogue + K walk (K sweep, MI355X)
+      const double per_wg = ts.fixed + k_tiles * cyc_tile;   // prologue + epilogue + K walk (K sweep, MI355X)
       const double rounds = std::ceil((double)wgs / GEMM_CUS);
       double us = rounds * per_wg / 2100.0;
       if (ns > 1) us += 1.5 + (double)(ns + 1) * M * N * nbatch * 4.0 / 3.0e6;   // in-launch reduce tail + slab traffic at ~3 TB/s
@@ -758,9 +795,12 @@ inline GemmPlan gemm_plan(int M, int N, int K, int nbatch, bool wants_sq, const 
   // (256x3706x2048 on 232 workgroups: 48 vs 57 us).  Every K-heavy 128/256-row GEMM of the C2 step is planned onto
   // <= 256 workgroups and stays fp32.  GEMMs of >= 6 GFLOP (the C4-sized steps: K or N = 50 000) run long enough
   // per workgroup that the split-bf16 loop wins on any grid (C4 shard: 955 vs 846 steps/s with every GEMM on it).
-  const double gflop = 2.0 * M * (double)N * K * nbatch * 1e-9;
   best.mode = tune.mode != MFMA_AUTO ? tune.mode : (wgs >= 2 * GEMM_CUS || gflop >= 6.0 ? MFMA_BF16X3 : MFMA_F32);
   best.bk = tune.bk;
+  // K groups: a 64 x 64 workgroup that has its CU to itself (ring 3: 96 KiB) runs 16 waves, four per SIMD (C2 step:
+  // 6130 -> 6660 steps/s with two per SIMD, 6760-6830 with four); co-resident ring-2 workgroups already interleave
+  best.kg = (best.tile == 64 && best.mode == MFMA_F32 && best.ring <= 3) ? (tune.kg ? tune.kg : (best.ring == 3 ? 4 : 1)) : 1;
+  if (best.kg == 4 && best.ring != 3) best.kg = 2;
   best.sq_count = wants_sq ? best.tiles_m * best.tiles_n : 0;   // (separate reduce kernel: GEMM_RED_GRID, set by gemm_run)
   return best;
 }
@@ -769,13 +809,13 @@ inline size_t gemm_slab_elems(const GemmPlan& pl, int M, int ldc, int nbatch) {
   return pl.nsplit > 1 ? (size_t)pl.nsplit * nbatch * M * ldc : 0;
 }
 
-template <int BM, int BN, int BK, int NS>
+template <int BM, int BN, int BK, int NS, int KG = 1>
 inline hipError_t gemm_launch_t(hipStream_t st, const GemmP& p, bool akm, bool bkm) {
   const int grid = p.tiles_m * p.tiles_n * p.nsplit * p.nbatch;
   if (grid <= 0) return hipSuccess;
-  if (!akm && !bkm) hipLaunchKernelGGL((gemm_f32_mfma<BM, BN, BK, NS, false, false>), dim3(grid), dim3(256), 0, st, p);
-  else if (!akm && bkm) hipLaunchKernelGGL((gemm_f32_mfma<BM, BN, BK, NS, false, true>), dim3(grid), dim3(256), 0, st, p);
-  else if (akm && bkm) hipLaunchKernelGGL((gemm_f32_mfma<BM, BN, BK, NS, true, true>), dim3(grid), dim3(256), 0, st, p);
+  if (!akm && !bkm) hipLaunchKernelGGL((gemm_f32_mfma<BM, BN, BK, NS, false, false, KG>), dim3(grid), dim3(256 * KG), 0, st, p);
+  else if (!akm && bkm) hipLaunchKernelGGL((gemm_f32_mfma<BM, BN, BK, NS, false, true, KG>), dim3(grid), dim3(256 * KG), 0, st, p);
+  else if (akm && bkm) hipLaunchKernelGGL((gemm_f32_mfma<BM, BN, BK, NS, true, true, KG>), dim3(grid), dim3(256 * KG), 0, st, p);
   else return hipErrorInvalidValue;  // TT is not needed by the GANMF step
   return hipGetLastError();
 }
@@ -822,6 +862,8 @@ inline hipError_t gemm_dispatch(hipStream_t st, const GemmP& p, bool akm, bool b
   if (pl.persist) return gemm_dispatch_persist(st, p, akm, bkm, pl);
   if (pl.mode == MFMA_BF16 || pl.mode == MFMA_BF16X3 || pl.mode == MFMA_F16) return gemm_dispatch_staged(st, p, akm, bkm, pl);
   if (pl.tile == 128) return pl.ring >= 3 ? gemm_launch_t<128, 128, 32, 3>(st, p, akm, bkm) : gemm_launch_t<128, 128, 32, 2>(st, p, akm, bkm);
+  if (pl.kg == 2) return pl.ring == 3 ? gemm_launch_t<64, 64, 64, 3, 2>(st, p, akm, bkm) : gemm_launch_t<64, 64, 64, 2, 2>(st, p, akm, bkm);
+  if (pl.kg == 4) return gemm_launch_t<64, 64, 64, 3, 4>(st, p, akm, bkm);
   if (pl.ring == 4) return gemm_launch_t<64, 64, 64, 4>(st, p, akm, bkm);   // 128 KiB ring: three K-tiles (96 KiB) in flight
   return pl.ring == 3 ? gemm_launch_t<64, 64, 64, 3>(st, p, akm, bkm) : gemm_launch_t<64, 64, 64, 2>(st, p, akm, bkm);
 }

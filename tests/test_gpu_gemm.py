@@ -84,3 +84,26 @@ def test_gemm_persistent_tile_walk(shape, waves, monkeypatch):
     monkeypatch.setenv("GANMF_PERSIST", "0")
     plain, _ = gemm_f32(A, B, False, False, tile=128)
     np.testing.assert_array_equal(out, plain)
+
+
+@pytest.mark.parametrize("akm,bkm", LAYOUTS)
+@pytest.mark.parametrize("kg", ["1", "2", "4"])
+@pytest.mark.parametrize("ring", ["2", "3"])
+@pytest.mark.parametrize("shape,nsplit", [((256, 992, 3707), 4), ((128, 250, 3706), 0), ((65, 70, 130), 1), ((1, 1, 1), 1),
+                                           ((200, 3706, 96), 1), ((130, 129, 64), 1)])
+def test_gemm_k_groups(akm, bkm, kg, ring, shape, nsplit, monkeypatch):
+    """64 x 64 fp32 ring kernel with KG groups of four waves per workgroup (GANMF_KG; the groups split the 8-wide chunks of
+    every K-tile and their partial tiles meet through LDS in the epilogue): every layout, both ring depths, ragged edges,
+    K shorter than one K-tile, split-K on top.  Same error bound as the one-group kernel, and run-to-run identical."""
+    from ganmf_amd.engine import gemm_f32
+    M, N, K = shape
+    rng = np.random.RandomState(M + 3 * N + 7 * K)
+    A, B, ref, bound = _mk(rng, M, N, K, akm, bkm)
+    monkeypatch.setenv("GANMF_MFMA", "f32")
+    monkeypatch.setenv("GANMF_KG", kg)
+    monkeypatch.setenv("GANMF_RING", ring)
+    out, _ = gemm_f32(A, B, akm, bkm, tile=64, nsplit=nsplit)
+    err = np.abs(out - ref)
+    assert np.all(err <= 4e-7 * bound * np.sqrt(K) + 1e-30), float((err / (bound + 1e-30)).max())
+    again, _ = gemm_f32(A, B, akm, bkm, tile=64, nsplit=nsplit)
+    np.testing.assert_array_equal(out, again)

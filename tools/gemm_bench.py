@@ -15,6 +15,8 @@ SETS = {
     "step": [("NT", 128, 3706, 250), ("NN", 256, 992, 3707), ("NN", 256, 3706, 993), ("NT", 256, 992, 3706),
              ("TN", 993, 3706, 256), ("TN", 3707, 992, 256), ("NT", 128, 3706, 992), ("NN", 128, 250, 3706),
              ("TN", 3706, 250, 128), ("NT", 6040, 3706, 250)],
+    # the K-heavy GEMMs of the C2 step whose outputs are too small to fill the chip without split-K
+    "skinny": [("NN", 256, 992, 3707), ("NT", 256, 992, 3706), ("NT", 128, 992, 3706), ("NN", 128, 250, 3706)],
 }
 
 
