@@ -36,6 +36,7 @@
 #include "gemm_bf16s.hpp"
 #include "gemm_persist.hpp"
 #include "kernels.hpp"
+#include "gemm_multi.hpp"
 
 using namespace ganmf;
 
@@ -195,6 +196,11 @@ struct ganmf_handle {
   float* fmp = nullptr;   // [RED_GRID]
   float* regp = nullptr;  // [slots][reg_cap] block partials of sum(theta^2): We_ext, Wd_ext, U, V, (DisGANMF layers)
   int reg_cap = 0;
+  bool defer_gub = true;  // the split-K slabs of gUb are summed by adam_rows_kernel (no reduce launch)
+  int multi = 7;          // combined launches (gemm_multi.hpp), bit 0: generator GEMM + CSR row expansion, bit 1: gUb + gV,
+                          // bit 2: slab sum of dE inside the gWd launch (GANMF_MULTI)
+  float* V_alt = nullptr; // second parameter buffer of item_embeddings: the fused gV update is written there while gUb
+                          // still reads the old V in the same launch; swapped with V.p after the launch
   bool fuse_adam = true;  // single GPU: Adam runs in the epilogue of the weight-gradient GEMMs
   float *d_parts = nullptr, *g_parts = nullptr;  // [cap][4]
   float* colbuf = nullptr;                       // [cap] one column of d_parts on its way through an all-reduce
@@ -424,22 +430,33 @@ int ensure_slab(ganmf_handle* h, size_t elems, int lane) {
 
 // One logical GEMM of the step: plan (tile / ring / split-K), launch, and when split the reduce
 // kernel that applies the epilogue.  *sq_count = partial sums per batch written to epi.sq_partials.
+// `defer` (plain-store GEMMs only): a split product is left as its slabs for the CONSUMER kernel to sum in split order
+// (one launch less); the slabs live in the second workspace so that the GEMMs in between may use the first.
+struct SlabRef { const float* p; int nsplit; long long split_stride; };
+
+// `defer_red`: a split product is launched WITHOUT its reduce kernel; the RedP that finishes it (slab sum + epilogue) is
+// handed back (part != nullptr) for the caller to attach to a later launch.  `attach`: such a RedP of ANOTHER product, run
+// as extra blocks of this GEMM's launch when the plan allows (gemm_bf16s_red), else as its own kernel first.
 int run_gemm(ganmf_handle* h, int tag_gemm, int tag_red, GemmP g, bool akm, bool bkm, int* sq_count = nullptr,
-             double extra_bytes = 0, int lane = 0, const GemmTune* force = nullptr) {
+             double extra_bytes = 0, int lane = 0, const GemmTune* force = nullptr, SlabRef* defer = nullptr,
+             RedP* defer_red = nullptr, const RedP* attach = nullptr) {
   if (g.nbatch < 1) g.nbatch = 1;
   g.zero_page = h->zero_page;
   hipStream_t st = lane ? h->st2 : h->st;
   const GemmTune& tn = force ? *force : h->tune;
   GemmPlan pl = gemm_plan(g.M, g.N, g.K, g.nbatch, g.epi.sq_partials != nullptr, tn, g.epi.kind == EPI_ADAM);
   pl.persist = gemm_persist_eligible(g, akm, bkm, pl, tn.persist) ? (tn.persist >= 2 ? tn.persist : 1) : 0;
-  if (pl.nsplit > 1) TRY(ensure_slab(h, gemm_slab_elems(pl, g.M, g.ldc, g.nbatch), lane));
-  float* slab = lane ? h->slab2 : h->slab;
-  const size_t slab_elems = lane ? h->slab2_elems : h->slab_elems;
+  if (defer) *defer = SlabRef{g.C, 1, 0};
+  const bool deferred = defer && pl.nsplit > 1 && g.epi.kind == EPI_STORE && g.nbatch == 1;
+  const int slab_lane = deferred ? 1 : lane;
+  if (pl.nsplit > 1) TRY(ensure_slab(h, gemm_slab_elems(pl, g.M, g.ldc, g.nbatch), slab_lane));
+  float* slab = slab_lane ? h->slab2 : h->slab;
+  const size_t slab_elems = slab_lane ? h->slab2_elems : h->slab_elems;
   unsigned* counters = h->inkernel_reduce ? (lane ? h->counters2 : h->counters) : nullptr;
   const size_t n_tiles = (size_t)pl.tiles_m * pl.tiles_n * g.nbatch;
   // the last-arriving workgroup reads nsplit slab tiles alone (~60-120 GB/s per block): in-launch
   // reduction only pays for shallow splits; deep splits keep the chip-wide reduce kernel
-  const bool in_launch = pl.nsplit > 1 && pl.nsplit <= h->inlaunch_max && counters && n_tiles <= (size_t)COUNTER_CAP;
+  const bool in_launch = !deferred && pl.nsplit > 1 && pl.nsplit <= h->inlaunch_max && counters && n_tiles <= (size_t)COUNTER_CAP;
   const bool wants_sq = g.epi.sq_partials != nullptr;
   const int sqc = !wants_sq ? 0 : (pl.nsplit > 1 && !in_launch ? GEMM_RED_GRID : pl.sq_count);
   if (sq_count) *sq_count = sqc;
@@ -455,6 +472,50 @@ int run_gemm(ganmf_handle* h, int tag_gemm, int tag_red, GemmP g, bool akm, bool
     }
   }
   const double fl = g.nbatch * gemm_flops(g.M, g.N, g.K), by = gemm_bytes((double)g.nbatch * g.M, g.N, g.K) + extra_bytes;
+  if (defer_red) defer_red->part = nullptr;
+  if (attach && attach->part) {
+    const int n4 = (attach->N + 3) / 4;
+    const int nred = (int)std::min<long long>(GEMM_RED_GRID, ((long long)attach->M * n4 + 255) / 256);
+    const bool combined = pl.mode == MFMA_BF16X3 && pl.tile == 64 && pl.bk == 32 && pl.nsplit == 1 && akm && bkm &&
+                          !pl.persist && g.nbatch == 1 && attach->epi.sq_partials == nullptr && !h->prof;
+    if (combined) {
+      GemmP q = g;
+      fill_plan(q, pl);
+      const int ng = pl.tiles_m * pl.tiles_n;
+      hipLaunchKernelGGL(gemm_bf16s_red, dim3(ng + nred), dim3(256), 0, st, q, *attach, nred);
+      HIP_TRY(hipGetLastError());
+      return 0;
+    }
+    {
+      Scope s(h, tag_red, 0, 4.0 * (attach->nsplit + 1) * attach->M * attach->N, st);
+      RedP r = *attach;
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(GEMM_RED_GRID, 1), dim3(256), 0, st, r);
+      HIP_TRY(hipGetLastError());
+    }
+  }
+  if (defer_red && pl.nsplit > 1 && !in_launch && !deferred && g.nbatch == 1) {    // GEMM now, its reduce rides in a later launch
+    Scope s(h, tag_gemm, fl, by, st);
+    GemmP q = g;
+    fill_plan(q, pl);
+    q.C = slab; q.c_split_stride = (long long)g.M * g.ldc; q.c_batch_stride = (long long)g.M * g.ldc;
+    HIP_TRY(gemm_dispatch(st, q, akm, bkm, pl));
+    RedP r{};
+    r.part = slab; r.nsplit = pl.nsplit; r.out = g.C; r.ld = g.ldc; r.M = g.M; r.N = g.N;
+    r.batch_stride = g.c_batch_stride; r.epi = g.epi; r.epi.sq_stride = GEMM_RED_GRID;
+    r.split_stride = (long long)g.M * g.ldc;
+    *defer_red = r;
+    if (sq_count && wants_sq) *sq_count = GEMM_RED_GRID;
+    return 0;
+  }
+  if (deferred) {     // slabs only: the consumer sums them
+    Scope s(h, tag_gemm, fl, by + 4.0 * pl.nsplit * g.M * g.N, st);
+    GemmP q = g;
+    q.tiles_m = pl.tiles_m; q.tiles_n = pl.tiles_n; q.nsplit = pl.nsplit; q.k_per_split = pl.kps; q.counters = nullptr;
+    q.C = slab; q.c_split_stride = (long long)g.M * g.ldc; q.c_batch_stride = (long long)g.M * g.ldc;
+    HIP_TRY(gemm_dispatch(st, q, akm, bkm, pl));
+    *defer = SlabRef{slab, pl.nsplit, (long long)g.M * g.ldc};
+    return 0;
+  }
   if (!h->prof || pl.nsplit == 1 || in_launch) {
     Scope s(h, tag_gemm, fl, by + (pl.nsplit > 1 ? 8.0 * pl.nsplit * g.nbatch * g.M * g.N : 0), st);
     HIP_TRY(gemm_run(st, g, akm, bkm, pl, slab, slab_elems, in_launch ? counters : nullptr, COUNTER_CAP));
@@ -526,6 +587,45 @@ int dp_update(ganmf_handle* h, int tag, Tensor& t, int alpha_idx, float reg, flo
   return 0;
 }
 
+// CSR row expansion of the real rows (+ ones column, + DisGANMF's float(uid) column), embedding lookup Ub = U[uids] and the
+// generator GEMM F = Ub . V^T -> rows [nb, 2nb) of XF (GANMF.py:82-83,183-184).  One launch when the generator GEMM is
+// planned onto the 16-wave fp32 ring kernel (front_kernel: the GEMM fetches its A rows from U through the row list, the
+// row expansion runs as extra workgroups of the same grid); else the two kernels one after the other.
+int rows_and_generator(ganmf_handle* h, const int* rows_dev, int nb, int which, int aslot, int uid_col, int row_offset) {
+  const int N = h->N, k = h->k;
+  DensP d{h->indptr, h->indices, h->data, rows_dev, nb, N, h->XF, h->ldN, h->Ue.p, h->ldk, h->Ub, h->scal, which, aslot,
+          which ? h->cfg.g_lr : h->cfg.d_lr, uid_col, row_offset};
+  GemmP g{};
+  g.A = h->Ub; g.lda = h->ldk; g.B = h->V.p; g.ldb = h->ldk;
+  g.C = h->XF + (size_t)nb * h->ldN; g.ldc = h->ldN;
+  g.M = nb; g.N = N; g.K = k; g.epi.kind = EPI_STORE; g.nbatch = 1;
+  g.zero_page = h->zero_page;
+  GemmPlan pl = gemm_plan(g.M, g.N, g.K, 1, false, h->tune);
+  pl.persist = gemm_persist_eligible(g, false, false, pl, h->tune.persist) ? 1 : 0;
+  if ((h->multi & 1) && plan_is_f32_64_kg(pl, 4) && pl.nsplit == 1) {
+    if (h->debug_plan) {
+      const long long key = ((long long)T_GEMM_GEN << 48) ^ ((long long)g.M << 32) ^ ((long long)g.N << 16) ^ g.K;
+      if (std::find(h->seen_plans.begin(), h->seen_plans.end(), key) == h->seen_plans.end()) {
+        h->seen_plans.push_back(key);
+        fprintf(stderr, "[ganmf plan] %-28s M=%d N=%d K=%d batch=1 -> tile 64 ring 3 kg 4 nsplit 1 (kps %d) mfma f32 wgs %d est %.1f us (one launch with the %d CSR rows)\n",
+                kTagName[T_GEMM_GEN], g.M, g.N, g.K, pl.kps, pl.tiles_m * pl.tiles_n, pl.est_us, nb);
+      }
+    }
+    Scope s(h, T_GEMM_GEN, gemm_flops(g.M, g.N, g.K), gemm_bytes(g.M, g.N, g.K) + 4.0 * nb * (N + 2 * k));
+    g.A = h->Ue.p; g.a_gather = rows_dev;        // A row r = U[rows[r]]: the lookup rides in the operand fetch
+    fill_plan(g, pl);
+    hipLaunchKernelGGL(front_kernel<4>, dim3(pl.tiles_m * pl.tiles_n + nb), dim3(1024), 0, h->st, g, d);
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
+  {
+    Scope s(h, T_DENSIFY, 0, 4.0 * nb * (N + 2 * k));
+    hipLaunchKernelGGL(densify_rows_kernel, dim3(nb), dim3(256), 0, h->st, d);
+    HIP_TRY(hipGetLastError());
+  }
+  return run_gemm(h, T_GEMM_GEN, T_RED_GEN, g, false, false);
+}
+
 // ---- shared front of both steps: X rows (+ones column), Ub, F, E = [X;F|1].We_ext ----------------
 int step_front(ganmf_handle* h, const int* rows_dev, int nb, int which) {
   const int N = h->N, k = h->k, e = h->e;
@@ -556,20 +656,7 @@ int step_front(ganmf_handle* h, const int* rows_dev, int nb, int which) {
     }
     return 0;
   }
-  {
-    Scope s(h, T_DENSIFY, 0, 4.0 * nb * (N + 2 * k));
-    hipLaunchKernelGGL(densify_rows_kernel, dim3(nb), dim3(256), 0, h->st, h->indptr, h->indices, h->data,
-                       rows_dev, nb, N, h->XF, h->ldN, h->Ue.p, h->ldk, h->Ub, h->scal, which, aslot,
-                       which ? h->cfg.g_lr : h->cfg.d_lr, -1, 0);
-    HIP_TRY(hipGetLastError());
-  }
-  {  // F = Ub . V^T  -> rows [nb, 2nb) of XF            (GANMF.py:83)
-    GemmP g{};
-    g.A = h->Ub; g.lda = h->ldk; g.B = h->V.p; g.ldb = h->ldk;
-    g.C = h->XF + (size_t)nb * h->ldN; g.ldc = h->ldN;
-    g.M = nb; g.N = N; g.K = k; g.epi.kind = EPI_STORE;
-    TRY(run_gemm(h, T_GEMM_GEN, T_RED_GEN, g, false, false));
-  }
+  TRY(rows_and_generator(h, rows_dev, nb, which, aslot, -1, 0));   // X rows, Ub, F = Ub . V^T -> rows [nb, 2nb) of XF  (GANMF.py:82-83)
   {  // E = [X;F | 1] . We_ext  (bias = row N); the ones column E[:, e] is never overwritten  (GANMF.py:64-65)
     TRY(dp_join(h));     // (data-parallel: the previous step's encoder update ran on the side lane under densify + generator GEMM)
     GemmP g{};
@@ -638,6 +725,7 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
     // the data-parallel path runs the same two GEMMs with a plain store epilogue: same tile, split and arithmetic,
     // so that it stays bitwise equal to the fused single-GPU path (tests/test_gpu_parity.py, one-rank RCCL)
     const GemmTune* wg_tune = &ft;
+    RedP dE_red{};                  // single GPU: the slab sum of dE rides in the gWd launch (gWd does not read dE, gWe does)
     auto gemm_gWd = [&]() -> int {  // gWd_ext = (rs*[E|1])^T . Delta   -> rows 0..e-1 = gWd, row e = gbd
       GemmP g{};
       g.A = h->Es; g.lda = h->lde; g.B = h->Dl; g.ldb = h->ldN;
@@ -648,7 +736,8 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
         g.epi.adam_alpha = h->scal + aslot; g.epi.adam_reg = h->cfg.d_reg;
         g.epi.sq_partials = regD ? regWd : nullptr;
       }
-      return run_gemm(h, T_GEMM_GWD, T_RED_GWD, g, true, true, &regn[1], fused ? 24.0 * h->Wd.count() : 0, 0, wg_tune);
+      return run_gemm(h, T_GEMM_GWD, T_RED_GWD, g, true, true, &regn[1], fused ? 24.0 * h->Wd.count() : 0, 0, wg_tune, nullptr,
+                      nullptr, dE_red.part ? &dE_red : nullptr);
     };
     // Data-parallel: the decoder gradient is produced first; its reduce-scatter runs on the side lane under the dE GEMM,
     // its Adam slice + all-gather (which overwrite Wd) under the gWe_ext GEMM, once dE has read the old decoder.
@@ -662,7 +751,8 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
       g.A = h->Dl; g.lda = h->ldN; g.B = h->Wd.p; g.ldb = h->ldN;
       g.C = h->dE; g.ldc = h->lde; g.M = 2 * nb; g.N = e; g.K = N;
       g.epi.kind = EPI_ROWSCALE; g.epi.rowscale = h->rs;
-      TRY(run_gemm(h, T_GEMM_DE, T_RED_DE, g, false, false));
+      TRY(run_gemm(h, T_GEMM_DE, T_RED_DE, g, false, false, nullptr, 0, 0, nullptr, nullptr,
+                   (!dist && (h->multi & 4)) ? &dE_red : nullptr));
     }
     // Weight-gradient GEMMs.  Single GPU: the gradient tile never leaves the CU -- the epilogue
     // applies TF-Adam to theta/m/v in place (after dE, which reads the old decoder).
@@ -717,12 +807,13 @@ int gen_update(ganmf_handle* h, int nb, int start, int b_global, int* regn_v, fl
   const bool dist = h->has_comm;
   const bool fused = h->fuse_adam && !dist && nb > 0;
   *regn_v = ADAM_GRID;
+  SlabRef gub{h->gUb, 1, 0};
   auto gemm_gUb = [&]() -> int {  // gUb = dF . V     (reads the OLD V)
     GemmP g{};
     g.A = h->dF; g.lda = h->ldN; g.B = h->V.p; g.ldb = h->ldk;
     g.C = h->gUb; g.ldc = h->ldk; g.M = nb; g.N = k; g.K = N; g.epi.kind = EPI_STORE;
     g.a_scale = grad_scale(h, b_global);      // dF
-    return run_gemm(h, T_GEMM_GUB, T_RED_GUB, g, false, true);
+    return run_gemm(h, T_GEMM_GUB, T_RED_GUB, g, false, true, nullptr, 0, 0, nullptr, h->defer_gub ? &gub : nullptr);   // slabs summed by adam_rows_kernel
   };
   auto gemm_gV = [&]() -> int {   // gV = dF^T . Ub
     GemmP g{};
@@ -757,15 +848,50 @@ int gen_update(ganmf_handle* h, int nb, int start, int b_global, int* regn_v, fl
     TRY(adam_dense(h, T_ADAM_V, h->V, h->V.g, S_ALPHA_G, h->cfg.g_reg, reg ? reg_v : nullptr, 1, off, slice));
     TRY(all_gather(h, h->V.p, h->V.cap, 1));
   } else if (nb > 0) {
-    TRY(gemm_gUb());
-    TRY(gemm_gV());      // fused: Adam(V) in the epilogue, after gUb has read the old V
+    bool paired = false;
+    if (fused && (h->multi & 2) && h->defer_gub && !h->prof && h->V_alt) {
+      // gUb and gV in ONE launch (pair_kernel): both read dF; gUb reads the old V while gV's Adam epilogue writes the new V
+      // into the second buffer, swapped in afterwards.  Only when both are planned onto the 16-wave fp32 ring kernel.
+      GemmP g0{}, g1{};
+      g0.A = h->dF; g0.lda = h->ldN; g0.B = h->V.p; g0.ldb = h->ldk;
+      g0.C = h->gUb; g0.ldc = h->ldk; g0.M = nb; g0.N = k; g0.K = N; g0.epi.kind = EPI_STORE; g0.nbatch = 1;
+      g0.zero_page = h->zero_page; g0.a_scale = grad_scale(h, b_global);
+      g1.A = h->dF; g1.lda = h->ldN; g1.B = h->Ub; g1.ldb = h->ldk;
+      g1.C = h->V.g; g1.ldc = h->ldk; g1.M = N; g1.N = k; g1.K = nb; g1.nbatch = 1;
+      g1.zero_page = h->zero_page; g1.a_scale = grad_scale(h, b_global);
+      g1.epi.kind = EPI_ADAM; g1.epi.adam_theta = h->V.p; g1.epi.adam_theta_out = h->V_alt; g1.epi.adam_m = h->V.m; g1.epi.adam_v = h->V.v;
+      g1.epi.adam_alpha = h->scal + S_ALPHA_G; g1.epi.adam_reg = h->cfg.g_reg;
+      g1.epi.sq_partials = reg ? reg_v : nullptr;
+      GemmPlan p0 = gemm_plan(g0.M, g0.N, g0.K, 1, false, h->tune);
+      GemmPlan p1 = gemm_plan(g1.M, g1.N, g1.K, 1, g1.epi.sq_partials != nullptr, h->tune, true);
+      if (plan_is_f32_64_kg(p0, 4) && plan_is_f32_64_kg(p1, 4) && p1.nsplit == 1) {
+        if (p0.nsplit > 1) {
+          TRY(ensure_slab(h, gemm_slab_elems(p0, g0.M, g0.ldc, 1), 1));
+          g0.C = h->slab2; g0.c_split_stride = (long long)g0.M * g0.ldc;
+          gub = SlabRef{h->slab2, p0.nsplit, (long long)g0.M * g0.ldc};
+        }
+        g0.c_batch_stride = (long long)g0.M * g0.ldc;
+        fill_plan(g0, p0);
+        fill_plan(g1, p1);
+        *regn_v = p1.sq_count;
+        const int n0 = p0.tiles_m * p0.tiles_n * p0.nsplit, n1 = p1.tiles_m * p1.tiles_n;
+        hipLaunchKernelGGL(pair_kernel<4>, dim3(n0 + n1), dim3(1024), 0, h->st, g0, g1);
+        HIP_TRY(hipGetLastError());
+        std::swap(h->V.p, h->V_alt);
+        paired = true;
+      }
+    }
+    if (!paired) {
+      TRY(gemm_gUb());
+      TRY(gemm_gV());      // fused: Adam(V) in the epilogue, after gUb has read the old V
+    }
   } else {
     HIP_TRY(hipMemsetAsync(h->V.g, 0, h->V.padded() * sizeof(float), h->st));
   }
   {
     Scope s(h, T_ADAM_U, 0, 24.0 * h->Ue.count());
-    hipLaunchKernelGGL(adam_rows_kernel, dim3(ADAM_GRID), dim3(256), 0, h->st, h->Ue.p, h->Ue.m, h->Ue.v, h->gUb,
-                       h->pos, start, nb, h->U, h->ldk, h->scal, S_ALPHA_G, h->cfg.g_reg,
+    hipLaunchKernelGGL(adam_rows_kernel, dim3(ADAM_GRID), dim3(256), 0, h->st, h->Ue.p, h->Ue.m, h->Ue.v, gub.p,
+                       gub.nsplit, gub.split_stride, h->pos, start, nb, h->U, h->ldk, h->scal, S_ALPHA_G, h->cfg.g_reg,
                        reg ? reg_u : nullptr);
     HIP_TRY(hipGetLastError());
   }
@@ -831,20 +957,9 @@ int g_step(ganmf_handle* h, const int* rows_dev, int nb, int start, int b_global
 // =================================================================================================
 int dis_forward(ganmf_handle* h, const int* rows_dev, int nb, int which) {
   const int N = h->N, k = h->k, e = h->e;
-  {
-    Scope s(h, T_DENSIFY, 0, 4.0 * nb * (N + 2 * k));
-    hipLaunchKernelGGL(densify_rows_kernel, dim3(nb), dim3(256), 0, h->st, h->indptr, h->indices, h->data,
-                       rows_dev, nb, N, h->XF, h->ldN, h->Ue.p, h->ldk, h->Ub, h->scal, which, which ? S_ALPHA_G : S_ALPHA_D,
-                       which ? h->cfg.g_lr : h->cfg.d_lr, N + 1, (int)h->cfg.row_offset);
-    HIP_TRY(hipGetLastError());
-  }
-  {  // F = Ub . V^T   (DisGANMF.py:77-78)
-    GemmP g{};
-    g.A = h->Ub; g.lda = h->ldk; g.B = h->V.p; g.ldb = h->ldk;
-    g.C = h->XF + (size_t)nb * h->ldN; g.ldc = h->ldN;
-    g.M = nb; g.N = N; g.K = k; g.epi.kind = EPI_STORE;
-    TRY(run_gemm(h, T_GEMM_GEN, T_RED_GEN, g, false, false));
-  }
+  // X rows with the float(uid) column, Ub, F = Ub . V^T   (DisGANMF.py:59,77-78)
+  TRY(rows_and_generator(h, rows_dev, nb, which, which ? S_ALPHA_G : S_ALPHA_D, N + 1, (int)h->cfg.row_offset));
+  (void)k;
   for (int l = 0; l < h->L; ++l) {  // a_l = act([a_{l-1} | 1 (| uid)] . W_l_ext)   (DisGANMF.py:60-62)
     GemmP g{};
     g.A = l == 0 ? h->XF : h->Al[l - 1]; g.lda = l == 0 ? h->ldN : h->lde;
@@ -1185,6 +1300,8 @@ static int create_impl(const ganmf_cfg* cfg, ganmf_handle* h) {
   HIP_TRY(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&h->ev_mid, hipEventDisableTiming));
   h->fuse_adam = env_int("GANMF_FUSE_ADAM", 1) != 0;
+  h->defer_gub = env_int("GANMF_DEFER_GUB", 1) != 0;
+  h->multi = env_int("GANMF_MULTI", 7);
   h->inkernel_reduce = env_int("GANMF_INKERNEL_REDUCE", 0) != 0;   // measured slower than the chip-wide reduce kernel
   h->inlaunch_max = env_int("GANMF_INLAUNCH_MAX", 4);
   TRY(dalloc((float**)&h->counters, COUNTER_CAP));
@@ -1195,6 +1312,7 @@ static int create_impl(const ganmf_cfg* cfg, ganmf_handle* h) {
   const int world = std::max(1, (int)cfg->world_size);
   TRY(alloc_tensor(h->Ue, U, k, false, 1));      // rows of U belong to their rank: never communicated
   TRY(alloc_tensor(h->V, N, k, true, world));
+  TRY(dalloc(&h->V_alt, h->V.cap));
   if (!dis) {
     TRY(alloc_tensor(h->We, N + 1, e, false, world));   // We_ext: row N = encoder bias
     TRY(alloc_tensor(h->Wd, e + 1, N, false, world, h->ldN));   // Wd_ext: row e = decoder bias; shares the leading dimension of the [.., N] work buffers
@@ -1276,7 +1394,7 @@ int ganmf_destroy(ganmf_handle* h) {
   free_tensor(h->Wo, false);
   for (float* a : h->Al) hipFree(a);
   hipFree(h->dz0); hipFree(h->dz1); hipFree(h->dlogit); hipFree(h->lossrow);
-  free_tensor(h->Ue, false); free_tensor(h->V, true);
+  free_tensor(h->Ue, false); free_tensor(h->V, true); hipFree(h->V_alt);
   hipFree(h->gD); hipFree(h->indptr); hipFree(h->indices); hipFree(h->data); hipFree(h->perm); hipFree(h->pos);
   hipFree(h->XF); hipFree(h->Ub); hipFree(h->E); hipFree(h->Dl); hipFree(h->dE); hipFree(h->dF); hipFree(h->gUb);
   hipFree(h->slab); hipFree(h->rs); hipFree(h->scal); hipFree(h->sqp); hipFree(h->fmp);

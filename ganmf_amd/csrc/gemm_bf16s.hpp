@@ -131,8 +131,16 @@ struct SplitStage {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
+template <int BM, int BN, int BK, int NPIECE>
+struct Bf16sLds {      // floats of LDS one workgroup needs: the piece planes, or the C tile the epilogue stages there
+  static constexpr int OPER = NPIECE * (BM * BK / 2 + BN * BK / 2);
+  static constexpr int DW = OPER > BM * BN ? OPER : BM * BN;
+};
+
+// (body = device function of (block index, blocks of this GEMM): one launch can carry more than one piece of work,
+// gemm_multi.hpp; `smem` is the launch's only LDS object, Bf16sLds<...>::DW floats)
 template <int BM, int BN, int BK, bool AKM, bool BKM, int NPIECE, bool F16 = false>
-__global__ __launch_bounds__(256, 2) void gemm_bf16s_mfma(const GemmP p) {
+__device__ __forceinline__ void gemm_bf16s_body(const GemmP& p, const int bid, const int nblk, float* __restrict__ smem) {
   static_assert(!F16 || NPIECE == 1, "fp16 pieces only in the single-piece (mixed precision) mode");
   const float sa = (F16 && p.a_scale != 0.f) ? p.a_scale : 1.f, sb = (F16 && p.b_scale != 0.f) ? p.b_scale : 1.f;
   using SA = SplitStage<BM, BK, AKM>;
@@ -142,9 +150,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16s_mfma(const GemmP p) {
   constexpr int NC = BK / 16;
   static_assert(NPIECE == 1 || NPIECE == 3, "pieces per operand");
   static_assert(BM % 32 == 0 && BN % 32 == 0, "row XOR of the K-major layout needs 32-row blocks");
-  constexpr int OPER = NPIECE * (SA::PLANE + SB::PLANE);
-  constexpr int LDS_DW = OPER > BM * BN ? OPER : BM * BN;    // the epilogue stages the C tile here
-  __shared__ __attribute__((aligned(16))) float smem[LDS_DW];
+  static_assert(Bf16sLds<BM, BN, BK, NPIECE>::OPER == NPIECE * (SA::PLANE + SB::PLANE), "LDS budget");
   unsigned* const planes_a = reinterpret_cast<unsigned*>(smem);
   unsigned* const planes_b = planes_a + NPIECE * SA::PLANE;
 
@@ -154,7 +160,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16s_mfma(const GemmP p) {
   const int wr = wave >> 1, wc = wave & 1;
   const int li = lane & 31, lh = lane >> 5;
 
-  int t = xcd_remap(blockIdx.x, gridDim.x);
+  int t = xcd_remap(bid, nblk);
   const int tm = t % p.tiles_m; t /= p.tiles_m;
   const int tn = t % p.tiles_n; t /= p.tiles_n;
   const int sp = t % p.nsplit;
@@ -271,6 +277,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16s_mfma(const GemmP p) {
     }
   }
   gemm_epilogue<BM, BN, TM, TN>(p, acc, smem, TileCoord{tm, tn, sp, bz, m0, n0});
+}
+
+template <int BM, int BN, int BK, bool AKM, bool BKM, int NPIECE, bool F16 = false>
+__global__ __launch_bounds__(256, 2) void gemm_bf16s_mfma(const GemmP p) {
+  __shared__ __attribute__((aligned(16))) float smem[Bf16sLds<BM, BN, BK, NPIECE>::DW];
+  gemm_bf16s_body<BM, BN, BK, AKM, BKM, NPIECE, F16>(p, (int)blockIdx.x, (int)gridDim.x, smem);
 }
 
 template <int BM, int BN, int BK, int NPIECE, bool F16 = false>

@@ -158,6 +158,8 @@ struct EpiD {
   const float* r1_w;       //          (DisGANMF's float(uid) input column kept OUT of a low-precision K loop)
   int r1_ld;
   float* adam_theta;       // EPI_ADAM: parameter and moments, same [M, ldc] geometry as C
+  float* adam_theta_out;   //   where the updated parameter goes (nullptr: in place).  A second buffer lets another GEMM of
+                           //   the SAME launch still read the old parameter (gemm_multi.hpp: gUb reads V while gV updates it)
   float* adam_m;
   float* adam_v;
   const float* adam_alpha; // device scalar lr_t of the step in flight
@@ -225,6 +227,8 @@ struct GemmP {
   float* Cf;               // final output [M, ldc] per batch
   long long cf_batch_stride;
   int c_pad_writable;           // columns N .. ldc-1 of C hold nothing the caller needs (gemm_persist.hpp writes zeros there)
+  const int* a_gather;          // K-contiguous A only: row r of A is A + a_gather[r] * lda (embedding lookup folded into the
+                                // operand fetch, GANMF.py:82); nullptr: row r is A + r * lda
   float a_scale, b_scale;       // MFMA_F16: powers of two applied to the operands at conversion (0 = 1); acc *= 1 / (a_scale * b_scale)
 };
 
@@ -249,7 +253,7 @@ struct Stage {
   int aux[NP];            // !KM: pointer increment per tile (0 for zero-page lanes); KM: k-row or -1
 
   __device__ inline void init(const float* __restrict__ base, int ld, int r0, int rlimit, int kbeg,
-                              const float* zero, int tid) {
+                              const float* zero, int tid, const int* __restrict__ gather = nullptr) {
     zero += (tid & 255) * 4;   // distinct lines per lane: no single-line hot spot
     zp = zero;
 #pragma unroll
@@ -259,7 +263,8 @@ struct Stage {
         const int row = pos / S, slot = pos % S;
         const int c4 = slot ^ swz(row);
         const bool ok = (r0 + row) < rlimit;
-        ptr[j] = ok ? base + (size_t)(r0 + row) * ld + kbeg + 4 * c4 : zero;
+        const int src_row = (ok && gather) ? gather[r0 + row] : r0 + row;
+        ptr[j] = ok ? base + (size_t)src_row * ld + kbeg + 4 * c4 : zero;
         aux[j] = ok ? BK : 0;
       } else {
         const int krow = pos / RC4, c4 = pos % RC4;
@@ -385,6 +390,7 @@ __device__ inline void gemm_epilogue(const GemmP& p, const f32x16 (&acc)[TM][TN]
   const int col = n0 + tc * 4;
   const bool adam = !deferred && e.kind == EPI_ADAM;
   const float alpha = adam ? *e.adam_alpha : 0.f;
+  float* __restrict__ theta_out = e.adam_theta_out ? e.adam_theta_out : e.adam_theta;
   const bool publish = deferred && p.counters != nullptr;
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   const __amdgpu_buffer_rsrc_t slab_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)C, (short)0, 0x7fffffff, 0x00020000);
@@ -409,12 +415,15 @@ __device__ inline void gemm_epilogue(const GemmP& p, const f32x16 (&acc)[TM][TN]
           adam_update(o[1], alpha, e.adam_reg, t4.y, m4.y, v4.y, sq);
           adam_update(o[2], alpha, e.adam_reg, t4.z, m4.z, v4.z, sq);
           adam_update(o[3], alpha, e.adam_reg, t4.w, m4.w, v4.w, sq);
-          *reinterpret_cast<float4*>(e.adam_theta + off) = t4;
+          *reinterpret_cast<float4*>(theta_out + off) = t4;
           *reinterpret_cast<float4*>(e.adam_m + off) = m4;
           *reinterpret_cast<float4*>(e.adam_v + off) = v4;
         } else {
-          for (int q = 0; q < 4 && col + q < p.N; ++q)
-            adam_update(o[q], alpha, e.adam_reg, e.adam_theta[off + q], e.adam_m[off + q], e.adam_v[off + q], sq);
+          for (int q = 0; q < 4 && col + q < p.N; ++q) {
+            float th = e.adam_theta[off + q];
+            adam_update(o[q], alpha, e.adam_reg, th, e.adam_m[off + q], e.adam_v[off + q], sq);
+            theta_out[off + q] = th;
+          }
         }
         continue;
       }
@@ -510,8 +519,10 @@ __device__ inline void gemm_epilogue(const GemmP& p, const f32x16 (&acc)[TM][TN]
 // CU that holds a single workgroup still has KG waves per SIMD -- one wave's fragment reads, piece issue and barrier
 // waits run under another's MFMAs (a single in-order wave per SIMD loses 15-30 % of the MFMA rate to them:
 // profiles/README.md).  The partial sums meet in the epilogue through LDS.
+// The body is a device function of (block index, blocks of this GEMM) so that one launch can carry several independent
+// pieces of work (gemm_multi.hpp); `smem` is the launch's only LDS object, NS ring slots of BM*BK + BN*BK floats.
 template <int BM, int BN, int BK, int NS, bool AKM, bool BKM, int KG = 1>
-__global__ __launch_bounds__(256 * KG) void gemm_f32_mfma(const GemmP p) {
+__device__ __forceinline__ void gemm_f32_body(const GemmP& p, const int bid, const int nblk, float* __restrict__ smem) {
   constexpr int NTHR = 256 * KG;
   using SA = Stage<BM, BK, AKM, NTHR>;
   using SB = Stage<BN, BK, BKM, NTHR>;
@@ -521,7 +532,6 @@ __global__ __launch_bounds__(256 * KG) void gemm_f32_mfma(const GemmP p) {
   static_assert(NS >= 2 && NS <= 4, "ring depth");
   constexpr int BUF = SA::SZ + SB::SZ;            // ring slot b: A at smem + b*BUF, B right behind
   constexpr int LOADS = SA::NP + SB::NP;          // glds per wave per tile
-  __shared__ __attribute__((aligned(16))) float smem[NS * BUF];   // the ONLY LDS object (cdna guide §5 item 4a)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -530,7 +540,7 @@ __global__ __launch_bounds__(256 * KG) void gemm_f32_mfma(const GemmP p) {
   const int wr = (wave >> 1) & 1, wc = wave & 1;
   const int li = lane & 31, lh = lane >> 5;
 
-  int t = xcd_remap(blockIdx.x, gridDim.x);
+  int t = xcd_remap(bid, nblk);
   const int tm = t % p.tiles_m; t /= p.tiles_m;
   const int tn = t % p.tiles_n; t /= p.tiles_n;
   const int sp = t % p.nsplit;
@@ -551,7 +561,7 @@ __global__ __launch_bounds__(256 * KG) void gemm_f32_mfma(const GemmP p) {
 
   SA la;
   SB lb;
-  la.init(p.A + (size_t)bz * p.a_batch_stride, p.lda, m0, p.M, kbeg, p.zero_page, tid);
+  la.init(p.A + (size_t)bz * p.a_batch_stride, p.lda, m0, p.M, kbeg, p.zero_page, tid, AKM ? nullptr : p.a_gather);
   lb.init(p.B, p.ldb, n0, p.N, kbeg, p.zero_page, tid);
 
   constexpr int NC = BK / 8 / KG;   // 8-wide k chunks per tile and K group (even: local chunk c uses fragment set c & 1)
@@ -659,6 +669,12 @@ __global__ __launch_bounds__(256 * KG) void gemm_f32_mfma(const GemmP p) {
   gemm_epilogue<BM, BN, TM, TN, KG>(p, acc, smem, TileCoord{tm, tn, sp, bz, m0, n0});
 }
 
+template <int BM, int BN, int BK, int NS, bool AKM, bool BKM, int KG = 1>
+__global__ __launch_bounds__(256 * KG) void gemm_f32_mfma(const GemmP p) {
+  __shared__ __attribute__((aligned(16))) float smem[NS * (BM + BN) * BK];   // the ONLY LDS object (cdna guide §5 item 4a)
+  gemm_f32_body<BM, BN, BK, NS, AKM, BKM, KG>(p, (int)blockIdx.x, (int)gridDim.x, smem);
+}
+
 // Reduce split-K slabs and apply the deferred epilogue: out[m,n] = epi(sum_s part[s][m,n]).
 // grid = (gx, nbatch); columns >= N are never written (ones / pad columns keep their values).
 struct RedP {
@@ -672,8 +688,9 @@ struct RedP {
   EpiD epi;
 };
 
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const RedP p) {
-  const int bz = blockIdx.y;
+// (bx of nbx blocks of 256 threads walk the elements of batch bz; `red` = 4 floats of LDS)
+template <int NT = 256>
+__device__ __forceinline__ void splitk_reduce_body(const RedP& p, const int bx, const int nbx, const int bz, float* __restrict__ red) {
   const int n4 = (p.N + 3) >> 2;
   const long long total = (long long)p.M * n4;
   const float* __restrict__ part = p.part + (size_t)bz * p.batch_stride;
@@ -681,8 +698,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const RedP p) {
   const EpiD& e = p.epi;
   const float* __restrict__ aux = e.aux ? e.aux + (size_t)bz * e.aux_batch_stride : nullptr;
   float sq = 0.f;
-  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (long long)gridDim.x * blockDim.x) {
+  for (long long idx = (long long)bx * NT + threadIdx.x; idx < total; idx += (long long)nbx * NT) {
     const int m = (int)(idx / n4), c = (int)(idx % n4) * 4;
     const size_t off = (size_t)m * p.ld + c;
     float4 s = *reinterpret_cast<const float4*>(part + off);
@@ -701,13 +717,22 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const RedP p) {
     }
   }
   if (e.sq_partials) {
-    __shared__ float red[4];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sq;
     __syncthreads();
-    if (threadIdx.x == 0) e.sq_partials[(size_t)bz * e.sq_stride + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (threadIdx.x == 0) {
+      float t = (red[0] + red[1]) + (red[2] + red[3]);
+#pragma unroll
+      for (int w = 4; w < NT / 64; w += 4) t += (red[w] + red[w + 1]) + (red[w + 2] + red[w + 3]);
+      e.sq_partials[(size_t)bz * e.sq_stride + bx] = t;
+    }
   }
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const RedP p) {
+  __shared__ float red[4];
+  splitk_reduce_body(p, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y, red);
 }
 
 // ---- host side: plan (tile, ring depth, split-K) and launch ------------------------------------

@@ -1,0 +1,64 @@
+// Launches that carry more than one piece of the GANMF step.
+//
+// Why: on this eight-XCD part every kernel boundary of a dependent chain costs ~4.4 us before the next kernel's first
+// wave runs (rocprofv3 shows d_coef, densify and the split-K reduce -- a few MB of traffic each -- at 4.4-4.8 us; the
+// per-XCD L2s are written back and invalidated at the boundary), and a D+G pair of the C2 step has 24 of them
+// (profiles/r02_step_classes.md).  Where two neighbours of the chain do not depend on each other they ride in ONE launch,
+// as block ranges of the same grid running different bodies:
+//   front_kernel       generator GEMM F = U[uids].V^T (rows gathered by the operand fetch, GemmP::a_gather) + the CSR row
+//                      expansion of the real rows (kernels.hpp densify_row_body): D- and G-step           (GANMF.py:82-83,183-184)
+//   pair_kernel        gUb = dF.V (split-K slabs, summed later by adam_rows_kernel) + gV = dF^T.Ub with the fused Adam
+//                      epilogue: the update of V is written to a SECOND buffer (EpiD::adam_theta_out) because gUb reads
+//                      the old V inside the same launch; the host swaps the two buffers                   (GANMF.py:139)
+//   gemm_bf16s_red     gWd_ext = Es^T.Delta with the fused Adam epilogue + the slab sum / row scale of dE = rs (.) (Delta.Wd^T),
+//                      which the previous launch left as split-K slabs and only the NEXT launch (gWe) reads (GANMF.py:138)
+// The bodies are the ordinary kernels' bodies (gemm_f32_body, gemm_bf16s_body, splitk_reduce_body): same arithmetic, same
+// summation order, bit-identical results to the separate launches.
+#pragma once
+#include "gemm_bf16s.hpp"
+#include "gemm_f32.hpp"
+#include "kernels.hpp"
+
+namespace ganmf {
+
+// blocks [0, ng): 64 x 64 tiles of the NT GEMM; blocks [ng, ng + d.nb): one CSR row each
+template <int KG>
+__global__ __launch_bounds__(256 * KG) void front_kernel(const GemmP g, const DensP d) {
+  __shared__ __attribute__((aligned(16))) float smem[3 * (64 + 64) * 64];
+  const int ng = g.tiles_m * g.tiles_n * g.nsplit * g.nbatch;
+  if ((int)blockIdx.x < ng) gemm_f32_body<64, 64, 64, 3, false, false, KG>(g, (int)blockIdx.x, ng, smem);
+  else densify_row_body(d, (int)blockIdx.x - ng);
+}
+
+// blocks [0, n0): g0, an NN GEMM; blocks [n0, n0 + n1): g1, a TN GEMM
+template <int KG>
+__global__ __launch_bounds__(256 * KG) void pair_kernel(const GemmP g0, const GemmP g1) {
+  __shared__ __attribute__((aligned(16))) float smem[3 * (64 + 64) * 64];
+  const int n0 = g0.tiles_m * g0.tiles_n * g0.nsplit * g0.nbatch;
+  const int n1 = g1.tiles_m * g1.tiles_n * g1.nsplit * g1.nbatch;
+  if ((int)blockIdx.x < n0) gemm_f32_body<64, 64, 64, 3, false, true, KG>(g0, (int)blockIdx.x, n0, smem);
+  else gemm_f32_body<64, 64, 64, 3, true, true, KG>(g1, (int)blockIdx.x - n0, n1, smem);
+}
+
+// blocks [0, ng): 64 x 64 x 32 tiles of the TN split-bf16 GEMM; blocks [ng, ng + nred): slab reduce of ANOTHER product
+__global__ __launch_bounds__(256, 2) void gemm_bf16s_red(const GemmP g, const RedP r, const int nred) {
+  __shared__ __attribute__((aligned(16))) float smem[Bf16sLds<64, 64, 32, 3>::DW];
+  const int ng = g.tiles_m * g.tiles_n * g.nsplit * g.nbatch;
+  if ((int)blockIdx.x < ng) gemm_bf16s_body<64, 64, 32, true, true, 3>(g, (int)blockIdx.x, ng, smem);
+  else splitk_reduce_body(r, (int)blockIdx.x - ng, nred, 0, smem);
+}
+
+// ---- host side: can this plan ride in the combined launch?
+inline bool plan_is_f32_64_kg(const GemmPlan& pl, int kg) {
+  return pl.mode == MFMA_F32 && pl.tile == 64 && pl.ring == 3 && pl.kg == kg && !pl.persist;
+}
+
+inline void fill_plan(GemmP& p, const GemmPlan& pl) {
+  if (p.nbatch < 1) p.nbatch = 1;
+  p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n;
+  p.nsplit = pl.nsplit; p.k_per_split = pl.kps;
+  p.epi.sq_stride = pl.sq_count;
+  p.counters = nullptr;
+}
+
+}  // namespace ganmf

@@ -41,41 +41,53 @@ __device__ inline float block_sum_256(float v, float* red4) {
 //   * copies row rows[b] of user_embeddings into Ub[b, :].
 // Block 0 / thread 0 also opens the optimizer step: lr_t from the beta powers (TF ApplyAdam),
 // then advances the powers.
-__global__ __launch_bounds__(256) void densify_rows_kernel(const long long* __restrict__ indptr,
-                                                           const int* __restrict__ indices,
-                                                           const float* __restrict__ data,
-                                                           const int* __restrict__ rows, int nb, int ncols,
-                                                           float* __restrict__ X, int ldx,
-                                                           const float* __restrict__ Uemb, int ldk,
-                                                           float* __restrict__ Ub, float* __restrict__ scal,
-                                                           int which, int alpha_idx, float lr, int uid_col, int row_offset) {
-  const int b = blockIdx.x;
+struct DensP {
+  const long long* indptr;
+  const int* indices;
+  const float* data;
+  const int* rows;
+  int nb, ncols;
+  float* X;
+  int ldx;
+  const float* Uemb;
+  int ldk;
+  float* Ub;
+  float* scal;
+  int which, alpha_idx;
+  float lr;
+  int uid_col, row_offset;
+};
+
+// (block b of the row expansion, any block size: also runs as extra workgroups of the generator GEMM's launch, gemm_multi.hpp)
+__device__ __forceinline__ void densify_row_body(const DensP& d, const int b) {
   if (b == 0 && threadIdx.x == 0) {
-    const int o = which ? S_B1P_G : S_B1P_D;
-    const float b1p = scal[o], b2p = scal[o + 1];
-    scal[alpha_idx] = lr * sqrtf(1.f - b2p) / (1.f - b1p);
-    scal[o] = b1p * ADAM_B1;
-    scal[o + 1] = b2p * ADAM_B2;
+    const int o = d.which ? S_B1P_G : S_B1P_D;
+    const float b1p = d.scal[o], b2p = d.scal[o + 1];
+    d.scal[d.alpha_idx] = d.lr * sqrtf(1.f - b2p) / (1.f - b1p);
+    d.scal[o] = b1p * ADAM_B1;
+    d.scal[o + 1] = b2p * ADAM_B2;
   }
-  const int r = rows[b];
-  float4* xr = reinterpret_cast<float4*>(X + (size_t)b * ldx);
-  for (int c = threadIdx.x; c < ldx / 4; c += blockDim.x) xr[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-  const float4* us = reinterpret_cast<const float4*>(Uemb + (size_t)r * ldk);
-  float4* ud = reinterpret_cast<float4*>(Ub + (size_t)b * ldk);
-  for (int c = threadIdx.x; c < ldk / 4; c += blockDim.x) ud[c] = us[c];
+  const int r = d.rows[b];
+  float4* xr = reinterpret_cast<float4*>(d.X + (size_t)b * d.ldx);
+  for (int c = threadIdx.x; c < d.ldx / 4; c += blockDim.x) xr[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4* us = reinterpret_cast<const float4*>(d.Uemb + (size_t)r * d.ldk);
+  float4* ud = reinterpret_cast<float4*>(d.Ub + (size_t)b * d.ldk);
+  for (int c = threadIdx.x; c < d.ldk / 4; c += blockDim.x) ud[c] = us[c];
   __syncthreads();
-  const long long s = indptr[r], e = indptr[r + 1];
-  float* x = X + (size_t)b * ldx;
-  for (long long j = s + threadIdx.x; j < e; j += blockDim.x) x[indices[j]] = data[j];
+  const long long s = d.indptr[r], e = d.indptr[r + 1];
+  float* x = d.X + (size_t)b * d.ldx;
+  for (long long j = s + threadIdx.x; j < e; j += blockDim.x) x[d.indices[j]] = d.data[j];
   if (threadIdx.x == 0) {
-    x[ncols] = 1.0f;
-    X[(size_t)(nb + b) * ldx + ncols] = 1.0f;
-    if (uid_col >= 0) {   // DisGANMF conditions D on float(uid) (DisGANMF.py:59,110-111)
-      x[uid_col] = (float)(row_offset + r);
-      X[(size_t)(nb + b) * ldx + uid_col] = (float)(row_offset + r);
+    x[d.ncols] = 1.0f;
+    d.X[(size_t)(d.nb + b) * d.ldx + d.ncols] = 1.0f;
+    if (d.uid_col >= 0) {   // DisGANMF conditions D on float(uid) (DisGANMF.py:59,110-111)
+      x[d.uid_col] = (float)(d.row_offset + r);
+      d.X[(size_t)(d.nb + b) * d.ldx + d.uid_col] = (float)(d.row_offset + r);
     }
   }
 }
+
+__global__ __launch_bounds__(256) void densify_rows_kernel(const DensP d) { densify_row_body(d, (int)blockIdx.x); }
 
 // SURVEY 8(f)-3, sparse-aware real path of the GENERATOR step.  In a G update the real rows X are needed for ONE thing:
 // their encodings Er = X.We + be in the feature-matching term (GANMF.py:134); nothing else reads X.  For a sparse
@@ -300,8 +312,11 @@ __global__ __launch_bounds__(256) void adam_dense_kernel(float* __restrict__ th,
 // SURVEY Appendix B.5): rows of the current batch take their gradient from gUb, others g = 0.
 //   m = m*b1 + g'(1-b1) ; v = v*b2 + g'^2(1-b2) ; theta -= alpha*m/(sqrt(v)+eps)
 // pos[r] = position of row r in this epoch's permutation (-1 if absent); batch = [start, start+nb).
+// The batch gradient arrives as gsplit split-K slabs of the gUb GEMM (slab s at gb + s * gstride), summed here in split
+// order -- exactly what splitk_reduce_kernel would have written, without its launch.
 __global__ __launch_bounds__(256) void adam_rows_kernel(float* __restrict__ th, float* __restrict__ mo,
                                                         float* __restrict__ vo, const float* __restrict__ gb,
+                                                        int gsplit, long long gstride,
                                                         const int* __restrict__ pos, int start, int nb,
                                                         int nrows, int ld, const float* __restrict__ scal,
                                                         int alpha_idx, float reg, float* __restrict__ sq_partials) {
@@ -315,7 +330,15 @@ __global__ __launch_bounds__(256) void adam_rows_kernel(float* __restrict__ th, 
     const int r = (int)(i / c4), c = (int)(i % c4);
     const int slot = pos[r] - start;
     float4 gg = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (slot >= 0 && slot < nb) gg = reinterpret_cast<const float4*>(gb + (size_t)slot * ld)[c];
+    if (slot >= 0 && slot < nb) {
+      const float* gp0 = gb + (size_t)slot * ld + 4 * c;
+      gg = *reinterpret_cast<const float4*>(gp0);
+#pragma unroll 8
+      for (int sp = 1; sp < gsplit; ++sp) {   // independent loads: several slabs in flight
+        const float4 q = *reinterpret_cast<const float4*>(gp0 + (size_t)sp * gstride);
+        gg.x += q.x; gg.y += q.y; gg.z += q.z; gg.w += q.w;
+      }
+    }
     float4 t = reinterpret_cast<float4*>(th)[i];
     float4 m = reinterpret_cast<float4*>(mo)[i];
     float4 v = reinterpret_cast<float4*>(vo)[i];

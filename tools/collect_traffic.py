@@ -1,65 +1,81 @@
 #!/usr/bin/env python3
-"""HBM traffic per launch of each GEMM class of the bench step from rocprofv3 PMC passes.
+"""HBM traffic per launch of every kernel class of the bench step from rocprofv3 PMC passes.
 
-    tools/collect_traffic.py PLAN_LOG FETCH_DIR WRITE_DIR > profiles/rNN_traffic.json
+    tools/collect_traffic.py FETCH_DIR WRITE_DIR [B N k e U] > profiles/rNN_traffic.json
 
-PLAN_LOG holds the `[ganmf plan]` lines (GANMF_DEBUG_PLAN=1) mapping a kernel class of the step to its
-template instantiation and grid; FETCH_DIR / WRITE_DIR are the outputs of two separate rocprofv3
---pmc passes (FETCH_SIZE, WRITE_SIZE: they do not fit one pass, MI355X_MICROARCH §rocprofv3 PMC slots).
-Corrections per MI355X_MICROARCH §HBM: counters are in KiB; on gfx950 FETCH_SIZE reports exactly half
-the bytes of wide coalesced reads (16 B/lane global_load and global_load_lds alike) -> doubled."""
+FETCH_DIR / WRITE_DIR are the outputs of two separate `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`
+passes over `python3 bench.py --no-cpu-baseline` (the two counters do not fit one pass, MI355X_MICROARCH §rocprofv3).
+Dispatches are labelled by their ORDER inside a step (tools/step_classes.py), so classes that share a kernel
+instantiation and grid (decode of the D-step, decode of the G-step, gUb) are kept apart.
+Corrections per MI355X_MICROARCH §HBM: counters are in KiB; on gfx950 FETCH_SIZE reports exactly half the bytes of wide
+coalesced reads (16 B/lane global_load and global_load_lds alike) -> doubled.
+`algorithmic_bytes` = every operand read once, every result written once, fp32: 4(MK + KN + MN) per GEMM (+ the
+epilogue's second operand where it has one), and for the fused-Adam weight-gradient GEMMs the SIX streams of the update
+(theta, m, v read and written: 24 MN; the gradient itself never reaches HBM)."""
 import collections
-import csv
 import glob
 import json
 import os
-import re
 import sys
 
-LAYOUT = {"gemm_generator": ("false", "false"), "gemm_encode": ("false", "true"), "gemm_decode": ("false", "true"),
-          "gemm_dE": ("false", "false"), "gemm_gWd": ("true", "true"), "gemm_gWe": ("true", "true"),
-          "gemm_dF": ("false", "false"), "gemm_gUb": ("false", "true"), "gemm_gV": ("true", "true"),
-          "gemm_scores": ("false", "false")}
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from step_classes import label, load  # noqa: E402
+
+TAG = {"gen": "gemm_generator[B,k]x[N,k]^T", "encode": "gemm_encode[2B,N]x[N,e]", "decode": "gemm_decode[2B,e]x[e,N]",
+       "dE": "gemm_dE[2B,N]x[e,N]^T", "gWd+adam": "gemm_gWd[2B,e]^Tx[2B,N]", "gWe+adam": "gemm_gWe[2B,N]^Tx[2B,e]",
+       "dF": "gemm_dF[B,e]x[N,e]^T", "gUb": "gemm_gUb[B,N]x[N,k]", "gV+adam": "gemm_gV[B,N]^Tx[B,k]",
+       "densify+gather": "densify_rows+gather", "d_coef": "d_coef+scale", "adam_rows_U": "adam_rows_U"}
 
 
-def counters(d, name):
+def algorithmic(cls, B, N, k, e, U):
+    step, name = cls.split(":")
+    g = lambda M, Nn, K: 4 * (M * K + K * Nn + M * Nn)
+    if name == "gen": return g(B, N, k)
+    if name == "encode": return g(2 * B, e, N + 1)
+    if name == "decode": return (2 if step == "D" else 1) * (4 * (B * (e + 1) + 2 * B * N)) + 4 * (e + 1) * N   # + the subtracted input
+    if name == "dE": return g(2 * B, e, N) if step == "D" else g(B, e, N) + 8 * B * e
+    if name == "gWd+adam": return 4 * (2 * B * (e + 1) + 2 * B * N) + 24 * (e + 1) * N
+    if name == "gWe+adam": return 4 * (2 * B * (N + 1) + 2 * B * e) + 24 * (N + 1) * e
+    if name == "dF": return g(B, N, e) + 4 * B * N
+    if name == "gUb": return g(B, k, N)
+    if name == "gV+adam": return 4 * (B * N + B * k) + 24 * N * k
+    if name == "adam_rows_U": return 24 * U * k + 4 * B * k
+    if name == "densify+gather": return 4 * B * (N + 2 * k)
+    if name == "d_coef": return 8 * 2 * B * e
+    if name.startswith("reduce("):
+        inner = name[7:-1]
+        M, Nn = {"encode": (2 * B, e), "decode": (B, N), "dE": ((2 * B if step == "D" else B), e), "dF": (B, N), "gUb": (B, k)}.get(inner, (0, 0))
+        return 4 * M * Nn     # + nsplit slabs read, which are not algorithmic
+    return 0
+
+
+def per_class(d, counter):
     f = max(glob.glob(d + "/*/*counter_collection.csv"), key=os.path.getmtime)   # newest pass if the directory was reused
-    acc = collections.defaultdict(list)
-    for r in csv.DictReader(open(f)):
-        if r["Counter_Name"] == name:
-            acc[(r["Kernel_Name"], r["Grid_Size"])].append(float(r["Counter_Value"]))
+    acc = collections.OrderedDict()
+    for cls, disp in label(load(f)):
+        a = acc.setdefault(cls, {"n": 0, "v": 0.0, "kernel": disp["name"]})
+        a["n"] += 1
+        a["v"] += disp["counters"].get(counter, 0.0)
     return acc
 
 
-plan_log, fdir, wdir = sys.argv[1:4]
-fetch, write = counters(fdir, "FETCH_SIZE"), counters(wdir, "WRITE_SIZE")
-out = {}
-for line in open(plan_log):
-    m = re.search(r"\[ganmf plan\] (\S+)\s+M=(\d+) N=(\d+) K=(\d+) batch=(\d+) -> tile (\d+) ring (\d+) nsplit (\d+) \(kps \d+\) mfma (\S+) wgs (\d+)", line)
-    if not m:
-        continue
-    g = m.groups()
-    tag, mode = g[0], g[8]
-    M, N, K, nb, tile, ring, ns, wgs = map(int, g[1:8] + (g[9],))
-    base = tag.split("[")[0]
-    if base not in LAYOUT:
-        continue
-    a, b = LAYOUT[base]
-    bk = 32 if tile == 128 else 64
-    if mode == "f32":
-        pat = "gemm_f32_mfma<%d, %d, %d, %d, %s, %s>" % (tile, tile, bk, ring, a, b)
-    else:   # bf16 matrix-core kernels (gemm_bf16s.hpp): <BM, BN, BK, AKM, BKM, NPIECE>
-        pat = "gemm_bf16s_mfma<%d, %d, %d, %s, %s, %d>" % (tile, tile, bk, a, b, 3 if mode == "bf16x3" else 1)
-    key = [k for k in fetch if pat in k[0] and int(k[1]) == wgs * 256]
-    if not key:
-        continue
-    k0 = key[0]
-    f_kib = sum(fetch[k0]) / len(fetch[k0])
-    w_kib = sum(write[k0]) / len(write[k0]) if k0 in write else 0.0
-    name = "%s M=%d N=%d K=%d batch=%d" % (tag, M, N, K, nb) + ("" if mode == "f32" else " mfma=" + mode)
-    out[name] = {"kernel": pat, "grid_threads": wgs * 256, "launches_sampled": len(fetch[k0]),
-                 "FETCH_SIZE_KiB_raw": round(f_kib, 1), "WRITE_SIZE_KiB_raw": round(w_kib, 1),
-                 "hbm_bytes_per_launch": int((2 * f_kib + w_kib) * 1024),
-                 "algorithmic_bytes": 4 * nb * (M * K + M * N) + 4 * N * K,
-                 "note": "shared (kernel, grid) with another class" if sum(1 for l in open(plan_log) if "wgs %d " % wgs in l and "tile %d " % tile in l) > 1 else ""}
-json.dump(out, sys.stdout, indent=1)
+def main():
+    fdir, wdir = sys.argv[1:3]
+    B, N, k, e, U = [int(x) for x in sys.argv[3:8]] if len(sys.argv) >= 8 else (128, 3706, 250, 992, 6040)
+    fetch, write = per_class(fdir, "FETCH_SIZE"), per_class(wdir, "WRITE_SIZE")
+    out = collections.OrderedDict()
+    for cls, f in fetch.items():
+        w = write.get(cls, {"n": 1, "v": 0.0})
+        f_kib, w_kib = f["v"] / f["n"], w["v"] / max(w["n"], 1)
+        step, name = cls.split(":")
+        tag = TAG.get(name, name)
+        out["%s (%s-step)" % (tag, step)] = {
+            "class": cls, "kernel": f["kernel"].replace("void ganmf::", "").split("(")[0], "launches_sampled": f["n"],
+            "FETCH_SIZE_KiB_raw": round(f_kib, 1), "WRITE_SIZE_KiB_raw": round(w_kib, 1),
+            "hbm_bytes_per_launch": int((2 * f_kib + w_kib) * 1024),
+            "algorithmic_bytes": int(algorithmic(cls, B, N, k, e, U))}
+    json.dump(out, sys.stdout, indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,111 @@
+#!/usr/bin/env python3
+"""rocprofv3 output of a bench.py run -> one row per GEMM / kernel CLASS of the training step, labelled by DISPATCH ORDER.
+
+Several classes share a (kernel, grid) pair (decode of the D-step, decode of the G-step and gUb are all
+`gemm_f32_mfma<64,64,64,3,false,true>` on 232 workgroups), so grouping by name cannot separate them.  The library
+launches a step in a fixed order (ganmf_hip.hip d_step / g_step):
+
+  D-step: densify, gen, encode[, reduce], decode[, reduce], d_coef, dE[, reduce], gWd+Adam, gWe+Adam
+  G-step: densify, gen, encode[, reduce], decode[, reduce], dE[, reduce], dF[, reduce], gUb[, reduce], gV+Adam, adam_rows_U
+
+A step starts at `densify_rows_kernel` (or `sparse_front_kernel`); it is a D-step when it contains `d_coef_kernel`.
+
+usage: step_classes.py <kernel_trace.csv | counter_collection.csv> [> out.md]
+With a counter file every counter is averaged per class next to the duration (PMC runs serialise kernels, so durations
+there are for orientation only)."""
+import collections
+import csv
+import sys
+
+D_GEMMS = ["gen", "encode", "decode", "dE", "gWd+adam", "gWe+adam"]
+G_GEMMS = ["gen", "encode", "decode", "dE", "dF", "gUb", "gV+adam"]
+
+
+def load(path):
+    rows = list(csv.DictReader(open(path)))
+    by = collections.OrderedDict()
+    for r in rows:
+        d = int(r["Dispatch_Id"])
+        e = by.setdefault(d, {"name": r["Kernel_Name"], "counters": {}, "start": None, "end": None,
+                              "grid": r.get("Grid_Size_X") or r.get("Grid_Size"), "lds": r.get("LDS_Block_Size"),
+                              "wgsize": r.get("Workgroup_Size_X") or r.get("Workgroup_Size") or "256"})
+        if r.get("Start_Timestamp") and r.get("End_Timestamp"):
+            e["start"], e["end"] = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        if "Counter_Name" in r:
+            e["counters"][r["Counter_Name"]] = e["counters"].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+    return [by[k] for k in sorted(by)]
+
+
+def label(disp):
+    steps, cur = [], None
+    for d in disp:
+        n = d["name"]
+        if "densify_rows_kernel" in n or "sparse_front_kernel" in n:
+            cur = [d]
+            steps.append(cur)
+        elif cur is not None:
+            if "persist" in n or "mask_topk" in n or "gather_rows" in n or "finish_parts" in n or "rocclr" in n:
+                cur = None      # scoring / epoch end: not part of a step
+            else:
+                cur.append(d)
+    out = []
+    for st in steps:
+        is_d = any("d_coef_kernel" in d["name"] for d in st)
+        names = D_GEMMS if is_d else G_GEMMS
+        gi, last = 0, None
+        kind = "D" if is_d else "G"
+        ok = sum(1 for d in st if "gemm_" in d["name"]) == len(names)
+        if not ok:
+            continue      # a truncated step at the edge of the trace
+        for d in st:
+            n = d["name"]
+            if "densify" in n or "sparse_front" in n:
+                lab = "densify+gather"
+            elif "gemm_" in n:
+                lab = names[gi]; gi += 1; last = lab
+            elif "splitk_reduce" in n:
+                lab = "reduce(%s)" % last
+            elif "d_coef" in n:
+                lab = "d_coef"
+            elif "adam_rows" in n:
+                lab = "adam_rows_U"
+            elif "adam_dense" in n:
+                lab = "adam_dense"
+            else:
+                lab = n.split("(")[0][-30:]
+            out.append((kind + ":" + lab, d))
+    return out
+
+
+def main():
+    disp = load(sys.argv[1])
+    lab = label(disp)
+    acc = collections.OrderedDict()
+    for k, d in lab:
+        a = acc.setdefault(k, {"n": 0, "us": 0.0, "c": collections.defaultdict(float), "kern": d["name"], "grid": d["grid"],
+                               "lds": d["lds"], "wgsize": d["wgsize"]})
+        a["n"] += 1
+        if d["start"] is not None:
+            a["us"] += (d["end"] - d["start"]) / 1e3
+        for cn, cv in d["counters"].items():
+            a["c"][cn] += cv
+    cnames = sorted({cn for a in acc.values() for cn in a["c"]})
+    per = {"D": 0.0, "G": 0.0}
+    print("| step:class | kernel | workgroups | launches | avg us |" + "".join(" %s |" % c for c in cnames))
+    print("|---|---|---|---|---|" + "---|" * len(cnames))
+    for k, a in acc.items():
+        kern = a["kern"].replace("void ganmf::", "").replace("ganmf::", "").split("(")[0][:48]
+        wg = ""
+        try:
+            wg = "%d x %s" % (int(a["grid"]) // int(a["wgsize"]), a["wgsize"])
+        except (TypeError, ValueError):
+            pass
+        avg = a["us"] / a["n"]
+        per[k[0]] += avg
+        print("| %s | `%s` | %s | %d | %.2f |" % (k, kern, wg, a["n"], avg) + "".join(" %.4g |" % (a["c"][c] / a["n"]) for c in cnames))
+    print("\nD-step %.1f us, G-step %.1f us, D+G pair %.1f us (sum of the class averages; %d labelled dispatches)" % (
+        per["D"], per["G"], per["D"] + per["G"], len(lab)))
+
+
+if __name__ == "__main__":
+    main()
