@@ -107,7 +107,7 @@ enum Tag : int {
   T_DENSIFY, T_GEMM_GEN, T_RED_GEN, T_GEMM_ENC, T_RED_ENC, T_GEMM_DEC, T_RED_DEC, T_DCOEF, T_GEMM_DE, T_RED_DE,
   T_GEMM_GWD, T_RED_GWD, T_GEMM_GWE, T_RED_GWE, T_ADAM_D, T_GEMM_DF, T_RED_DF, T_GEMM_GUB, T_RED_GUB, T_GEMM_GV,
   T_RED_GV, T_ADAM_V, T_ADAM_U, T_MULTIRED, T_ALLREDUCE, T_SCORE_GEMM, T_RED_SCORE, T_DIS_FWD, T_RED_DIS_FWD, T_DIS_HEAD,
-  T_DIS_GW, T_RED_DIS_GW, T_DIS_BWD, T_RED_DIS_BWD, T_COUNT
+  T_DIS_GW, T_RED_DIS_GW, T_DIS_BWD, T_RED_DIS_BWD, T_FRONT, T_GWD_RED, T_PAIR, T_COUNT
 };
 const char* const kTagName[T_COUNT] = {
   "densify_rows+gather", "gemm_generator[B,k]x[N,k]^T", "reduce_generator", "gemm_encode[2B,N]x[N,e]",
@@ -116,7 +116,8 @@ const char* const kTagName[T_COUNT] = {
   "gemm_dF[B,e]x[N,e]^T", "reduce_dF", "gemm_gUb[B,N]x[N,k]", "reduce_gUb", "gemm_gV[B,N]^Tx[B,k]", "reduce_gV",
   "adam_dense_V", "adam_rows_U", "multi_reduce", "rccl_allreduce", "gemm_scores", "reduce_scores",
   "gemm_dis_layer_fwd", "reduce_dis_layer_fwd", "dis_head", "gemm_dis_gW", "reduce_dis_gW", "gemm_dis_bwd",
-  "reduce_dis_bwd"};
+  "reduce_dis_bwd", "gemm_generator[B,k]x[N,k]^T + CSR rows (one launch)", "gemm_gWd[2B,e]^Tx[2B,N] + reduce_dE (one launch)",
+  "gemm_gUb[B,N]x[N,k] + gemm_gV[B,N]^Tx[B,k] (one launch)"};
 
 struct ProfRec { int tag; hipEvent_t a, b; double flops, bytes; };
 
@@ -477,8 +478,9 @@ int run_gemm(ganmf_handle* h, int tag_gemm, int tag_red, GemmP g, bool akm, bool
     const int n4 = (attach->N + 3) / 4;
     const int nred = (int)std::min<long long>(GEMM_RED_GRID, ((long long)attach->M * n4 + 255) / 256);
     const bool combined = pl.mode == MFMA_BF16X3 && pl.tile == 64 && pl.bk == 32 && pl.nsplit == 1 && akm && bkm &&
-                          !pl.persist && g.nbatch == 1 && attach->epi.sq_partials == nullptr && !h->prof;
+                          !pl.persist && g.nbatch == 1 && attach->epi.sq_partials == nullptr;
     if (combined) {
+      Scope s(h, T_GWD_RED, fl, by + 4.0 * (attach->nsplit + 1) * attach->M * attach->N, st);
       GemmP q = g;
       fill_plan(q, pl);
       const int ng = pl.tiles_m * pl.tiles_n;
@@ -611,7 +613,7 @@ int rows_and_generator(ganmf_handle* h, const int* rows_dev, int nb, int which, 
                 kTagName[T_GEMM_GEN], g.M, g.N, g.K, pl.kps, pl.tiles_m * pl.tiles_n, pl.est_us, nb);
       }
     }
-    Scope s(h, T_GEMM_GEN, gemm_flops(g.M, g.N, g.K), gemm_bytes(g.M, g.N, g.K) + 4.0 * nb * (N + 2 * k));
+    Scope s(h, T_FRONT, gemm_flops(g.M, g.N, g.K), gemm_bytes(g.M, g.N, g.K) + 4.0 * nb * (N + 2 * k));
     g.A = h->Ue.p; g.a_gather = rows_dev;        // A row r = U[rows[r]]: the lookup rides in the operand fetch
     fill_plan(g, pl);
     hipLaunchKernelGGL(front_kernel<4>, dim3(pl.tiles_m * pl.tiles_n + nb), dim3(1024), 0, h->st, g, d);
@@ -849,7 +851,7 @@ int gen_update(ganmf_handle* h, int nb, int start, int b_global, int* regn_v, fl
     TRY(all_gather(h, h->V.p, h->V.cap, 1));
   } else if (nb > 0) {
     bool paired = false;
-    if (fused && (h->multi & 2) && h->defer_gub && !h->prof && h->V_alt) {
+    if (fused && (h->multi & 2) && h->defer_gub && h->V_alt) {
       // gUb and gV in ONE launch (pair_kernel): both read dF; gUb reads the old V while gV's Adam epilogue writes the new V
       // into the second buffer, swapped in afterwards.  Only when both are planned onto the 16-wave fp32 ring kernel.
       GemmP g0{}, g1{};
@@ -875,8 +877,12 @@ int gen_update(ganmf_handle* h, int nb, int start, int b_global, int* regn_v, fl
         fill_plan(g1, p1);
         *regn_v = p1.sq_count;
         const int n0 = p0.tiles_m * p0.tiles_n * p0.nsplit, n1 = p1.tiles_m * p1.tiles_n;
-        hipLaunchKernelGGL(pair_kernel<4>, dim3(n0 + n1), dim3(1024), 0, h->st, g0, g1);
-        HIP_TRY(hipGetLastError());
+        {
+          Scope s(h, T_PAIR, gemm_flops(g0.M, g0.N, g0.K) + gemm_flops(g1.M, g1.N, g1.K),
+                  gemm_bytes(g0.M, g0.N, g0.K) + gemm_bytes(g1.M, g1.N, g1.K) + 24.0 * h->V.count());
+          hipLaunchKernelGGL(pair_kernel<4>, dim3(n0 + n1), dim3(1024), 0, h->st, g0, g1);
+          HIP_TRY(hipGetLastError());
+        }
         std::swap(h->V.p, h->V_alt);
         paired = true;
       }

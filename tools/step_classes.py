@@ -7,8 +7,10 @@ launches a step in a fixed order (ganmf_hip.hip d_step / g_step):
 
   D-step: densify, gen, encode[, reduce], decode[, reduce], d_coef, dE[, reduce], gWd+Adam, gWe+Adam
   G-step: densify, gen, encode[, reduce], decode[, reduce], dE[, reduce], dF[, reduce], gUb[, reduce], gV+Adam, adam_rows_U
+with the combined launches of gemm_multi.hpp standing in for their parts: `front_kernel` = densify + gen, `pair_kernel` =
+gUb + gV+Adam, `gemm_bf16s_red` = gWd+Adam + reduce(dE).
 
-A step starts at `densify_rows_kernel` (or `sparse_front_kernel`); it is a D-step when it contains `d_coef_kernel`.
+A step starts at `densify_rows_kernel` / `sparse_front_kernel` / `front_kernel`; it is a D-step when it contains `d_coef_kernel`.
 
 usage: step_classes.py <kernel_trace.csv | counter_collection.csv> [> out.md]
 With a counter file every counter is averaged per class next to the duration (PMC runs serialise kernels, so durations
@@ -36,11 +38,16 @@ def load(path):
     return [by[k] for k in sorted(by)]
 
 
+def _gemm_like(n):
+    return "gemm_" in n or "front_kernel" in n or "pair_kernel" in n
+
+
 def label(disp):
+    """[(class label, dispatch)] for every dispatch that belongs to a complete training step."""
     steps, cur = [], None
     for d in disp:
         n = d["name"]
-        if "densify_rows_kernel" in n or "sparse_front_kernel" in n:
+        if "densify_rows_kernel" in n or "sparse_front_kernel" in n or "front_kernel" in n:
             cur = [d]
             steps.append(cur)
         elif cur is not None:
@@ -51,17 +58,23 @@ def label(disp):
     out = []
     for st in steps:
         is_d = any("d_coef_kernel" in d["name"] for d in st)
-        names = D_GEMMS if is_d else G_GEMMS
+        paired = any("pair_kernel" in d["name"] for d in st)
+        names = list(D_GEMMS if is_d else G_GEMMS)
+        if paired:
+            names = names[:5] + ["gUb+gV+adam"]
         gi, last = 0, None
         kind = "D" if is_d else "G"
-        ok = sum(1 for d in st if "gemm_" in d["name"]) == len(names)
-        if not ok:
+        if sum(1 for d in st if _gemm_like(d["name"])) != len(names):
             continue      # a truncated step at the edge of the trace
         for d in st:
             n = d["name"]
-            if "densify" in n or "sparse_front" in n:
+            if "front_kernel" in n and "sparse" not in n:
+                lab = "gen+rows"; gi += 1; last = "gen"          # generator GEMM + CSR row expansion in one launch
+            elif "densify" in n or "sparse_front" in n:
                 lab = "densify+gather"
-            elif "gemm_" in n:
+            elif "gemm_bf16s_red" in n:
+                lab = names[gi] + "+reduce(%s)" % last; gi += 1  # the slab sum of the previous product rides in this launch
+            elif _gemm_like(n):
                 lab = names[gi]; gi += 1; last = lab
             elif "splitk_reduce" in n:
                 lab = "reduce(%s)" % last
@@ -90,9 +103,14 @@ def main():
         for cn, cv in d["counters"].items():
             a["c"][cn] += cv
     cnames = sorted({cn for a in acc.values() for cn in a["c"]})
+    # derived columns when the SQ pass is present.  SQ_BUSY_CYCLES is summed over the 32 shader engines (8 XCDs x 4) and
+    # SQ_VALU_MFMA_BUSY_CYCLES over the 1024 SIMDs (256 CUs x 4): clock = busy cycles per SE / duration, MFMA utilisation
+    # = MFMA-busy cycles per SIMD / busy cycles per SE
+    derived = "SQ_BUSY_CYCLES" in cnames and "SQ_VALU_MFMA_BUSY_CYCLES" in cnames
     per = {"D": 0.0, "G": 0.0}
-    print("| step:class | kernel | workgroups | launches | avg us |" + "".join(" %s |" % c for c in cnames))
-    print("|---|---|---|---|---|" + "---|" * len(cnames))
+    print("| step:class | kernel | workgroups | launches | avg us |" + "".join(" %s |" % c for c in cnames) +
+          (" clock GHz | MFMA busy % |" if derived else ""))
+    print("|---|---|---|---|---|" + "---|" * (len(cnames) + (2 if derived else 0)))
     for k, a in acc.items():
         kern = a["kern"].replace("void ganmf::", "").replace("ganmf::", "").split("(")[0][:48]
         wg = ""
@@ -102,7 +120,11 @@ def main():
             pass
         avg = a["us"] / a["n"]
         per[k[0]] += avg
-        print("| %s | `%s` | %s | %d | %.2f |" % (k, kern, wg, a["n"], avg) + "".join(" %.4g |" % (a["c"][c] / a["n"]) for c in cnames))
+        extra = ""
+        if derived:
+            busy_se = a["c"]["SQ_BUSY_CYCLES"] / a["n"] / 32.0
+            extra = " %.2f | %.1f |" % (busy_se / max(avg, 1e-9) / 1e3, 100.0 * a["c"]["SQ_VALU_MFMA_BUSY_CYCLES"] / a["n"] / 1024.0 / max(busy_se, 1.0))
+        print("| %s | `%s` | %s | %d | %.2f |" % (k, kern, wg, a["n"], avg) + "".join(" %.4g |" % (a["c"][c] / a["n"]) for c in cnames) + extra)
     print("\nD-step %.1f us, G-step %.1f us, D+G pair %.1f us (sum of the class averages; %d labelled dispatches)" % (
         per["D"], per["G"], per["D"] + per["G"], len(lab)))
 
