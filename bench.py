@@ -16,7 +16,8 @@ Workload at every N: BASELINE.json configs[1] — "GANMF --user on MovieLens-1M 
 d_reg=1e-4, alpha=0.01) on a synthetic binary user x item matrix of that shape and density
 (ganmf_amd/synthetic.py), resident in HBM as CSR before the timed region.  With N > 1 GPUs each
 rank holds its own 6040-user shard (global users = 6040*N, weak scaling) and the gradients of the
-replicated tensors are all-reduced over RCCL every step; `value` counts the 128-row minibatch
+replicated tensors are reduce-scattered over RCCL every step (Adam on the rank's slice, parameters
+all-gathered: DESIGN.md section 6); `value` counts the 128-row minibatch
 updates all ranks processed per second (= N x synchronous global steps/s).
 
 Extra objects on the JSON line: `roofline` (dominant kernel of the step, HIP-event timed on the
@@ -247,11 +248,13 @@ def main():
             "config": {"workload": "GANMF --user, MovieLens-1M shape %dx%d per GPU, k=%d, emb_dim=%d, batch=%d/GPU, "
                                    "tuned hyper-parameters (BASELINE.json configs[1])" % (w["U"], w["N"], w["k"], w["e"], w["B"]),
                        "step": "one 128-row minibatch update (D or G), K/2 D then K/2 G",
-                       "arithmetic": "float32 tensors throughout; GEMM K loops on the fp32 MFMA, except the two fused-Adam "
-                                     "weight-gradient GEMMs of the D-step, which run the fp32-accurate split-bf16 loop "
-                                     "(3 exact bf16 pieces per operand, 6 piece products, fp32 accumulate)",
+                       "arithmetic": "float32 tensors throughout; GEMM K loops on the fp32 MFMA (16-wave workgroups), except the "
+                                     "two fused-Adam weight-gradient GEMMs of the D-step, which run the fp32-accurate split-bf16 "
+                                     "loop (3 exact bf16 pieces per operand, 6 piece products, fp32 accumulate)",
+                       "launches": "D-step 8, G-step 11 (generator GEMM + CSR rows, gUb + gV, gWd + slab sum of dE share a launch)",
                        "global_steps_per_s": round(done / el, 2), "rows_per_s": round(world * done * w["B"] / el, 1),
-                       "parallelism": "dp%d (users sharded row-wise, RCCL all-reduce of D and V gradients)" % world},
+                       "parallelism": "dp%d (users sharded row-wise; RCCL reduce-scatter of the D and V gradients, Adam on the rank's "
+                                      "slice, all-gather of the parameters)" % world},
             "roofline": roofline, "scoring_gemm": scoring, "kernels": kernels,
             "reference_derived_steps_per_s": 84.0,
         }
