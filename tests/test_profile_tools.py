@@ -1,0 +1,74 @@
+"""tools/step_classes.py and tools/collect_traffic.py on a synthetic rocprofv3 output: dispatches are labelled by their ORDER
+inside a step, so classes that share a kernel instantiation and grid stay apart, and the combined launches of
+csrc/gemm_multi.hpp stand in for their parts (CPU only: pure CSV processing)."""
+import csv
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+F32 = "void ganmf::gemm_f32_mfma<64, 64, 64, 3, false, true, 4>(ganmf::GemmP)"
+D_STEP = ["void ganmf::front_kernel<4>(ganmf::GemmP, ganmf::DensP)", F32, "ganmf::splitk_reduce_kernel(ganmf::RedP)", F32,
+          "ganmf::d_coef_kernel(float*)", F32, "ganmf::gemm_bf16s_red(ganmf::GemmP, ganmf::RedP, int)",
+          "void ganmf::gemm_bf16s_mfma<64, 64, 32, true, true, 3, false>(ganmf::GemmP)"]
+G_STEP = ["void ganmf::front_kernel<4>(ganmf::GemmP, ganmf::DensP)", F32, "ganmf::splitk_reduce_kernel(ganmf::RedP)", F32,
+          "ganmf::splitk_reduce_kernel(ganmf::RedP)", F32, "ganmf::splitk_reduce_kernel(ganmf::RedP)", F32,
+          "ganmf::splitk_reduce_kernel(ganmf::RedP)", "void ganmf::pair_kernel<4>(ganmf::GemmP, ganmf::GemmP)",
+          "ganmf::adam_rows_kernel(float*)"]
+OLD_G_STEP = ["ganmf::densify_rows_kernel(ganmf::DensP)", F32, F32, "ganmf::splitk_reduce_kernel(ganmf::RedP)", F32, F32, F32, F32,
+              "ganmf::splitk_reduce_kernel(ganmf::RedP)", F32, "ganmf::adam_rows_kernel(float*)"]
+
+
+def _write(path, steps, counter=None):
+    cols = ["Dispatch_Id", "Kernel_Name", "Start_Timestamp", "End_Timestamp", "Grid_Size_X", "Grid_Size", "Workgroup_Size_X",
+            "LDS_Block_Size"] + (["Counter_Name", "Counter_Value"] if counter else [])
+    t, d = 1000, 0
+    with open(path, "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=cols)
+        w.writeheader()
+        for names in steps:
+            for i, n in enumerate(names):
+                d += 1
+                row = {"Dispatch_Id": d, "Kernel_Name": n, "Start_Timestamp": t, "End_Timestamp": t + 1000 * (i + 1),
+                       "Grid_Size_X": 262144, "Grid_Size": 262144, "Workgroup_Size_X": 1024, "LDS_Block_Size": 98304}
+                if counter:
+                    row.update({"Counter_Name": counter, "Counter_Value": 100.0 * (i + 1)})
+                w.writerow(row)
+                t += 1000 * (i + 1)
+
+
+def test_labels_follow_dispatch_order(tmp_path):
+    from step_classes import label, load
+    p = tmp_path / "trace.csv"
+    _write(p, [D_STEP, G_STEP, D_STEP, OLD_G_STEP, D_STEP[:4]])      # the last step is truncated and must be dropped
+    lab = [k for k, _ in label(load(str(p)))]
+    assert lab[:8] == ["D:gen+rows", "D:encode", "D:reduce(encode)", "D:decode", "D:d_coef", "D:dE",
+                       "D:gWd+adam+reduce(dE)", "D:gWe+adam"]
+    assert lab[8:19] == ["G:gen+rows", "G:encode", "G:reduce(encode)", "G:decode", "G:reduce(decode)", "G:dE", "G:reduce(dE)",
+                         "G:dF", "G:reduce(dF)", "G:gUb+gV+adam", "G:adam_rows_U"]
+    old = lab[27:38]      # one kernel per piece: three consecutive launches of ONE instantiation are three classes
+    assert old == ["G:densify+gather", "G:gen", "G:encode", "G:reduce(encode)", "G:decode", "G:dE", "G:dF", "G:gUb",
+                   "G:reduce(gUb)", "G:gV+adam", "G:adam_rows_U"]
+    assert len(lab) == 8 + 11 + 8 + 11
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "step_classes.py"), str(p)], capture_output=True, text=True)
+    assert out.returncode == 0 and "| D:encode |" in out.stdout and "D+G pair" in out.stdout
+
+
+def test_traffic_per_class(tmp_path):
+    for name, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+        os.makedirs(tmp_path / name / "run")
+        _write(tmp_path / name / "run" / "1_counter_collection.csv", [D_STEP, G_STEP], counter)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "collect_traffic.py"), str(tmp_path / "fetch"),
+                          str(tmp_path / "write")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    d = json.loads(out.stdout)
+    enc = d["gemm_encode[2B,N]x[N,e] (D-step)"]
+    assert enc["FETCH_SIZE_KiB_raw"] == 200.0 and enc["hbm_bytes_per_launch"] == (2 * 200 + 200) * 1024     # FETCH doubled (gfx950)
+    assert enc["algorithmic_bytes"] == 4 * (256 * 3707 + 3707 * 992 + 256 * 992)
+    gw = d["gemm_gWd[2B,e]^Tx[2B,N] + reduce_dE (D-step)"]
+    assert gw["algorithmic_bytes"] >= 24 * 993 * 3706       # the six Adam streams are counted
+    assert "gemm_gUb[B,N]x[N,k] + gemm_gV[B,N]^Tx[B,k] (G-step)" in d
+    assert len({v["class"] for v in d.values()}) == len(d)      # no entry shared between classes
