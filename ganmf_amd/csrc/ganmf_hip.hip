@@ -197,6 +197,7 @@ struct ganmf_handle {
   float* fmp = nullptr;   // [RED_GRID]
   float* regp = nullptr;  // [slots][reg_cap] block partials of sum(theta^2): We_ext, Wd_ext, U, V, (DisGANMF layers)
   int reg_cap = 0;
+  int pair_ring = 2;      // LDS ring depth of the gUb + gV launch (GANMF_PAIR_RING)
   bool defer_gub = true;  // the split-K slabs of gUb are summed by adam_rows_kernel (no reduce launch)
   int multi = 7;          // combined launches (gemm_multi.hpp), bit 0: generator GEMM + CSR row expansion, bit 1: gUb + gV,
                           // bit 2: slab sum of dE inside the gWd launch (GANMF_MULTI)
@@ -880,7 +881,8 @@ int gen_update(ganmf_handle* h, int nb, int start, int b_global, int* regn_v, fl
         {
           Scope s(h, T_PAIR, gemm_flops(g0.M, g0.N, g0.K) + gemm_flops(g1.M, g1.N, g1.K),
                   gemm_bytes(g0.M, g0.N, g0.K) + gemm_bytes(g1.M, g1.N, g1.K) + 24.0 * h->V.count());
-          hipLaunchKernelGGL(pair_kernel<4>, dim3(n0 + n1), dim3(1024), 0, h->st, g0, g1);
+          if (h->pair_ring == 2) hipLaunchKernelGGL((pair_kernel<4, 2>), dim3(n0 + n1), dim3(1024), 0, h->st, g0, g1);
+          else hipLaunchKernelGGL((pair_kernel<4, 3>), dim3(n0 + n1), dim3(1024), 0, h->st, g0, g1);
           HIP_TRY(hipGetLastError());
         }
         std::swap(h->V.p, h->V_alt);
@@ -1308,6 +1310,7 @@ static int create_impl(const ganmf_cfg* cfg, ganmf_handle* h) {
   h->fuse_adam = env_int("GANMF_FUSE_ADAM", 1) != 0;
   h->defer_gub = env_int("GANMF_DEFER_GUB", 1) != 0;
   h->multi = env_int("GANMF_MULTI", 7);
+  h->pair_ring = env_int("GANMF_PAIR_RING", 2) == 3 ? 3 : 2;
   h->inkernel_reduce = env_int("GANMF_INKERNEL_REDUCE", 0) != 0;   // measured slower than the chip-wide reduce kernel
   h->inlaunch_max = env_int("GANMF_INLAUNCH_MAX", 4);
   TRY(dalloc((float**)&h->counters, COUNTER_CAP));

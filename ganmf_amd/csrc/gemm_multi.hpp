@@ -31,13 +31,15 @@ __global__ __launch_bounds__(256 * KG) void front_kernel(const GemmP g, const De
 }
 
 // blocks [0, n0): g0, an NN GEMM; blocks [n0, n0 + n1): g1, a TN GEMM
-template <int KG>
+// NS = 2: 64 KiB of LDS and 52 VGPRs per workgroup, so TWO of the 16-wave workgroups share a CU and the 464 workgroups of
+// the C2 pair are resident in one round (with the 96 KiB ring of the single-GEMM launches they ran as two rounds)
+template <int KG, int NS>
 __global__ __launch_bounds__(256 * KG) void pair_kernel(const GemmP g0, const GemmP g1) {
-  __shared__ __attribute__((aligned(16))) float smem[3 * (64 + 64) * 64];
+  __shared__ __attribute__((aligned(16))) float smem[NS * (64 + 64) * 64];
   const int n0 = g0.tiles_m * g0.tiles_n * g0.nsplit * g0.nbatch;
   const int n1 = g1.tiles_m * g1.tiles_n * g1.nsplit * g1.nbatch;
-  if ((int)blockIdx.x < n0) gemm_f32_body<64, 64, 64, 3, false, true, KG>(g0, (int)blockIdx.x, n0, smem);
-  else gemm_f32_body<64, 64, 64, 3, true, true, KG>(g1, (int)blockIdx.x - n0, n1, smem);
+  if ((int)blockIdx.x < n0) gemm_f32_body<64, 64, 64, NS, false, true, KG>(g0, (int)blockIdx.x, n0, smem);
+  else gemm_f32_body<64, 64, 64, NS, true, true, KG>(g1, (int)blockIdx.x - n0, n1, smem);
 }
 
 // blocks [0, ng): 64 x 64 x 32 tiles of the TN split-bf16 GEMM; blocks [ng, ng + nred): slab reduce of ANOTHER product
