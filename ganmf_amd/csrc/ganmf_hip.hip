@@ -178,8 +178,11 @@ struct ganmf_handle {
   bool has_urm = false;
   bool sparse_g = false;   // generator steps take the real rows' encodings from a CSR row-sum (no densify of X)
   // epoch schedule
-  int* perm = nullptr;
+  int* perm = nullptr;      // [2U] device: the epoch's permutation, then (pos = perm + U) its inverse
   int* pos = nullptr;
+  int* stage_i = nullptr;   // pinned host staging (ensure_stage)
+  float* stage_f = nullptr;
+  size_t stage_i_cap = 0, stage_f_cap = 0;
   // minibatch work buffers
   float *XF = nullptr, *Ub = nullptr, *E = nullptr, *Es = nullptr, *Dl = nullptr, *dE = nullptr, *dF = nullptr, *gUb = nullptr;
   float* zero_page = nullptr;
@@ -1158,6 +1161,24 @@ int arenas_finish(ganmf_handle* h, int64_t nd, int64_t ng) {
   return 0;
 }
 
+// pinned host staging (ints: permutation | inverse permutation; floats: loss parts), grown on demand
+int ensure_stage(ganmf_handle* h, size_t n_int, size_t n_float) {
+  if (n_int > h->stage_i_cap) {
+    if (h->stage_i) hipHostFree(h->stage_i);
+    h->stage_i = nullptr; h->stage_i_cap = 0;
+    HIP_TRY(hipHostMalloc((void**)&h->stage_i, n_int * sizeof(int), hipHostMallocDefault));
+    h->stage_i_cap = n_int;
+  }
+  if (n_float > h->stage_f_cap) {
+    if (h->stage_f) hipHostFree(h->stage_f);
+    h->stage_f = nullptr; h->stage_f_cap = 0;
+    const size_t want = n_float + n_float / 2 + 256;
+    HIP_TRY(hipHostMalloc((void**)&h->stage_f, want * sizeof(float), hipHostMallocDefault));
+    h->stage_f_cap = want;
+  }
+  return 0;
+}
+
 int ensure_parts(ganmf_handle* h, int64_t steps) {
   if (steps <= h->parts_cap) return 0;
   HIP_TRY(hipStreamSynchronize(h->st));
@@ -1345,8 +1366,8 @@ static int create_impl(const ganmf_cfg* cfg, ganmf_handle* h) {
     h->Wo.g = gp;
   }
   TRY(dalloc(&h->zero_page, 2048 + 64));   // 8 KiB: one 32-byte line per lane of a workgroup
-  TRY(dalloc((float**)&h->perm, U));
-  TRY(dalloc((float**)&h->pos, U));
+  TRY(dalloc((float**)&h->perm, (size_t)2 * U));
+  h->pos = h->perm + U;
   TRY(dalloc(&h->XF, (size_t)2 * B * h->ldN));
   TRY(dalloc(&h->Ub, (size_t)B * h->ldk));
   TRY(dalloc(&h->dF, (size_t)B * h->ldN));
@@ -1404,7 +1425,9 @@ int ganmf_destroy(ganmf_handle* h) {
   for (float* a : h->Al) hipFree(a);
   hipFree(h->dz0); hipFree(h->dz1); hipFree(h->dlogit); hipFree(h->lossrow);
   free_tensor(h->Ue, false); free_tensor(h->V, true); hipFree(h->V_alt);
-  hipFree(h->gD); hipFree(h->indptr); hipFree(h->indices); hipFree(h->data); hipFree(h->perm); hipFree(h->pos);
+  hipFree(h->gD); hipFree(h->indptr); hipFree(h->indices); hipFree(h->data); hipFree(h->perm);
+  if (h->stage_i) hipHostFree(h->stage_i);
+  if (h->stage_f) hipHostFree(h->stage_f);
   hipFree(h->XF); hipFree(h->Ub); hipFree(h->E); hipFree(h->Dl); hipFree(h->dE); hipFree(h->dF); hipFree(h->gUb);
   hipFree(h->slab); hipFree(h->rs); hipFree(h->scal); hipFree(h->sqp); hipFree(h->fmp);
   hipFree(h->seen_indptr); hipFree(h->seen_indices); hipFree(h->topk_items); hipFree(h->topk_vals); hipFree(h->sc_ids);
@@ -1555,12 +1578,19 @@ int ganmf_train_epoch(ganmf_handle* h, const int32_t* perm, int64_t n, int32_t d
   const int64_t local_steps = (n + B - 1) / B;
   const int64_t per_pass = std::max(local_steps, n_steps_per_pass);
   if (per_pass == 0) return 0;
-  std::vector<int> pos(h->U, -1);
+  // the permutation and its inverse go up from ONE pinned staging buffer in one asynchronous copy, the loss parts come back
+  // into pinned memory: pageable copies are staged synchronously by the runtime, ~0.1 ms per epoch call that a 10-slice call
+  // (2.6 ms of GPU work) notices
+  TRY(ensure_stage(h, (size_t)2 * h->U, 0));
+  int* const stage_perm = h->stage_i;
+  int* const pos = h->stage_i + h->U;
+  std::fill(pos, pos + h->U, -1);
   for (int64_t i = 0; i < n; ++i) {
     const int r = perm[i];
     if (r < 0 || r >= h->U) return fail(-1, "ganmf_train_epoch: row id %d out of range at %lld", r, (long long)i);
     if (pos[r] != -1) return fail(-1, "ganmf_train_epoch: row id %d appears twice in the permutation", r);
     pos[r] = (int)i;
+    stage_perm[i] = r;
   }
   std::vector<int> bglob(per_pass);
   for (int64_t i = 0; i < per_pass; ++i) {
@@ -1569,8 +1599,7 @@ int ganmf_train_epoch(ganmf_handle* h, const int32_t* perm, int64_t n, int32_t d
     bglob[i] = global_batch_rows ? global_batch_rows[i] : nb;
     if (bglob[i] < nb || bglob[i] < 1) return fail(-1, "ganmf_train_epoch: global_batch_rows[%lld]=%d < local %d", (long long)i, bglob[i], nb);
   }
-  HIP_TRY(hipMemcpyAsync(h->perm, perm, n * sizeof(int), hipMemcpyHostToDevice, h->st));
-  HIP_TRY(hipMemcpyAsync(h->pos, pos.data(), (size_t)h->U * sizeof(int), hipMemcpyHostToDevice, h->st));
+  HIP_TRY(hipMemcpyAsync(h->perm, stage_perm, (size_t)2 * h->U * sizeof(int), hipMemcpyHostToDevice, h->st));   // perm | pos, contiguous on both sides
   const int64_t nd = (int64_t)d_steps * per_pass, ng = (int64_t)g_steps * per_pass;
   TRY(ensure_parts(h, std::max(nd, ng)));
   HIP_TRY(hipMemsetAsync(h->d_parts, 0, (size_t)std::max<int64_t>(nd, 1) * 4 * sizeof(float), h->st));
@@ -1607,10 +1636,12 @@ int ganmf_train_epoch(ganmf_handle* h, const int32_t* perm, int64_t n, int32_t d
     }
   }
   if (dist && ng > 0) TRY(allreduce(h, h->g_parts, (size_t)ng * 4));
-  std::vector<float> dp((size_t)std::max<int64_t>(nd, 1) * 4), gp((size_t)std::max<int64_t>(ng, 1) * 4);
-  HIP_TRY(hipMemcpyAsync(dp.data(), h->d_parts, dp.size() * sizeof(float), hipMemcpyDeviceToHost, h->st));
-  HIP_TRY(hipMemcpyAsync(gp.data(), h->g_parts, gp.size() * sizeof(float), hipMemcpyDeviceToHost, h->st));
+  const size_t ndp = (size_t)std::max<int64_t>(nd, 1) * 4, ngp = (size_t)std::max<int64_t>(ng, 1) * 4;
+  TRY(ensure_stage(h, 0, ndp + ngp));
+  HIP_TRY(hipMemcpyAsync(h->stage_f, h->d_parts, ndp * sizeof(float), hipMemcpyDeviceToHost, h->st));
+  HIP_TRY(hipMemcpyAsync(h->stage_f + ndp, h->g_parts, ngp * sizeof(float), hipMemcpyDeviceToHost, h->st));
   HIP_TRY(hipStreamSynchronize(h->st));
+  const std::vector<float> dp(h->stage_f, h->stage_f + ndp), gp(h->stage_f + ndp, h->stage_f + ndp + ngp);
   finish_losses(h, dp, gp, bglob, nd, ng, per_pass, d_losses, g_losses);
   return 0;
 }
