@@ -243,6 +243,24 @@ class GANMF(BaseRecommender):
             items[i, :len(row)] = row
         return items
 
+    def evaluate_on_device(self, evaluator_key, urm_test_sorted, gains, user_id_array, cutoffs, disc, ideal_cum,
+                           remove_seen_flag=True):
+        """Hold-out metric sums for EvaluatorHoldoutFast without leaving the device (ganmf_evaluate): [len(cutoffs), 9]
+        float64 in the order of ganmf_amd._lib.EVAL_METRICS, or None when the device route does not apply (cut-off beyond
+        the device selection, too many cut-offs).  The test matrix is uploaded once per evaluator (`evaluator_key`)."""
+        from . import _lib as L
+        self._require_engine()
+        cutoffs = list(cutoffs)
+        if not cutoffs or len(cutoffs) > L.EVAL_MAX_CUTOFFS or not (1 <= max(cutoffs) <= min(self._DEVICE_TOPK_MAX, self.n_items)):
+            return None
+        if min(cutoffs) < 1:
+            return None
+        if getattr(self, "_test_on_device", None) != (evaluator_key, id(self.engine)):
+            self.engine.set_test(urm_test_sorted, gains)
+            self._test_on_device = (evaluator_key, id(self.engine))
+        return self.engine.evaluate(np.asarray(user_id_array).reshape(-1), cutoffs, disc, ideal_cum,
+                                    transposed=(self.mode == 'item'), remove_seen=remove_seen_flag)
+
     def recommend(self, user_id_array, cutoff=None, remove_seen_flag=True, items_to_compute=None,
                   remove_top_pop_flag=False, remove_CustomItems_flag=False, return_scores=False):
         device_ok = (not return_scores and items_to_compute is None and not remove_top_pop_flag

@@ -14,6 +14,8 @@ MFMA_FLAGS = {None: 0, "auto": 0, "f32": FLAG_MFMA_F32, "bf16": FLAG_MFMA_BF16, 
 ACT = {"linear": 0, "tanh": 1, "relu": 2, "sigmoid": 3}
 T_USER_EMB, T_ITEM_EMB = 100, 101
 SLOT_PARAM, SLOT_ADAM_M, SLOT_ADAM_V, SLOT_BEST = 0, 1, 2, 3
+EVAL_METRICS = ("ROC_AUC", "PRECISION", "PRECISION_RECALL_MIN_DEN", "RECALL", "MAP", "MRR", "NDCG", "HIT_RATE", "ARHR")
+EVAL_MAX_CUTOFFS = 8
 PROF_MAX = 48
 
 # every exported symbol of include/ganmf_hip.h (checked by tests/test_abi.py)
@@ -21,7 +23,7 @@ SYMBOLS = [
     "ganmf_create", "ganmf_destroy", "ganmf_comm_unique_id", "ganmf_comm_init", "ganmf_comm_init_local", "ganmf_set_urm_csr",
     "ganmf_set_tensor", "ganmf_get_tensor", "ganmf_tensor_shape", "ganmf_get_adam_powers",
     "ganmf_set_adam_powers", "ganmf_train_epoch", "ganmf_train_step", "ganmf_scores",
-    "ganmf_set_seen_csr", "ganmf_recommend", "ganmf_snapshot_best", "ganmf_restore_best", "ganmf_profile_enable", "ganmf_profile_read",
+    "ganmf_set_seen_csr", "ganmf_recommend", "ganmf_set_test_csr", "ganmf_evaluate", "ganmf_snapshot_best", "ganmf_restore_best", "ganmf_profile_enable", "ganmf_profile_read",
     "ganmf_bench_scores", "ganmf_gemm_f32", "ganmf_crc32c", "ganmf_device_count", "ganmf_abi_version", "ganmf_last_error",
 ]
 
@@ -88,6 +90,9 @@ def load_library():
         "ganmf_scores": (C.c_int, [vp, P(C.c_int32), i64, C.c_int, f32p]),
         "ganmf_set_seen_csr": (C.c_int, [vp, P(C.c_int64), P(C.c_int32), i64, i64]),
         "ganmf_recommend": (C.c_int, [vp, P(C.c_int32), i64, C.c_int, i32, C.c_int, P(C.c_int32), f32p]),
+        "ganmf_set_test_csr": (C.c_int, [vp, P(C.c_int64), P(C.c_int32), P(C.c_double), i64, i64]),
+        "ganmf_evaluate": (C.c_int, [vp, P(C.c_int32), i64, C.c_int, C.c_int, P(C.c_int32), i32, P(C.c_double), P(C.c_double),
+                                     P(C.c_double)]),
         "ganmf_crc32c": (C.c_uint32, [C.c_uint32, vp, C.c_uint64]),
         "ganmf_snapshot_best": (C.c_int, [vp]),
         "ganmf_restore_best": (C.c_int, [vp]),

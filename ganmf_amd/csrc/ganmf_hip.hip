@@ -218,6 +218,13 @@ struct ganmf_handle {
   int* topk_items = nullptr;
   float* topk_vals = nullptr;
   size_t topk_cap = 0;
+  // ganmf_evaluate(): URM_test in evaluation orientation (sorted rows) with the DCG gains, work buffers
+  long long* test_indptr = nullptr;
+  int* test_indices = nullptr;
+  double* test_gain = nullptr;
+  int64_t test_rows = 0, test_cols = 0;
+  double* eval_buf = nullptr;      // disc | ideal_cum | block partials
+  size_t eval_cap = 0;
   // scoring scratch
   int* sc_ids = nullptr;
   size_t sc_ids_cap = 0;
@@ -1428,6 +1435,7 @@ int ganmf_destroy(ganmf_handle* h) {
   hipFree(h->gD); hipFree(h->indptr); hipFree(h->indices); hipFree(h->data); hipFree(h->perm);
   if (h->stage_i) hipHostFree(h->stage_i);
   if (h->stage_f) hipHostFree(h->stage_f);
+  hipFree(h->test_indptr); hipFree(h->test_indices); hipFree(h->test_gain); hipFree(h->eval_buf);
   hipFree(h->XF); hipFree(h->Ub); hipFree(h->E); hipFree(h->Dl); hipFree(h->dE); hipFree(h->dF); hipFree(h->gUb);
   hipFree(h->slab); hipFree(h->rs); hipFree(h->scal); hipFree(h->sqp); hipFree(h->fmp);
   hipFree(h->seen_indptr); hipFree(h->seen_indices); hipFree(h->topk_items); hipFree(h->topk_vals); hipFree(h->sc_ids);
@@ -1762,17 +1770,18 @@ int ganmf_set_seen_csr(ganmf_handle* h, const int64_t* indptr, const int32_t* in
   return 0;
 }
 
-int ganmf_recommend(ganmf_handle* h, const int32_t* ids, int64_t n, int transposed, int32_t cutoff, int remove_seen,
-                    int32_t* out_items, float* out_scores) {
-  if (!h || !ids || !out_items) return fail(-1, "ganmf_recommend: null argument");
-  if (n < 1 || n > (1 << 30)) return fail(-1, "ganmf_recommend: n out of range");
+// scores -> seen mask -> top-`cutoff` of the rows `ids`, left on the device in h->topk_items / h->topk_vals ([n, cutoff]);
+// *ids_dev_out = the uploaded ids.  Shared by ganmf_recommend and ganmf_evaluate.
+static int recommend_device(ganmf_handle* h, const char* who, const int32_t* ids, int64_t n, int transposed, int32_t cutoff,
+                            int remove_seen, int** ids_dev_out) {
+  if (n < 1 || n > (1 << 30)) return fail(-1, "%s: n out of range", who);
   const int limit = transposed ? h->N : h->U, W = transposed ? h->U : h->N;
   if (cutoff < 1 || cutoff > W || cutoff > GANMF_RECOMMEND_MAX_CUTOFF)
-    return fail(-1, "ganmf_recommend: cutoff %d out of range [1,%d]", cutoff, std::min(W, GANMF_RECOMMEND_MAX_CUTOFF));
+    return fail(-1, "%s: cutoff %d out of range [1,%d]", who, cutoff, std::min(W, GANMF_RECOMMEND_MAX_CUTOFF));
   for (int64_t i = 0; i < n; ++i)
-    if (ids[i] < 0 || ids[i] >= limit) return fail(-1, "ganmf_recommend: id %d out of range [0,%d)", ids[i], limit);
+    if (ids[i] < 0 || ids[i] >= limit) return fail(-1, "%s: id %d out of range [0,%d)", who, ids[i], limit);
   if (remove_seen && (!h->seen_indptr || h->seen_rows != limit || h->seen_cols != W))
-    return fail(-1, "ganmf_recommend: remove_seen needs ganmf_set_seen_csr with a %d x %d matrix", limit, W);
+    return fail(-1, "%s: remove_seen needs ganmf_set_seen_csr with a %d x %d matrix", who, limit, W);
   HIP_TRY(hipSetDevice(h->dev));
   int* ids_dev = nullptr;
   TRY(upload_ids(h, ids, n, &ids_dev));
@@ -1786,20 +1795,99 @@ int ganmf_recommend(ganmf_handle* h, const int32_t* ids, int64_t n, int transpos
     h->topk_cap = need;
   }
   float* od = nullptr; int Wd = 0, ldw = 0;
-  int rc = scores_device(h, ids_dev, n, transposed, &od, &Wd, &ldw);
-  if (rc == 0) {
-    const int lds_cap = 32768;   // floats: 128 KiB of the CU's 160 KiB
-    const size_t shmem = Wd <= lds_cap ? (size_t)Wd * sizeof(float) : 0;
-    hipError_t e = hipSuccess;
-    if (shmem > 48 * 1024)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(mask_topk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    if (e == hipSuccess) {
-    hipLaunchKernelGGL(mask_topk_kernel, dim3((int)n), dim3(256), shmem, h->st, od, ldw, Wd, ids_dev,
-                       remove_seen ? h->seen_indptr : (const long long*)nullptr, h->seen_indices, (int)cutoff, lds_cap,
-                       h->topk_items, h->topk_vals);
-    e = hipGetLastError();
+  TRY(scores_device(h, ids_dev, n, transposed, &od, &Wd, &ldw));
+  const int lds_cap = 32768;   // floats: 128 KiB of the CU's 160 KiB
+  const size_t shmem = Wd <= lds_cap ? (size_t)Wd * sizeof(float) : 0;
+  if (shmem > 48 * 1024)
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mask_topk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+  hipLaunchKernelGGL(mask_topk_kernel, dim3((int)n), dim3(256), shmem, h->st, od, ldw, Wd, ids_dev,
+                     remove_seen ? h->seen_indptr : (const long long*)nullptr, h->seen_indices, (int)cutoff, lds_cap,
+                     h->topk_items, h->topk_vals);
+  HIP_TRY(hipGetLastError());
+  if (ids_dev_out) *ids_dev_out = ids_dev;
+  return 0;
+}
+
+int ganmf_set_test_csr(ganmf_handle* h, const int64_t* indptr, const int32_t* indices, const double* gains, int64_t n_rows,
+                       int64_t n_cols) {
+  if (!h || !indptr || (!indices && indptr[n_rows] > 0) || (!gains && indptr[n_rows] > 0)) return fail(-1, "ganmf_set_test_csr: null argument");
+  if (n_rows < 1 || n_cols < 1) return fail(-1, "ganmf_set_test_csr: empty matrix");
+  const int64_t nnz = indptr[n_rows];
+  for (int64_t r = 0; r < n_rows; ++r) {
+    if (indptr[r + 1] < indptr[r]) return fail(-1, "ganmf_set_test_csr: indptr not monotone at row %lld", (long long)r);
+    for (int64_t j = indptr[r]; j < indptr[r + 1]; ++j) {
+      if (indices[j] < 0 || indices[j] >= n_cols) return fail(-1, "ganmf_set_test_csr: column %d out of range in row %lld", indices[j], (long long)r);
+      if (j > indptr[r] && indices[j] <= indices[j - 1]) return fail(-1, "ganmf_set_test_csr: row %lld is not sorted / has duplicates", (long long)r);
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(out_items, h->topk_items, need * sizeof(int), hipMemcpyDeviceToHost, h->st);
+  }
+  HIP_TRY(hipSetDevice(h->dev));
+  HIP_TRY(hipStreamSynchronize(h->st));
+  hipFree(h->test_indptr); hipFree(h->test_indices); hipFree(h->test_gain);
+  h->test_indptr = nullptr; h->test_indices = nullptr; h->test_gain = nullptr; h->test_rows = h->test_cols = 0;
+  HIP_TRY(hipMalloc((void**)&h->test_indptr, (size_t)(n_rows + 1) * sizeof(long long)));
+  HIP_TRY(hipMalloc((void**)&h->test_indices, (size_t)std::max<int64_t>(nnz, 1) * sizeof(int)));
+  HIP_TRY(hipMalloc((void**)&h->test_gain, (size_t)std::max<int64_t>(nnz, 1) * sizeof(double)));
+  static_assert(sizeof(long long) == sizeof(int64_t), "indptr width");
+  HIP_TRY(hipMemcpy(h->test_indptr, indptr, (size_t)(n_rows + 1) * sizeof(long long), hipMemcpyHostToDevice));
+  if (nnz > 0) {
+    HIP_TRY(hipMemcpy(h->test_indices, indices, (size_t)nnz * sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->test_gain, gains, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice));
+  }
+  h->test_rows = n_rows; h->test_cols = n_cols;
+  return 0;
+}
+
+int ganmf_evaluate(ganmf_handle* h, const int32_t* ids, int64_t n, int transposed, int remove_seen, const int32_t* cutoffs,
+                   int32_t n_cutoffs, const double* disc, const double* ideal_cum, double* sums) {
+  if (!h || !ids || !cutoffs || !disc || !ideal_cum || !sums) return fail(-1, "ganmf_evaluate: null argument");
+  if (n_cutoffs < 1 || n_cutoffs > GANMF_EVAL_MAX_CUTOFFS) return fail(-1, "ganmf_evaluate: 1..%d cut-offs per call", GANMF_EVAL_MAX_CUTOFFS);
+  const int limit = transposed ? h->N : h->U, W = transposed ? h->U : h->N;
+  if (!h->test_indptr || h->test_rows != limit || h->test_cols != W)
+    return fail(-1, "ganmf_evaluate: needs ganmf_set_test_csr with a %d x %d matrix", limit, W);
+  int K = 0;
+  for (int i = 0; i < n_cutoffs; ++i) {
+    if (cutoffs[i] < 1) return fail(-1, "ganmf_evaluate: cut-off %d", cutoffs[i]);
+    K = std::max(K, (int)cutoffs[i]);
+  }
+  int* ids_dev = nullptr;
+  TRY(recommend_device(h, "ganmf_evaluate", ids, n, transposed, K, remove_seen, &ids_dev));
+  const int grid = (int)((n + 255) / 256);
+  const size_t n_part = (size_t)grid * n_cutoffs * EVAL_METRICS;
+  const size_t need = (size_t)K + (size_t)n * K + n_part;
+  if (need > h->eval_cap) {
+    HIP_TRY(hipStreamSynchronize(h->st));
+    hipFree(h->eval_buf); h->eval_buf = nullptr; h->eval_cap = 0;
+    HIP_TRY(hipMalloc((void**)&h->eval_buf, need * sizeof(double)));
+    h->eval_cap = need;
+  }
+  double* d_disc = h->eval_buf;
+  double* d_ideal = d_disc + K;
+  double* d_part = d_ideal + (size_t)n * K;
+  HIP_TRY(hipMemcpyAsync(d_disc, disc, (size_t)K * sizeof(double), hipMemcpyHostToDevice, h->st));
+  HIP_TRY(hipMemcpyAsync(d_ideal, ideal_cum, (size_t)n * K * sizeof(double), hipMemcpyHostToDevice, h->st));
+  EvalP p{};
+  p.items = h->topk_items; p.K = K; p.n = (int)n; p.ids = ids_dev;
+  p.t_indptr = h->test_indptr; p.t_indices = h->test_indices; p.t_gain = h->test_gain;
+  p.disc = d_disc; p.ideal_cum = d_ideal; p.ncut = n_cutoffs; p.partials = d_part;
+  for (int i = 0; i < n_cutoffs; ++i) p.cutoffs[i] = cutoffs[i];
+  hipLaunchKernelGGL(eval_topk_kernel, dim3(grid), dim3(256), 0, h->st, p);
+  HIP_TRY(hipGetLastError());
+  std::vector<double> part(n_part);
+  HIP_TRY(hipMemcpyAsync(part.data(), d_part, n_part * sizeof(double), hipMemcpyDeviceToHost, h->st));
+  HIP_TRY(hipStreamSynchronize(h->st));
+  for (int i = 0; i < n_cutoffs * EVAL_METRICS; ++i) sums[i] = 0.0;
+  for (int b = 0; b < grid; ++b)      // block order: reproducible
+    for (int i = 0; i < n_cutoffs * EVAL_METRICS; ++i) sums[i] += part[(size_t)b * n_cutoffs * EVAL_METRICS + i];
+  return 0;
+}
+
+int ganmf_recommend(ganmf_handle* h, const int32_t* ids, int64_t n, int transposed, int32_t cutoff, int remove_seen,
+                    int32_t* out_items, float* out_scores) {
+  if (!h || !ids || !out_items) return fail(-1, "ganmf_recommend: null argument");
+  int rc = recommend_device(h, "ganmf_recommend", ids, n, transposed, cutoff, remove_seen, nullptr);
+  if (rc == 0) {
+    const size_t need = (size_t)n * cutoff;
+    hipError_t e = hipMemcpyAsync(out_items, h->topk_items, need * sizeof(int), hipMemcpyDeviceToHost, h->st);
     if (e == hipSuccess && out_scores) e = hipMemcpyAsync(out_scores, h->topk_vals, need * sizeof(float), hipMemcpyDeviceToHost, h->st);
     if (e == hipSuccess) e = hipStreamSynchronize(h->st);
     if (e != hipSuccess) rc = fail(-2, "ganmf_recommend: %s", hipGetErrorString(e));

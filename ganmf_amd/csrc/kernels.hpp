@@ -499,4 +499,90 @@ __global__ void fill_kernel(float* __restrict__ p, float v, long long n) {
     p[i] = v;
 }
 
+// Hold-out ranking metrics on the device (Base/Evaluation/Evaluator.py:262-335 with the metric definitions of
+// Base/Evaluation/metrics.py: roc_auc, precision, precision_recall_min_denominator, recall, map, rr, ndcg, arhr and the
+// hit count).  One THREAD per evaluated user: it walks the user's top-K list (mask_topk_kernel's output, -1 padded) once
+// per cut-off, finds each recommended item in the user's sorted test row by binary search and forms the user's metric
+// values in float64 exactly as ganmf_amd/evaluation.py::EvaluatorHoldoutFast does; the per-user values are summed per
+// block in a fixed tree order and the host adds the block partials in block order (bitwise reproducible).
+constexpr int EVAL_METRICS = 9;      // ROC_AUC, PRECISION, PRECISION_RECALL_MIN_DEN, RECALL, MAP, MRR, NDCG, HIT_RATE, ARHR
+constexpr int EVAL_MAX_CUTOFFS = 8;
+struct EvalP {
+  const int* items;            // [n, K] recommended ids, -1 padded
+  int K, n;
+  const int* ids;              // [n] evaluated rows of the test matrix
+  const long long* t_indptr;   // test matrix, evaluation orientation, column indices sorted inside a row
+  const int* t_indices;
+  const double* t_gain;        // 2^rating - 1 per stored entry
+  const double* disc;          // [K] 1 / ln(rank + 1), as the host evaluator forms it (float32 logarithm)
+  const double* ideal_cum;     // [n, K] prefix sums of the user's ideal DCG terms
+  int ncut;
+  int cutoffs[EVAL_MAX_CUTOFFS];
+  double* partials;            // [gridDim.x][ncut][EVAL_METRICS]
+};
+
+__global__ __launch_bounds__(256) void eval_topk_kernel(const EvalP p) {
+  __shared__ double red[256];
+  const int u = blockIdx.x * 256 + threadIdx.x;
+  const bool live = u < p.n;
+  long long t0 = 0, t1 = 0;
+  if (live) { const int r = p.ids[u]; t0 = p.t_indptr[r]; t1 = p.t_indptr[r + 1]; }
+  const double n_test = (double)(t1 - t0);
+  for (int ci = 0; ci < p.ncut; ++ci) {
+    const int c = p.cutoffs[ci];
+    double m[EVAL_METRICS];
+#pragma unroll
+    for (int q = 0; q < EVAL_METRICS; ++q) m[q] = 0.0;
+    if (live) {
+      double hits = 0.0, nneg = 0.0, len = 0.0, pairs = 0.0, ap = 0.0, arhr = 0.0, dcg = 0.0, rr = 0.0;
+      for (int i = 0; i < c && i < p.K; ++i) {
+        const int it = p.items[(size_t)u * p.K + i];
+        if (it < 0) continue;
+        len += 1.0;
+        long long lo = t0, hi = t1;          // first stored index >= it
+        while (lo < hi) {
+          const long long mid = (lo + hi) >> 1;
+          if (p.t_indices[mid] < it) lo = mid + 1; else hi = mid;
+        }
+        const bool hit = lo < t1 && p.t_indices[lo] == it;
+        const double inv_rank = 1.0 / (double)(i + 1);
+        if (hit) {
+          hits += 1.0;
+          ap += hits * inv_rank;
+          arhr += inv_rank;
+          if (rr == 0.0) rr = inv_rank;
+          dcg += p.t_gain[lo] * p.disc[i];
+        } else {
+          nneg += 1.0;
+          pairs += hits;                     // every hit ranked before this miss is a correctly ordered pair
+        }
+      }
+      const double den = fmin(n_test, len);
+      m[0] = nneg == 0.0 ? 1.0 : (hits > 0.0 ? pairs / (hits * nneg) : 0.0);
+      m[1] = len > 0.0 ? hits / len : 0.0;
+      m[2] = len > 0.0 ? hits / fmax(den, 1.0) : 0.0;
+      m[3] = hits / n_test;
+      m[4] = len > 0.0 ? ap / fmax(den, 1.0) : 0.0;
+      m[5] = rr;
+      if (dcg > 0.0) {
+        const double ideal = p.ideal_cum[(size_t)u * p.K + (len > 0.0 ? (int)len - 1 : 0)];
+        m[6] = dcg / (ideal > 0.0 ? ideal : 1.0);
+      }
+      m[7] = hits;
+      m[8] = arhr;
+    }
+#pragma unroll
+    for (int q = 0; q < EVAL_METRICS; ++q) {
+      red[threadIdx.x] = m[q];
+      __syncthreads();
+      for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+      }
+      if (threadIdx.x == 0) p.partials[((size_t)blockIdx.x * p.ncut + ci) * EVAL_METRICS + q] = red[0];
+      __syncthreads();
+    }
+  }
+}
+
 }  // namespace ganmf

@@ -129,6 +129,36 @@ class Engine:
                                              _i32p(items), _f32p(vals)), "ganmf_recommend")
         return items, vals
 
+    def set_test(self, urm_test_csr, gains):
+        """URM_test in evaluation orientation, column indices sorted inside each row; `gains` = 2^rating - 1 per stored
+        entry (float64, same order as urm_test_csr.data)."""
+        urm = urm_test_csr.tocsr()
+        assert urm.has_sorted_indices
+        indptr = np.ascontiguousarray(urm.indptr, dtype=np.int64)
+        indices = np.ascontiguousarray(urm.indices, dtype=np.int32)
+        g = np.ascontiguousarray(gains, dtype=np.float64)
+        assert g.size == indices.size
+        dp = C.POINTER(C.c_double)
+        L.check(self.lib.ganmf_set_test_csr(self.h, indptr.ctypes.data_as(C.POINTER(C.c_int64)), _i32p(indices),
+                                            g.ctypes.data_as(dp), urm.shape[0], urm.shape[1]), "ganmf_set_test_csr")
+
+    def evaluate(self, ids, cutoffs, disc, ideal_cum, transposed=False, remove_seen=True):
+        """Sums over the users `ids` of the nine ranking metrics (L.EVAL_METRICS) per cut-off, formed on the device from
+        the device's own top-k lists: returns a [len(cutoffs), 9] float64 array."""
+        ids = np.ascontiguousarray(ids, dtype=np.int32).ravel()
+        cut = np.ascontiguousarray(cutoffs, dtype=np.int32).ravel()
+        K = int(cut.max())
+        disc = np.ascontiguousarray(disc, dtype=np.float64).ravel()
+        ideal = np.ascontiguousarray(ideal_cum, dtype=np.float64)
+        assert disc.size >= K and ideal.shape == (ids.size, K)
+        out = np.zeros((cut.size, len(L.EVAL_METRICS)), dtype=np.float64)
+        dp = C.POINTER(C.c_double)
+        if ids.size:
+            L.check(self.lib.ganmf_evaluate(self.h, _i32p(ids), ids.size, int(transposed), int(remove_seen), _i32p(cut), cut.size,
+                                            disc.ctypes.data_as(dp), ideal.ctypes.data_as(dp), out.ctypes.data_as(dp)),
+                    "ganmf_evaluate")
+        return out
+
     def snapshot_best(self):
         L.check(self.lib.ganmf_snapshot_best(self.h), "ganmf_snapshot_best")
 

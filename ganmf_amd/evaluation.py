@@ -185,6 +185,11 @@ class EvaluatorHoldoutFast(EvaluatorHoldout):
             ideal[i, :len(r)] = (np.power(2.0, r).astype(np.float64) - 1.0) * disc[:len(r)]
         self._ideal_cum = np.cumsum(ideal, axis=1)
         self._disc = disc
+        # device route (recommender.evaluate_on_device -> ganmf_evaluate): the test matrix with sorted rows and its DCG gains
+        self._test_sorted = self.URM_test.tocsr().copy()
+        self._test_sorted.sort_indices()
+        self._test_gain = np.power(2.0, self._test_sorted.data.astype(np.float32)).astype(np.float64) - 1.0
+        self.use_device_metrics = True
 
     def _topk(self, rec, batch):
         K = self.max_cutoff
@@ -204,6 +209,20 @@ class EvaluatorHoldoutFast(EvaluatorHoldout):
         sums = {c: {m: 0.0 for m in names} for c in self.cutoff_list}
         n_eval = len(self._users)
         inv_rank = 1.0 / np.arange(1, K + 1, dtype=np.float64)
+        if self.use_device_metrics and n_eval > 0 and hasattr(recommender_object, "evaluate_on_device"):
+            # everything on the device: scores, seen mask, top-k AND the metric sums (only len(cutoffs) x 9 doubles come back)
+            dev = recommender_object.evaluate_on_device(id(self), self._test_sorted, self._test_gain, self._users, self.cutoff_list,
+                                                        self._disc, self._ideal_cum, remove_seen_flag=self.exclude_seen)
+            if dev is not None:
+                from ._lib import EVAL_METRICS
+                for ci, c in enumerate(self.cutoff_list):
+                    for mi, name in enumerate(EVAL_METRICS):
+                        sums[c][name] = float(dev[ci, mi])
+                results = _finish(sums, n_eval, self.cutoff_list)
+                for c in self.cutoff_list:
+                    results[c] = {m: float(v) for m, v in results[c].items()}
+                    results[c]["RMSE"] = float("nan")
+                return results, get_result_string(results)
         for start in range(0, n_eval, block_size):
             sl = slice(start, min(start + block_size, n_eval))
             batch = self._users[sl]

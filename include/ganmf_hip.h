@@ -172,6 +172,22 @@ typedef struct ganmf_prof_entry {
 int ganmf_profile_enable(ganmf_handle* h, int on);
 int ganmf_profile_read(ganmf_handle* h, ganmf_prof_entry* out, int32_t cap, int32_t* n_out);
 
+/* Hold-out evaluation on the device (replaces the per-user metric loop of
+ * Base/Evaluation/Evaluator.py:262-335 with the definitions of Base/Evaluation/metrics.py): ganmf_evaluate ranks the rows
+ * `ids` exactly as ganmf_recommend does (cutoff = the largest of `cutoffs`), looks every recommended item up in the test
+ * matrix and returns, per cut-off, the SUMS over the n users of
+ *   ROC_AUC, PRECISION, PRECISION_RECALL_MIN_DEN, RECALL, MAP, MRR, NDCG, HIT_RATE, ARHR      (GANMF_EVAL_METRICS values, this order)
+ * in float64; only n_cutoffs * 9 doubles cross PCIe.  ganmf_set_test_csr uploads URM_test in EVALUATION orientation with
+ * column indices sorted inside each row and `gains` = 2^rating - 1 per stored entry; `disc[k]` = 1 / ln(k + 2) and
+ * `ideal_cum[i, k]` = the prefix sums of user i's ideal DCG terms (both [.., max cutoff], formed by the caller the way
+ * the reference forms them, in float32 where it does).  At most GANMF_EVAL_MAX_CUTOFFS cut-offs per call. */
+#define GANMF_EVAL_METRICS 9
+#define GANMF_EVAL_MAX_CUTOFFS 8
+int ganmf_set_test_csr(ganmf_handle* h, const int64_t* indptr, const int32_t* indices, const double* gains, int64_t n_rows,
+                       int64_t n_cols);
+int ganmf_evaluate(ganmf_handle* h, const int32_t* ids, int64_t n, int transposed, int remove_seen, const int32_t* cutoffs,
+                   int32_t n_cutoffs, const double* disc, const double* ideal_cum, double* sums);
+
 /* Device-resident scoring GEMM timing (no D2H): scores for the first n rows, `iters` launches;
  * returns average milliseconds per launch measured with hipEvents on the handle's stream. */
 int ganmf_bench_scores(ganmf_handle* h, int64_t n, int transposed, int32_t iters, float* ms_per_launch);

@@ -178,3 +178,51 @@ def test_trial_parallel_tuner_on_gpu(tmp_path, golden_dir):
     assert len(t.func_vals) == 4 and all(np.isfinite(t.func_vals))
     assert "trial failed" not in open(os.path.join(str(tmp_path / "tune"), "results.txt")).read()
     assert best < 0 and set(params) == {d.name for d in t.dims}
+
+
+@pytest.mark.parametrize("mode", ["user", "item"])
+@pytest.mark.parametrize("exclude_seen", [True, False])
+def test_device_metrics_equal_host_metrics(mode, exclude_seen):
+    """ganmf_evaluate (metric sums formed on the device from the device's own top-k lists) against the same
+    evaluator computing them on the host from the downloaded ids: graded ratings (DCG gains), users whose lists are shorter
+    than the cut-off (few unseen items left), users without test items dropped by the evaluator, four cut-offs at once."""
+    from ganmf_amd.evaluation import EvaluatorHoldoutFast
+    model, urm, rng = _model(mode, 300, 23, 6, seed=11, density=0.5)      # 23 items, half of them seen: lists of ~11 < cutoff 20
+    nu, ni = urm.shape
+    t = (rng.rand(nu, ni) < 0.15) * rng.randint(1, 6, size=(nu, ni))
+    t[rng.rand(nu) < 0.1] = 0                                             # users without test items
+    test = sps.csr_matrix(t.astype(np.float32))
+    ev = EvaluatorHoldoutFast(test, [1, 5, 10, 20], exclude_seen=exclude_seen)
+    assert ev.use_device_metrics
+    dev, _ = ev.evaluateRecommender(model)
+    ev.use_device_metrics = False
+    host, _ = ev.evaluateRecommender(model)
+    for c in (1, 5, 10, 20):
+        for name, v in host[c].items():
+            if name == "RMSE":
+                assert np.isnan(dev[c][name])
+                continue
+            assert abs(dev[c][name] - v) <= 1e-12 * max(1.0, abs(v)), (mode, exclude_seen, c, name, dev[c][name], v)
+    assert host[5]["MAP"] > 0 and host[20]["NDCG"] > 0
+    model.engine.close()
+
+
+def test_device_metrics_reject_bad_input():
+    from ganmf_amd._lib import GanmfError
+    model, urm, rng = _model("user", 40, 30, 4, seed=3)
+    eng = model.engine
+    test = sps.csr_matrix((rng.rand(40, 30) < 0.2).astype(np.float32))
+    test.sort_indices()
+    disc, ideal = np.ones(5), np.ones((4, 5))
+    with pytest.raises(GanmfError):       # no test matrix yet
+        eng.evaluate(np.arange(4), [5], disc, ideal)
+    eng.set_test(test, np.ones(test.nnz))
+    with pytest.raises(GanmfError):       # more cut-offs than one call takes
+        eng.evaluate(np.arange(4), list(range(1, 10)), np.ones(9), np.ones((4, 9)))
+    bad = test.copy()
+    bad.indices = bad.indices[::-1].copy()
+    with pytest.raises((GanmfError, AssertionError)):
+        eng.set_test(bad, np.ones(bad.nnz))
+    out = eng.evaluate(np.arange(4), [5], disc, ideal, remove_seen=False)
+    assert out.shape == (1, 9) and np.all(np.isfinite(out))
+    eng.close()

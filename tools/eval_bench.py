@@ -16,10 +16,12 @@ train = sps.load_npz(os.path.join(g, "Movielens1M_URM_train.npz")).tocsr()
 test = sps.load_npz(os.path.join(g, "Movielens1M_URM_test.npz")).tocsr()
 model = GANMF(train, mode="user", is_experiment=True, seed=1)
 model.fit(num_factors=250, emb_dim=992, epochs=1, batch_size=128, d_lr=1e-3, g_lr=1e-3, m=10, recon_coefficient=0.1)
-slow_ev, fast_ev = EvaluatorHoldout(test, [5]), EvaluatorHoldoutFast(test, [5])
+slow_ev, fast_ev, host_ev = EvaluatorHoldout(test, [5]), EvaluatorHoldoutFast(test, [5]), EvaluatorHoldoutFast(test, [5])
+host_ev.use_device_metrics = False      # device top-k ids, metrics in numpy on the host (round 1's fast evaluator)
 users = np.arange(train.shape[0])
 for name, fn in (("slow evaluator", lambda: slow_ev.evaluateRecommender(model)),
-                 ("fast evaluator", lambda: fast_ev.evaluateRecommender(model)),
+                 ("fast evaluator, metrics on the host", lambda: host_ev.evaluateRecommender(model)),
+                 ("fast evaluator, metrics on the device", lambda: fast_ev.evaluateRecommender(model)),
                  ("device recommend top-5, all users", lambda: model.recommend_topk(users, 5)),
                  ("device recommend top-50, all users", lambda: model.recommend_topk(users, 50)),
                  ("host recommend top-5, all users", lambda: model.recommend(users, cutoff=5, return_scores=True))):
