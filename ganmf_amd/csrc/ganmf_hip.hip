@@ -261,10 +261,16 @@ struct Scope {
       r.tag = tag; r.flops = flops; r.bytes = bytes;
       hipEventCreate(&r.a); hipEventCreate(&r.b);
       hipEventRecord(r.a, s);
+      launch_prof() = LaunchProf{r.a, r.b, 0};      // the first kernel launched inside the scope stamps both events itself
     }
   }
   ~Scope() {
-    if (on) { hipEventRecord(r.b, s); h->recs.push_back(r); }
+    if (on) {
+      // exactly one kernel: its own start / end are on the events.  None (a collective) or several: bracket as before.
+      if (launch_prof().count != 1) hipEventRecord(r.b, s);
+      launch_prof() = LaunchProf{};
+      h->recs.push_back(r);
+    }
   }
 };
 
@@ -377,7 +383,7 @@ int collective_local(ganmf_handle* h, float* buf, size_t count, hipStream_t st, 
   g.bufs.p[h->cfg.rank] = buf;
   if (++g.arrived == g.world) {
     const int grid = (int)std::min<size_t>(1024, (count + 255) / 256);
-    hipLaunchKernelGGL(local_collective_kernel, dim3(std::max(grid, 1)), dim3(256), 0, st, g.bufs, g.world, count, op);
+    GANMF_LAUNCH(local_collective_kernel, dim3(std::max(grid, 1)), dim3(256), 0, st, g.bufs, g.world, count, op);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     g.arrived = 0;
@@ -495,14 +501,14 @@ int run_gemm(ganmf_handle* h, int tag_gemm, int tag_red, GemmP g, bool akm, bool
       GemmP q = g;
       fill_plan(q, pl);
       const int ng = pl.tiles_m * pl.tiles_n;
-      hipLaunchKernelGGL(gemm_bf16s_red, dim3(ng + nred), dim3(256), 0, st, q, *attach, nred);
+      GANMF_LAUNCH(gemm_bf16s_red, dim3(ng + nred), dim3(256), 0, st, q, *attach, nred);
       HIP_TRY(hipGetLastError());
       return 0;
     }
     {
       Scope s(h, tag_red, 0, 4.0 * (attach->nsplit + 1) * attach->M * attach->N, st);
       RedP r = *attach;
-      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(GEMM_RED_GRID, 1), dim3(256), 0, st, r);
+      GANMF_LAUNCH(splitk_reduce_kernel, dim3(GEMM_RED_GRID, 1), dim3(256), 0, st, r);
       HIP_TRY(hipGetLastError());
     }
   }
@@ -549,7 +555,7 @@ int run_gemm(ganmf_handle* h, int tag_gemm, int tag_red, GemmP g, bool akm, bool
     r.part = slab; r.nsplit = pl.nsplit; r.out = g.C; r.ld = g.ldc; r.M = g.M; r.N = g.N;
     r.batch_stride = g.c_batch_stride; r.epi = g.epi; r.epi.sq_stride = GEMM_RED_GRID;
     r.split_stride = (long long)g.nbatch * g.M * g.ldc;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(GEMM_RED_GRID, g.nbatch), dim3(256), 0, st, r);
+    GANMF_LAUNCH(splitk_reduce_kernel, dim3(GEMM_RED_GRID, g.nbatch), dim3(256), 0, st, r);
     HIP_TRY(hipGetLastError());
   }
   return 0;
@@ -581,7 +587,7 @@ int adam_dense(ganmf_handle* h, int tag, Tensor& t, const float* g, int alpha_id
   const long long n4 = (long long)count / 4;
   hipStream_t st = lane ? h->st2 : h->st;
   Scope s(h, tag, 0, 28.0 * count, st);
-  hipLaunchKernelGGL(adam_dense_kernel, dim3(ADAM_GRID), dim3(256), 0, st, t.p + off, t.m + off, t.v + off, g + off, n4, h->scal,
+  GANMF_LAUNCH(adam_dense_kernel, dim3(ADAM_GRID), dim3(256), 0, st, t.p + off, t.m + off, t.v + off, g + off, n4, h->scal,
                      alpha_idx, reg, sq);
   HIP_TRY(hipGetLastError());
   return 0;
@@ -627,13 +633,13 @@ int rows_and_generator(ganmf_handle* h, const int* rows_dev, int nb, int which, 
     Scope s(h, T_FRONT, gemm_flops(g.M, g.N, g.K), gemm_bytes(g.M, g.N, g.K) + 4.0 * nb * (N + 2 * k));
     g.A = h->Ue.p; g.a_gather = rows_dev;        // A row r = U[rows[r]]: the lookup rides in the operand fetch
     fill_plan(g, pl);
-    hipLaunchKernelGGL(front_kernel<4>, dim3(pl.tiles_m * pl.tiles_n + nb), dim3(1024), 0, h->st, g, d);
+    GANMF_LAUNCH(front_kernel<4>, dim3(pl.tiles_m * pl.tiles_n + nb), dim3(1024), 0, h->st, g, d);
     HIP_TRY(hipGetLastError());
     return 0;
   }
   {
     Scope s(h, T_DENSIFY, 0, 4.0 * nb * (N + 2 * k));
-    hipLaunchKernelGGL(densify_rows_kernel, dim3(nb), dim3(256), 0, h->st, d);
+    GANMF_LAUNCH(densify_rows_kernel, dim3(nb), dim3(256), 0, h->st, d);
     HIP_TRY(hipGetLastError());
   }
   return run_gemm(h, T_GEMM_GEN, T_RED_GEN, g, false, false);
@@ -649,7 +655,7 @@ int step_front(ganmf_handle* h, const int* rows_dev, int nb, int which) {
     TRY(dp_join(h));
     {
       Scope s(h, T_DENSIFY, 0, 4.0 * nb * (2 * k + e) + 4.0 * (double)h->nnz / std::max(h->U, 1) * nb * e);
-      hipLaunchKernelGGL(sparse_front_kernel, dim3(nb), dim3(256), 0, h->st, h->indptr, h->indices, h->data, rows_dev, nb, N,
+      GANMF_LAUNCH(sparse_front_kernel, dim3(nb), dim3(256), 0, h->st, h->indptr, h->indices, h->data, rows_dev, nb, N,
                          h->XF, h->ldN, h->Ue.p, h->ldk, h->Ub, h->scal, which, aslot, h->cfg.g_lr, h->We.p, h->lde, e, h->E);
       HIP_TRY(hipGetLastError());
     }
@@ -705,7 +711,7 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
     }
   } else {
     // rank out of rows: still open the optimizer step and contribute zeros to the collectives
-    hipLaunchKernelGGL(open_step_kernel, dim3(1), dim3(64), 0, h->st, h->scal, 0, aslot, h->cfg.d_lr);
+    GANMF_LAUNCH(open_step_kernel, dim3(1), dim3(64), 0, h->st, h->scal, 0, aslot, h->cfg.d_lr);
     HIP_TRY(hipGetLastError());
   }
   if (dist) {
@@ -715,7 +721,7 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
     mr.e[1] = {h->sqp + sqn, sqn, S_SUM_FAKE, 0};
     {
       Scope s(h, T_MULTIRED, 0, 0);
-      hipLaunchKernelGGL(multi_reduce_kernel, dim3(1), dim3(256), 0, h->st, mr);
+      GANMF_LAUNCH(multi_reduce_kernel, dim3(1), dim3(256), 0, h->st, mr);
       HIP_TRY(hipGetLastError());
     }
     TRY(allreduce(h, h->scal + S_SUM_REAL, 2));
@@ -724,7 +730,7 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
     Scope s(h, T_DCOEF, 0, 8.0 * 2 * nb * e);
     const long long total = (long long)2 * nb * (h->lde / 4);
     const int grid = (int)std::max<long long>(1, std::min<long long>(128, (total + 1023) / 1024));
-    hipLaunchKernelGGL(d_coef_kernel, dim3(grid), dim3(256), 0, h->st, h->scal, h->sqp, sqn, sqn,
+    GANMF_LAUNCH(d_coef_kernel, dim3(grid), dim3(256), 0, h->st, h->scal, h->sqp, sqn, sqn,
                        dist ? 1 : 0, h->cfg.m, nb, inv_bn, h->E, h->Es, h->lde, h->rs, parts);
     HIP_TRY(hipGetLastError());
   }
@@ -891,8 +897,8 @@ int gen_update(ganmf_handle* h, int nb, int start, int b_global, int* regn_v, fl
         {
           Scope s(h, T_PAIR, gemm_flops(g0.M, g0.N, g0.K) + gemm_flops(g1.M, g1.N, g1.K),
                   gemm_bytes(g0.M, g0.N, g0.K) + gemm_bytes(g1.M, g1.N, g1.K) + 24.0 * h->V.count());
-          if (h->pair_ring == 2) hipLaunchKernelGGL((pair_kernel<4, 2>), dim3(n0 + n1), dim3(1024), 0, h->st, g0, g1);
-          else hipLaunchKernelGGL((pair_kernel<4, 3>), dim3(n0 + n1), dim3(1024), 0, h->st, g0, g1);
+          if (h->pair_ring == 2) GANMF_LAUNCH((pair_kernel<4, 2>), dim3(n0 + n1), dim3(1024), 0, h->st, g0, g1);
+          else GANMF_LAUNCH((pair_kernel<4, 3>), dim3(n0 + n1), dim3(1024), 0, h->st, g0, g1);
           HIP_TRY(hipGetLastError());
         }
         std::swap(h->V.p, h->V_alt);
@@ -908,7 +914,7 @@ int gen_update(ganmf_handle* h, int nb, int start, int b_global, int* regn_v, fl
   }
   {
     Scope s(h, T_ADAM_U, 0, 24.0 * h->Ue.count());
-    hipLaunchKernelGGL(adam_rows_kernel, dim3(ADAM_GRID), dim3(256), 0, h->st, h->Ue.p, h->Ue.m, h->Ue.v, gub.p,
+    GANMF_LAUNCH(adam_rows_kernel, dim3(ADAM_GRID), dim3(256), 0, h->st, h->Ue.p, h->Ue.m, h->Ue.v, gub.p,
                        gub.nsplit, gub.split_stride, h->pos, start, nb, h->U, h->ldk, h->scal, S_ALPHA_G, h->cfg.g_reg,
                        reg ? reg_u : nullptr);
     HIP_TRY(hipGetLastError());
@@ -957,7 +963,7 @@ int g_step(ganmf_handle* h, const int* rows_dev, int nb, int start, int b_global
       TRY(run_gemm(h, T_GEMM_DF, T_RED_DF, g, false, false, nullptr, 4.0 * nb * N));
     }
   } else {
-    hipLaunchKernelGGL(open_step_kernel, dim3(1), dim3(64), 0, h->st, h->scal, 1, S_ALPHA_G, h->cfg.g_lr);
+    GANMF_LAUNCH(open_step_kernel, dim3(1), dim3(64), 0, h->st, h->scal, 1, S_ALPHA_G, h->cfg.g_lr);
     HIP_TRY(hipGetLastError());
   }
   const bool reg = h->cfg.g_reg != 0.f;
@@ -1014,7 +1020,7 @@ int dis_backprop_hidden(ganmf_handle* h, int row0, int nrows, bool param_grads, 
       if (uid_apart) g.M = N + 1;      // the float(uid) row of W_0_ext gets its gradient from the fp32 reduction below
       TRY(run_gemm(h, T_DIS_GW, T_RED_DIS_GW, g, true, true));
       if (uid_apart) {
-        hipLaunchKernelGGL(dis_uid_grad_kernel, dim3((e + 255) / 256), dim3(256), 0, h->st, h->XF, h->ldN, N + 1, cur, h->lde,
+        GANMF_LAUNCH(dis_uid_grad_kernel, dim3((e + 255) / 256), dim3(256), 0, h->st, h->XF, h->ldN, N + 1, cur, h->lde,
                            nrows, e, h->Wl[0].g + (size_t)(N + 1) * h->lde);
         HIP_TRY(hipGetLastError());
       }
@@ -1042,16 +1048,16 @@ int dis_d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float
     float* feat = h->Al[h->L - 1];
     {
       Scope s(h, T_DIS_HEAD, 0, 4.0 * 2 * nb * e * 3);
-      hipLaunchKernelGGL(dis_head_kernel, dim3((2 * nb + 3) / 4), dim3(256), 0, h->st, feat, h->lde, e + 1,
+      GANMF_LAUNCH(dis_head_kernel, dim3((2 * nb + 3) / 4), dim3(256), 0, h->st, feat, h->lde, e + 1,
                          h->Wo.p, 0, 2 * nb, nb, inv_b, h->dlogit, h->lossrow);
-      hipLaunchKernelGGL(dis_dz_top_kernel, dim3((e + 1 + 63) / 64), dim3(256), 0, h->st, feat, h->lde, e,
+      GANMF_LAUNCH(dis_dz_top_kernel, dim3((e + 1 + 63) / 64), dim3(256), 0, h->st, feat, h->lde, e,
                          h->Wo.p, h->dlogit, 0, 2 * nb, 0, 0.f, h->act, h->dz0, h->Wo.g, (float*)nullptr);
       HIP_TRY(hipGetLastError());
     }
     float* dz0;
     TRY(dis_backprop_hidden(h, 0, 2 * nb, true, b_global, &dz0));
   } else {
-    hipLaunchKernelGGL(open_step_kernel, dim3(1), dim3(64), 0, h->st, h->scal, 0, S_ALPHA_D, h->cfg.d_lr);
+    GANMF_LAUNCH(open_step_kernel, dim3(1), dim3(64), 0, h->st, h->scal, 0, S_ALPHA_D, h->cfg.d_lr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemsetAsync(h->gD, 0, h->gD_elems * sizeof(float), h->st));
     HIP_TRY(hipMemsetAsync(h->lossrow, 0, (size_t)2 * h->B * sizeof(float), h->st));
@@ -1073,14 +1079,14 @@ int dis_d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float
     mr.e[1] = {h->lossrow + nb, nb, 1, 0};
     mr.count = 2;
     Scope s(h, T_MULTIRED, 0, 0);
-    hipLaunchKernelGGL(multi_reduce_kernel, dim3(1), dim3(256), 0, h->st, mr);
+    GANMF_LAUNCH(multi_reduce_kernel, dim3(1), dim3(256), 0, h->st, mr);
     if (reg) {
       for (int i = 0; i <= h->L; i += 6) {
         MultiRed m2{};
         m2.out = parts;
         m2.count = std::min(6, h->L + 1 - i);
         for (int j = 0; j < m2.count; ++j) m2.e[j] = {h->regp + (4 + i + j) * h->reg_cap, ADAM_GRID, 2, (i + j) ? 1 : 0};
-        hipLaunchKernelGGL(multi_reduce_kernel, dim3(1), dim3(256), 0, h->st, m2);
+        GANMF_LAUNCH(multi_reduce_kernel, dim3(1), dim3(256), 0, h->st, m2);
       }
     }
     HIP_TRY(hipGetLastError());
@@ -1099,10 +1105,10 @@ int dis_g_step(ganmf_handle* h, const int* rows_dev, int nb, int start, int b_gl
     const float fmc = alpha * 2.0f / ((float)b_global * (float)e);
     {  // generator loss = loss_fake + alpha * FM  (DisGANMF.py:135-136): generated rows only, label 0
       Scope s(h, T_DIS_HEAD, 0, 4.0 * 2 * nb * e * 3);
-      hipLaunchKernelGGL(dis_head_kernel, dim3((nb + 3) / 4), dim3(256), 0, h->st, feat, h->lde, e + 1, h->Wo.p,
+      GANMF_LAUNCH(dis_head_kernel, dim3((nb + 3) / 4), dim3(256), 0, h->st, feat, h->lde, e + 1, h->Wo.p,
                          nb, nb, nb, inv_b, h->dlogit, h->lossrow);
       fmn = (e + 1 + 63) / 64;
-      hipLaunchKernelGGL(dis_dz_top_kernel, dim3(fmn), dim3(256), 0, h->st, feat, h->lde, e, h->Wo.p, h->dlogit,
+      GANMF_LAUNCH(dis_dz_top_kernel, dim3(fmn), dim3(256), 0, h->st, feat, h->lde, e, h->Wo.p, h->dlogit,
                          nb, nb, nb, fmc, h->act, h->dz0, (float*)nullptr, h->fmp);
       HIP_TRY(hipGetLastError());
     }
@@ -1116,7 +1122,7 @@ int dis_g_step(ganmf_handle* h, const int* rows_dev, int nb, int start, int b_gl
       TRY(run_gemm(h, T_GEMM_DF, T_RED_DF, g, false, false));
     }
   } else {
-    hipLaunchKernelGGL(open_step_kernel, dim3(1), dim3(64), 0, h->st, h->scal, 1, S_ALPHA_G, h->cfg.g_lr);
+    GANMF_LAUNCH(open_step_kernel, dim3(1), dim3(64), 0, h->st, h->scal, 1, S_ALPHA_G, h->cfg.g_lr);
     HIP_TRY(hipGetLastError());
   }
   const bool reg = h->cfg.g_reg != 0.f;
@@ -1134,7 +1140,7 @@ int dis_g_step(ganmf_handle* h, const int* rows_dev, int nb, int start, int b_gl
       mr.count = 4;
     }
     Scope s(h, T_MULTIRED, 0, 0);
-    hipLaunchKernelGGL(multi_reduce_kernel, dim3(1), dim3(256), 0, h->st, mr);
+    GANMF_LAUNCH(multi_reduce_kernel, dim3(1), dim3(256), 0, h->st, mr);
     HIP_TRY(hipGetLastError());
   }
   return 0;
@@ -1162,8 +1168,8 @@ int arenas_begin(ganmf_handle* h, int64_t nd, int64_t ng) {
 int arenas_finish(ganmf_handle* h, int64_t nd, int64_t ng) {
   if (h->cfg.model != GANMF_MODEL_GANMF) return 0;
   Scope s(h, T_MULTIRED, 0, 4.0 * (nd + ng) * 4 * h->reg_cap);
-  if (nd > 0) hipLaunchKernelGGL(finish_parts_kernel, dim3((int)nd), dim3(256), 0, h->st, h->d_arena, h->reg_cap, 0, h->d_parts);
-  if (ng > 0) hipLaunchKernelGGL(finish_parts_kernel, dim3((int)ng), dim3(256), 0, h->st, h->g_arena, h->reg_cap, 1, h->g_parts);
+  if (nd > 0) GANMF_LAUNCH(finish_parts_kernel, dim3((int)nd), dim3(256), 0, h->st, h->d_arena, h->reg_cap, 0, h->d_parts);
+  if (ng > 0) GANMF_LAUNCH(finish_parts_kernel, dim3((int)ng), dim3(256), 0, h->st, h->g_arena, h->reg_cap, 1, h->g_parts);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -1636,10 +1642,10 @@ int ganmf_train_epoch(ganmf_handle* h, const int32_t* perm, int64_t n, int32_t d
     if (h->cfg.model == GANMF_MODEL_DISGANMF) TRY(allreduce(h, h->d_parts, (size_t)nd * 4));
     else {
       const int grid = (int)std::min<int64_t>(256, (nd + 255) / 256);
-      hipLaunchKernelGGL(col_copy_kernel, dim3(grid), dim3(256), 0, h->st, h->d_parts, h->colbuf, (long long)nd, 2, 1);
+      GANMF_LAUNCH(col_copy_kernel, dim3(grid), dim3(256), 0, h->st, h->d_parts, h->colbuf, (long long)nd, 2, 1);
       HIP_TRY(hipGetLastError());
       TRY(allreduce(h, h->colbuf, (size_t)nd));
-      hipLaunchKernelGGL(col_copy_kernel, dim3(grid), dim3(256), 0, h->st, h->d_parts, h->colbuf, (long long)nd, 2, 0);
+      GANMF_LAUNCH(col_copy_kernel, dim3(grid), dim3(256), 0, h->st, h->d_parts, h->colbuf, (long long)nd, 2, 0);
       HIP_TRY(hipGetLastError());
     }
   }
@@ -1705,7 +1711,7 @@ static int scores_device(ganmf_handle* h, const int* ids_dev, int64_t n, int tra
     TRY(dalloc(&h->sc_out, need_out)); h->sc_out_cap = need_out;
   }
   const long long total = (long long)n * (h->ldk / 4);
-  hipLaunchKernelGGL(gather_rows_kernel, dim3((int)std::min<long long>(2048, (total + 255) / 256)), dim3(256), 0,
+  GANMF_LAUNCH(gather_rows_kernel, dim3((int)std::min<long long>(2048, (total + 255) / 256)), dim3(256), 0,
                      h->st, rowsT.p, h->ldk, ids_dev, (int)n, h->sc_rows);
   HIP_TRY(hipGetLastError());
   GemmP g{};
@@ -1800,7 +1806,7 @@ static int recommend_device(ganmf_handle* h, const char* who, const int32_t* ids
   const size_t shmem = Wd <= lds_cap ? (size_t)Wd * sizeof(float) : 0;
   if (shmem > 48 * 1024)
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mask_topk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-  hipLaunchKernelGGL(mask_topk_kernel, dim3((int)n), dim3(256), shmem, h->st, od, ldw, Wd, ids_dev,
+  GANMF_LAUNCH(mask_topk_kernel, dim3((int)n), dim3(256), shmem, h->st, od, ldw, Wd, ids_dev,
                      remove_seen ? h->seen_indptr : (const long long*)nullptr, h->seen_indices, (int)cutoff, lds_cap,
                      h->topk_items, h->topk_vals);
   HIP_TRY(hipGetLastError());
@@ -1870,7 +1876,7 @@ int ganmf_evaluate(ganmf_handle* h, const int32_t* ids, int64_t n, int transpose
   p.t_indptr = h->test_indptr; p.t_indices = h->test_indices; p.t_gain = h->test_gain;
   p.disc = d_disc; p.ideal_cum = d_ideal; p.ncut = n_cutoffs; p.partials = d_part;
   for (int i = 0; i < n_cutoffs; ++i) p.cutoffs[i] = cutoffs[i];
-  hipLaunchKernelGGL(eval_topk_kernel, dim3(grid), dim3(256), 0, h->st, p);
+  GANMF_LAUNCH(eval_topk_kernel, dim3(grid), dim3(256), 0, h->st, p);
   HIP_TRY(hipGetLastError());
   std::vector<double> part(n_part);
   HIP_TRY(hipMemcpyAsync(part.data(), d_part, n_part * sizeof(double), hipMemcpyDeviceToHost, h->st));

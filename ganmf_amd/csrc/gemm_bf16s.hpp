@@ -289,9 +289,9 @@ template <int BM, int BN, int BK, int NPIECE, bool F16 = false>
 inline hipError_t gemm_bf16s_launch(hipStream_t st, const GemmP& p, bool akm, bool bkm) {
   const int grid = p.tiles_m * p.tiles_n * p.nsplit * p.nbatch;
   if (grid <= 0) return hipSuccess;
-  if (!akm && !bkm) hipLaunchKernelGGL((gemm_bf16s_mfma<BM, BN, BK, false, false, NPIECE, F16>), dim3(grid), dim3(256), 0, st, p);
-  else if (!akm && bkm) hipLaunchKernelGGL((gemm_bf16s_mfma<BM, BN, BK, false, true, NPIECE, F16>), dim3(grid), dim3(256), 0, st, p);
-  else if (akm && bkm) hipLaunchKernelGGL((gemm_bf16s_mfma<BM, BN, BK, true, true, NPIECE, F16>), dim3(grid), dim3(256), 0, st, p);
+  if (!akm && !bkm) GANMF_LAUNCH((gemm_bf16s_mfma<BM, BN, BK, false, false, NPIECE, F16>), dim3(grid), dim3(256), 0, st, p);
+  else if (!akm && bkm) GANMF_LAUNCH((gemm_bf16s_mfma<BM, BN, BK, false, true, NPIECE, F16>), dim3(grid), dim3(256), 0, st, p);
+  else if (akm && bkm) GANMF_LAUNCH((gemm_bf16s_mfma<BM, BN, BK, true, true, NPIECE, F16>), dim3(grid), dim3(256), 0, st, p);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }

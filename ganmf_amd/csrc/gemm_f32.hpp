@@ -31,12 +31,29 @@
 // chosen per GEMM by gemm_plan below; both kernels share gemm_epilogue.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cmath>
 #include <type_traits>
 
 namespace ganmf {
+
+// Every kernel of the library is launched through GANMF_LAUNCH.  While a profiling scope is armed (ganmf_profile_enable:
+// bench.py's per-class table and its `roofline` object) the FIRST launch inside the scope goes through hipExtLaunchKernelGGL
+// with the scope's two events, which the runtime then stamps with the kernel's own start and end -- the same interval
+// rocprofv3 reports -- instead of bracketing the launch with event records (which adds the ~2 us the two marker packets
+// and the launch gap take).  Outside profiling it is a plain hipLaunchKernelGGL.
+struct LaunchProf { hipEvent_t start = nullptr, stop = nullptr; int count = 0; };
+inline LaunchProf& launch_prof() { static thread_local LaunchProf lp; return lp; }
+
+template <class F, class... Args>
+inline void launch_kernel(F kernel, const dim3& grid, const dim3& block, unsigned shmem, hipStream_t st, Args... args) {
+  LaunchProf& lp = launch_prof();
+  if (lp.start && lp.count++ == 0) hipExtLaunchKernelGGL(kernel, grid, block, shmem, st, lp.start, lp.stop, 0, args...);
+  else hipLaunchKernelGGL(kernel, grid, block, shmem, st, args...);
+}
+#define GANMF_LAUNCH(...) ::ganmf::launch_kernel(__VA_ARGS__)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -838,9 +855,9 @@ template <int BM, int BN, int BK, int NS, int KG = 1>
 inline hipError_t gemm_launch_t(hipStream_t st, const GemmP& p, bool akm, bool bkm) {
   const int grid = p.tiles_m * p.tiles_n * p.nsplit * p.nbatch;
   if (grid <= 0) return hipSuccess;
-  if (!akm && !bkm) hipLaunchKernelGGL((gemm_f32_mfma<BM, BN, BK, NS, false, false, KG>), dim3(grid), dim3(256 * KG), 0, st, p);
-  else if (!akm && bkm) hipLaunchKernelGGL((gemm_f32_mfma<BM, BN, BK, NS, false, true, KG>), dim3(grid), dim3(256 * KG), 0, st, p);
-  else if (akm && bkm) hipLaunchKernelGGL((gemm_f32_mfma<BM, BN, BK, NS, true, true, KG>), dim3(grid), dim3(256 * KG), 0, st, p);
+  if (!akm && !bkm) GANMF_LAUNCH((gemm_f32_mfma<BM, BN, BK, NS, false, false, KG>), dim3(grid), dim3(256 * KG), 0, st, p);
+  else if (!akm && bkm) GANMF_LAUNCH((gemm_f32_mfma<BM, BN, BK, NS, false, true, KG>), dim3(grid), dim3(256 * KG), 0, st, p);
+  else if (akm && bkm) GANMF_LAUNCH((gemm_f32_mfma<BM, BN, BK, NS, true, true, KG>), dim3(grid), dim3(256 * KG), 0, st, p);
   else return hipErrorInvalidValue;  // TT is not needed by the GANMF step
   return hipGetLastError();
 }
@@ -874,7 +891,7 @@ inline hipError_t gemm_run(hipStream_t st, GemmP p, bool akm, bool bkm, const Ge
   hipError_t e;
   e = gemm_dispatch(st, p, akm, bkm, pl);
   if (e != hipSuccess || pl.nsplit == 1 || in_launch) return e;
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(GEMM_RED_GRID, p.nbatch), dim3(256), 0, st, r);
+  GANMF_LAUNCH(splitk_reduce_kernel, dim3(GEMM_RED_GRID, p.nbatch), dim3(256), 0, st, r);
   return hipGetLastError();
 }
 

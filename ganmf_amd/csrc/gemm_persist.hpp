@@ -583,7 +583,7 @@ inline hipError_t gemm_persist_launch(hipStream_t st, const GemmP& p, bool akm, 
     (void)hipMemset(dbg, 0, 128 * 8);
     GemmP pd = p;
     pd.counters = reinterpret_cast<unsigned*>(dbg);
-    hipLaunchKernelGGL((gemm_f32_persist<BM, BN, BK, NS, WGM, WGN, false, false>), dim3(pp.grid), dim3(64 * WGM * WGN), 0, st, pd, q);
+    GANMF_LAUNCH((gemm_f32_persist<BM, BN, BK, NS, WGM, WGN, false, false>), dim3(pp.grid), dim3(64 * WGM * WGN), 0, st, pd, q);
     (void)hipDeviceSynchronize();
     unsigned long long hs[128];
     (void)hipMemcpy(hs, dbg, sizeof hs, hipMemcpyDeviceToHost);
@@ -596,7 +596,7 @@ inline hipError_t gemm_persist_launch(hipStream_t st, const GemmP& p, bool akm, 
       }
     return hipGetLastError();
   }
-  hipLaunchKernelGGL((gemm_f32_persist<BM, BN, BK, NS, WGM, WGN, false, false>), dim3(pp.grid), dim3(64 * WGM * WGN), 0, st, p, q);
+  GANMF_LAUNCH((gemm_f32_persist<BM, BN, BK, NS, WGM, WGN, false, false>), dim3(pp.grid), dim3(64 * WGM * WGN), 0, st, p, q);
   return hipGetLastError();
 }
 
@@ -628,7 +628,7 @@ inline hipError_t gemm_dispatch_persist(hipStream_t st, const GemmP& p, bool akm
     (void)hipMemset(dbg, 0, 128 * 8);
     GemmP pd = p;
     pd.counters = reinterpret_cast<unsigned*>(dbg);
-    hipLaunchKernelGGL((gemm_f32_persist2<32, false, false>), dim3(p2.grid), dim3(256), 0, st, pd, q);
+    GANMF_LAUNCH((gemm_f32_persist2<32, false, false>), dim3(p2.grid), dim3(256), 0, st, pd, q);
     (void)hipDeviceSynchronize();
     unsigned long long hs[128];
     (void)hipMemcpy(hs, dbg, sizeof hs, hipMemcpyDeviceToHost);
@@ -642,7 +642,7 @@ inline hipError_t gemm_dispatch_persist(hipStream_t st, const GemmP& p, bool akm
       }
     return hipGetLastError();
   }
-  hipLaunchKernelGGL((gemm_f32_persist2<32, false, false>), dim3(p2.grid), dim3(256), 0, st, p, q);
+  GANMF_LAUNCH((gemm_f32_persist2<32, false, false>), dim3(p2.grid), dim3(256), 0, st, p, q);
   return hipGetLastError();
 }
 
