@@ -107,7 +107,7 @@ enum Tag : int {
   T_DENSIFY, T_GEMM_GEN, T_RED_GEN, T_GEMM_ENC, T_RED_ENC, T_GEMM_DEC, T_RED_DEC, T_DCOEF, T_GEMM_DE, T_RED_DE,
   T_GEMM_GWD, T_RED_GWD, T_GEMM_GWE, T_RED_GWE, T_ADAM_D, T_GEMM_DF, T_RED_DF, T_GEMM_GUB, T_RED_GUB, T_GEMM_GV,
   T_RED_GV, T_ADAM_V, T_ADAM_U, T_MULTIRED, T_ALLREDUCE, T_SCORE_GEMM, T_RED_SCORE, T_DIS_FWD, T_RED_DIS_FWD, T_DIS_HEAD,
-  T_DIS_GW, T_RED_DIS_GW, T_DIS_BWD, T_RED_DIS_BWD, T_FRONT, T_GWD_RED, T_PAIR, T_COUNT
+  T_DIS_GW, T_RED_DIS_GW, T_DIS_BWD, T_RED_DIS_BWD, T_FRONT, T_GWD_RED, T_PAIR, T_DE_DCOEF, T_COUNT
 };
 const char* const kTagName[T_COUNT] = {
   "densify_rows+gather", "gemm_generator[B,k]x[N,k]^T", "reduce_generator", "gemm_encode[2B,N]x[N,e]",
@@ -117,7 +117,7 @@ const char* const kTagName[T_COUNT] = {
   "adam_dense_V", "adam_rows_U", "multi_reduce", "rccl_allreduce", "gemm_scores", "reduce_scores",
   "gemm_dis_layer_fwd", "reduce_dis_layer_fwd", "dis_head", "gemm_dis_gW", "reduce_dis_gW", "gemm_dis_bwd",
   "reduce_dis_bwd", "gemm_generator[B,k]x[N,k]^T + CSR rows (one launch)", "gemm_gWd[2B,e]^Tx[2B,N] + reduce_dE (one launch)",
-  "gemm_gUb[B,N]x[N,k] + gemm_gV[B,N]^Tx[B,k] (one launch)"};
+  "gemm_gUb[B,N]x[N,k] + gemm_gV[B,N]^Tx[B,k] (one launch)", "gemm_dE[2B,N]x[e,N]^T + d_coef (one launch)"};
 
 struct ProfRec { int tag; hipEvent_t a, b; double flops, bytes; };
 
@@ -202,8 +202,8 @@ struct ganmf_handle {
   int reg_cap = 0;
   int pair_ring = 2;      // LDS ring depth of the gUb + gV launch (GANMF_PAIR_RING)
   bool defer_gub = true;  // the split-K slabs of gUb are summed by adam_rows_kernel (no reduce launch)
-  int multi = 7;          // combined launches (gemm_multi.hpp), bit 0: generator GEMM + CSR row expansion, bit 1: gUb + gV,
-                          // bit 2: slab sum of dE inside the gWd launch (GANMF_MULTI)
+  int multi = 15;         // combined launches (gemm_multi.hpp), bit 0: generator GEMM + CSR row expansion, bit 1: gUb + gV,
+                          // bit 2: slab sum of dE inside the gWd launch, bit 3 (with bit 2): d_coef inside the dE launch (GANMF_MULTI)
   float* V_alt = nullptr; // second parameter buffer of item_embeddings: the fused gV update is written there while gUb
                           // still reads the old V in the same launch; swapped with V.p after the launch
   bool fuse_adam = true;  // single GPU: Adam runs in the epilogue of the weight-gradient GEMMs
@@ -726,12 +726,36 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
     }
     TRY(allreduce(h, h->scal + S_SUM_REAL, 2));
   }
-  {
+  const DCoefP dc{h->scal, h->sqp, sqn, sqn, dist ? 1 : 0, h->cfg.m, nb, inv_bn, h->E, h->Es, h->lde, h->rs, parts};
+  const long long dc_total = (long long)2 * nb * (h->lde / 4);
+  // Single GPU, dE split along K: the dE GEMM only writes slabs (its row scale is applied when they are summed, inside the gWd
+  // launch), so it does not depend on the hinge scalars and d_coef rides in ITS launch as extra blocks (de_dcoef_kernel).
+  bool dcoef_done = false;
+  GemmP gde{};
+  GemmPlan pde;
+  if (nb > 0 && !dist && (h->multi & 4) && (h->multi & 8)) {
+    gde.A = h->Dl; gde.lda = h->ldN; gde.B = h->Wd.p; gde.ldb = h->ldN;
+    gde.C = h->dE; gde.ldc = h->lde; gde.M = 2 * nb; gde.N = e; gde.K = N; gde.nbatch = 1;
+    gde.epi.kind = EPI_ROWSCALE; gde.epi.rowscale = h->rs; gde.zero_page = h->zero_page;
+    pde = gemm_plan(gde.M, gde.N, gde.K, 1, false, h->tune);
+    pde.persist = 0;
+    if (plan_is_f32_64_kg(pde, 4) && pde.nsplit > 1 && !(h->inkernel_reduce && pde.nsplit <= h->inlaunch_max)) {
+      TRY(ensure_slab(h, gemm_slab_elems(pde, gde.M, gde.ldc, 1), 0));
+      Scope s(h, T_DE_DCOEF, gemm_flops(gde.M, gde.N, gde.K), gemm_bytes(gde.M, gde.N, gde.K) + 8.0 * 2 * nb * e);
+      GemmP q = gde;
+      fill_plan(q, pde);
+      q.C = h->slab; q.c_split_stride = (long long)gde.M * gde.ldc; q.c_batch_stride = (long long)gde.M * gde.ldc;
+      const int ng = pde.tiles_m * pde.tiles_n * pde.nsplit;
+      const int nd = (int)std::max<long long>(1, std::min<long long>(32, (dc_total + 4095) / 4096));
+      GANMF_LAUNCH(de_dcoef_kernel<4>, dim3(ng + nd), dim3(1024), 0, h->st, q, dc, nd);
+      HIP_TRY(hipGetLastError());
+      dcoef_done = true;
+    }
+  }
+  if (!dcoef_done) {
     Scope s(h, T_DCOEF, 0, 8.0 * 2 * nb * e);
-    const long long total = (long long)2 * nb * (h->lde / 4);
-    const int grid = (int)std::max<long long>(1, std::min<long long>(128, (total + 1023) / 1024));
-    GANMF_LAUNCH(d_coef_kernel, dim3(grid), dim3(256), 0, h->st, h->scal, h->sqp, sqn, sqn,
-                       dist ? 1 : 0, h->cfg.m, nb, inv_bn, h->E, h->Es, h->lde, h->rs, parts);
+    const int grid = (int)std::max<long long>(1, std::min<long long>(128, (dc_total + 1023) / 1024));
+    GANMF_LAUNCH(d_coef_kernel, dim3(grid), dim3(256), 0, h->st, dc);
     HIP_TRY(hipGetLastError());
   }
   if (nb > 0) {
@@ -765,7 +789,12 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
       TRY(lane_fork(h));
       TRY(reduce_scatter(h, h->Wd.g, h->Wd.cap, 1));
     }
-    {  // dE = rs * (Delta . Wd^T)          (bias row e of Wd_ext is not part of this product; reads the OLD Wd)
+    if (dcoef_done) {   // the slabs are there already: hand their sum (+ row scale) to the gWd launch
+      dE_red = RedP{};
+      dE_red.part = h->slab; dE_red.nsplit = pde.nsplit; dE_red.out = gde.C; dE_red.ld = gde.ldc; dE_red.M = gde.M; dE_red.N = gde.N;
+      dE_red.batch_stride = 0; dE_red.epi = gde.epi; dE_red.epi.sq_stride = GEMM_RED_GRID;
+      dE_red.split_stride = (long long)gde.M * gde.ldc;
+    } else {  // dE = rs * (Delta . Wd^T)          (bias row e of Wd_ext is not part of this product; reads the OLD Wd)
       GemmP g{};
       g.A = h->Dl; g.lda = h->ldN; g.B = h->Wd.p; g.ldb = h->ldN;
       g.C = h->dE; g.ldc = h->lde; g.M = 2 * nb; g.N = e; g.K = N;
@@ -1343,7 +1372,7 @@ static int create_impl(const ganmf_cfg* cfg, ganmf_handle* h) {
   HIP_TRY(hipEventCreateWithFlags(&h->ev_mid, hipEventDisableTiming));
   h->fuse_adam = env_int("GANMF_FUSE_ADAM", 1) != 0;
   h->defer_gub = env_int("GANMF_DEFER_GUB", 1) != 0;
-  h->multi = env_int("GANMF_MULTI", 7);
+  h->multi = env_int("GANMF_MULTI", 15);
   h->pair_ring = env_int("GANMF_PAIR_RING", 2) == 3 ? 3 : 2;
   h->inkernel_reduce = env_int("GANMF_INKERNEL_REDUCE", 0) != 0;   // measured slower than the chip-wide reduce kernel
   h->inlaunch_max = env_int("GANMF_INLAUNCH_MAX", 4);

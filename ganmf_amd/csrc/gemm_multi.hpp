@@ -10,6 +10,8 @@
 //   pair_kernel        gUb = dF.V (split-K slabs, summed later by adam_rows_kernel) + gV = dF^T.Ub with the fused Adam
 //                      epilogue: the update of V is written to a SECOND buffer (EpiD::adam_theta_out) because gUb reads
 //                      the old V inside the same launch; the host swaps the two buffers                   (GANMF.py:139)
+//   de_dcoef_kernel    dE = Delta.Wd^T as split-K slabs + the hinge scalars / row scales / Es = rs (.) E of the same step:
+//                      the slabs are scaled when they are summed, one launch later                        (GANMF.py:131-132)
 //   gemm_bf16s_red     gWd_ext = Es^T.Delta with the fused Adam epilogue + the slab sum / row scale of dE = rs (.) (Delta.Wd^T),
 //                      which the previous launch left as split-K slabs and only the NEXT launch (gWe) reads (GANMF.py:138)
 // The bodies are the ordinary kernels' bodies (gemm_f32_body, gemm_bf16s_body, splitk_reduce_body): same arithmetic, same
@@ -28,6 +30,17 @@ __global__ __launch_bounds__(256 * KG) void front_kernel(const GemmP g, const De
   const int ng = g.tiles_m * g.tiles_n * g.nsplit * g.nbatch;
   if ((int)blockIdx.x < ng) gemm_f32_body<64, 64, 64, 3, false, false, KG>(g, (int)blockIdx.x, ng, smem);
   else densify_row_body(d, (int)blockIdx.x - ng);
+}
+
+// blocks [0, ng): 64 x 64 tiles of the NT GEMM dE = Delta . Wd^T, which here only writes its split-K slabs; blocks [ng, ng + nd):
+// the discriminator scalars and Es = rs (.) E (kernels.hpp d_coef_body), whose outputs the GEMM does not read -- the row scale
+// of dE is applied by the slab sum, in the NEXT launch
+template <int KG>
+__global__ __launch_bounds__(256 * KG) void de_dcoef_kernel(const GemmP g, const DCoefP d, const int nd) {
+  __shared__ __attribute__((aligned(16))) float smem[3 * (64 + 64) * 64];
+  const int ng = g.tiles_m * g.tiles_n * g.nsplit * g.nbatch;
+  if ((int)blockIdx.x < ng) gemm_f32_body<64, 64, 64, 3, false, false, KG>(g, (int)blockIdx.x, ng, smem);
+  else d_coef_body(d, (int)blockIdx.x - ng, nd, smem);
 }
 
 // blocks [0, n0): g0, an NN GEMM; blocks [n0, n0 + n1): g1, a TN GEMM

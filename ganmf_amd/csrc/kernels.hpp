@@ -230,47 +230,66 @@ __global__ void col_copy_kernel(float* __restrict__ parts, float* __restrict__ v
 // in every block) and then scales its slice of the encodings: Es = rs (.) E, the A operand of the
 // decoder-gradient GEMM (its ones column becomes rs, which yields the decoder-bias gradient).
 // presummed = 1: scal[S_SUM_REAL/FAKE] already hold the all-reduced sums (data-parallel).
-__global__ __launch_bounds__(256) void d_coef_kernel(float* __restrict__ scal, const float* __restrict__ partials,
-                                                     int np, int pstride, int presummed, float m, int b_local,
-                                                     float inv_bn /* 1/(B_global*N) */, const float* __restrict__ E,
-                                                     float* __restrict__ Es, int lde, float* __restrict__ rs,
-                                                     float* __restrict__ loss_parts) {
-  __shared__ float red[4];
-  __shared__ float sums[2];
-  if (!presummed) {
+struct DCoefP {
+  float* scal;
+  const float* partials;
+  int np, pstride, presummed;
+  float m;
+  int b_local;
+  float inv_bn;               // 1 / (B_global * N)
+  const float* E;
+  float* Es;
+  int lde;
+  float* rs;
+  float* loss_parts;
+};
+
+// (block bx of nbx; any block size that is a multiple of 256: the two sums are formed by the first 256 threads in the order of
+// the 256-thread kernel, so that the launch that carries this body as extra blocks -- gemm_multi.hpp, dE GEMM + d_coef --
+// reproduces it bit for bit; `red` = 6 floats of LDS)
+__device__ __forceinline__ void d_coef_body(const DCoefP& p, const int bx, const int nbx, float* __restrict__ red) {
+  float* sums = red + 4;
+  if (!p.presummed) {
     for (int z = 0; z < 2; ++z) {
       float s = 0.f;
-      for (int i = threadIdx.x; i < np; i += 256) s += partials[(size_t)z * pstride + i];
-      const float t = block_sum_256(s, red);
-      if (threadIdx.x == 0) sums[z] = t;
+      if (threadIdx.x < 256)
+        for (int i = threadIdx.x; i < p.np; i += 256) s += p.partials[(size_t)z * p.pstride + i];
+      s = wave_sum(s);
+      if (threadIdx.x < 256 && (threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+      __syncthreads();
+      if (threadIdx.x == 0) sums[z] = (red[0] + red[1]) + (red[2] + red[3]);
       __syncthreads();
     }
   } else {
-    if (threadIdx.x == 0) { sums[0] = scal[S_SUM_REAL]; sums[1] = scal[S_SUM_FAKE]; }
+    if (threadIdx.x == 0) { sums[0] = p.scal[S_SUM_REAL]; sums[1] = p.scal[S_SUM_FAKE]; }
     __syncthreads();
   }
-  const float Lr = sums[0] * inv_bn, Lf = sums[1] * inv_bn;
-  const float h = m * Lr - Lf;
+  const float Lr = sums[0] * p.inv_bn, Lf = sums[1] * p.inv_bn;
+  const float h = p.m * Lr - Lf;
   const bool on = h > 0.f;
-  const float cr = (on ? 1.f + m : 1.f) * (2.f * inv_bn);
-  const float cf = (on ? -1.f : 0.f) * (2.f * inv_bn);
-  const int c4 = lde / 4;
-  const long long total = (long long)2 * b_local * c4;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (long long)gridDim.x * blockDim.x) {
+  const float cr = (on ? 1.f + p.m : 1.f) * (2.f * p.inv_bn);
+  const float cf = (on ? -1.f : 0.f) * (2.f * p.inv_bn);
+  const int c4 = p.lde / 4;
+  const long long total = (long long)2 * p.b_local * c4;
+  for (long long i = (long long)bx * blockDim.x + threadIdx.x; i < total; i += (long long)nbx * blockDim.x) {
     const int r = (int)(i / c4);
-    const float sc = r < b_local ? cr : cf;
-    float4 v = reinterpret_cast<const float4*>(E)[i];
+    const float sc = r < p.b_local ? cr : cf;
+    float4 v = reinterpret_cast<const float4*>(p.E)[i];
     v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
-    reinterpret_cast<float4*>(Es)[i] = v;
+    reinterpret_cast<float4*>(p.Es)[i] = v;
   }
-  if (blockIdx.x == 0) {
-    for (int r = threadIdx.x; r < 2 * b_local; r += blockDim.x) rs[r] = r < b_local ? cr : cf;
+  if (bx == 0) {
+    for (int r = threadIdx.x; r < 2 * p.b_local; r += blockDim.x) p.rs[r] = r < p.b_local ? cr : cf;
     if (threadIdx.x == 0) {
-      loss_parts[0] = Lr + fmaxf(0.f, h);
-      loss_parts[1] = on ? 1.f : 0.f;
+      p.loss_parts[0] = Lr + fmaxf(0.f, h);
+      p.loss_parts[1] = on ? 1.f : 0.f;
     }
   }
+}
+
+__global__ __launch_bounds__(256) void d_coef_kernel(const DCoefP p) {
+  __shared__ float red[6];
+  d_coef_body(p, (int)blockIdx.x, (int)gridDim.x, red);
 }
 
 // ApplyAdam (dense):  g' = g + reg*theta ; m += (g'-m)(1-b1) ; v += (g'^2-v)(1-b2) ;

@@ -18,6 +18,9 @@ G_STEP = ["void ganmf::front_kernel<4>(ganmf::GemmP, ganmf::DensP)", F32, "ganmf
           "ganmf::splitk_reduce_kernel(ganmf::RedP)", F32, "ganmf::splitk_reduce_kernel(ganmf::RedP)", F32,
           "ganmf::splitk_reduce_kernel(ganmf::RedP)", "void ganmf::pair_kernel<4>(ganmf::GemmP, ganmf::GemmP)",
           "ganmf::adam_rows_kernel(float*)"]
+NEW_D_STEP = ["void ganmf::front_kernel<4>(ganmf::GemmP, ganmf::DensP)", F32, "ganmf::splitk_reduce_kernel(ganmf::RedP)", F32,
+              "void ganmf::de_dcoef_kernel<4>(ganmf::GemmP, ganmf::DCoefP, int)", "ganmf::gemm_bf16s_red(ganmf::GemmP, ganmf::RedP, int)",
+              "void ganmf::gemm_bf16s_mfma<64, 64, 32, true, true, 3, false>(ganmf::GemmP)"]
 OLD_G_STEP = ["ganmf::densify_rows_kernel(ganmf::DensP)", F32, F32, "ganmf::splitk_reduce_kernel(ganmf::RedP)", F32, F32, F32, F32,
               "ganmf::splitk_reduce_kernel(ganmf::RedP)", F32, "ganmf::adam_rows_kernel(float*)"]
 
@@ -43,7 +46,7 @@ def _write(path, steps, counter=None):
 def test_labels_follow_dispatch_order(tmp_path):
     from step_classes import label, load
     p = tmp_path / "trace.csv"
-    _write(p, [D_STEP, G_STEP, D_STEP, OLD_G_STEP, D_STEP[:4]])      # the last step is truncated and must be dropped
+    _write(p, [D_STEP, G_STEP, D_STEP, OLD_G_STEP, NEW_D_STEP, D_STEP[:4]])      # the last step is truncated and must be dropped
     lab = [k for k, _ in label(load(str(p)))]
     assert lab[:8] == ["D:gen+rows", "D:encode", "D:reduce(encode)", "D:decode", "D:d_coef", "D:dE",
                        "D:gWd+adam+reduce(dE)", "D:gWe+adam"]
@@ -52,7 +55,8 @@ def test_labels_follow_dispatch_order(tmp_path):
     old = lab[27:38]      # one kernel per piece: three consecutive launches of ONE instantiation are three classes
     assert old == ["G:densify+gather", "G:gen", "G:encode", "G:reduce(encode)", "G:decode", "G:dE", "G:dF", "G:gUb",
                    "G:reduce(gUb)", "G:gV+adam", "G:adam_rows_U"]
-    assert len(lab) == 8 + 11 + 8 + 11
+    assert lab[38:45] == ["D:gen+rows", "D:encode", "D:reduce(encode)", "D:decode", "D:dE+d_coef", "D:gWd+adam+reduce(dE)", "D:gWe+adam"]
+    assert len(lab) == 8 + 11 + 8 + 11 + 7
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "step_classes.py"), str(p)], capture_output=True, text=True)
     assert out.returncode == 0 and "| D:encode |" in out.stdout and "D+G pair" in out.stdout
 

@@ -8,9 +8,9 @@ launches a step in a fixed order (ganmf_hip.hip d_step / g_step):
   D-step: densify, gen, encode[, reduce], decode[, reduce], d_coef, dE[, reduce], gWd+Adam, gWe+Adam
   G-step: densify, gen, encode[, reduce], decode[, reduce], dE[, reduce], dF[, reduce], gUb[, reduce], gV+Adam, adam_rows_U
 with the combined launches of gemm_multi.hpp standing in for their parts: `front_kernel` = densify + gen, `pair_kernel` =
-gUb + gV+Adam, `gemm_bf16s_red` = gWd+Adam + reduce(dE).
+gUb + gV+Adam, `gemm_bf16s_red` = gWd+Adam + reduce(dE), `de_dcoef_kernel` = dE + d_coef.
 
-A step starts at `densify_rows_kernel` / `sparse_front_kernel` / `front_kernel`; it is a D-step when it contains `d_coef_kernel`.
+A step starts at `densify_rows_kernel` / `sparse_front_kernel` / `front_kernel`; it is a D-step when it contains `d_coef_kernel` or `de_dcoef_kernel`.
 
 usage: step_classes.py <kernel_trace.csv | counter_collection.csv> [> out.md]
 With a counter file every counter is averaged per class next to the duration (PMC runs serialise kernels, so durations
@@ -39,7 +39,7 @@ def load(path):
 
 
 def _gemm_like(n):
-    return "gemm_" in n or "front_kernel" in n or "pair_kernel" in n
+    return "gemm_" in n or "front_kernel" in n or "pair_kernel" in n or "de_dcoef_kernel" in n
 
 
 def label(disp):
@@ -63,7 +63,7 @@ def label(disp):
         elif "gemm_bf16s_mfma<128, 128, 32, false, false, 3" in n:
             out.append(("S:scoring 6040x3706x250 (split-bf16)", d))
     for st in steps:
-        is_d = any("d_coef_kernel" in d["name"] for d in st)
+        is_d = any("d_coef_kernel" in d["name"] or "de_dcoef_kernel" in d["name"] for d in st)
         paired = any("pair_kernel" in d["name"] for d in st)
         names = list(D_GEMMS if is_d else G_GEMMS)
         if paired:
@@ -78,6 +78,8 @@ def label(disp):
                 lab = "gen+rows"; gi += 1; last = "gen"          # generator GEMM + CSR row expansion in one launch
             elif "densify" in n or "sparse_front" in n:
                 lab = "densify+gather"
+            elif "de_dcoef_kernel" in n:
+                lab = names[gi] + "+d_coef"; last = names[gi]; gi += 1    # the hinge scalars / Es ride in the dE launch
             elif "gemm_bf16s_red" in n:
                 lab = names[gi] + "+reduce(%s)" % last; gi += 1  # the slab sum of the previous product rides in this launch
             elif _gemm_like(n):
