@@ -1,0 +1,32 @@
+"""Steps/s of BASELINE configs[4] -- DisGANMF on ML-1M shape (6040 x 3706, k=250, d_nodes=1024, one linear layer, B=128) -- in the
+three arithmetic modes: fp32-accurate (default), fp16 MFMA as the config is written, bf16 MFMA.  Usage: python tools/c5_bench.py"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ganmf_amd import _lib as L  # noqa: E402
+from ganmf_amd.engine import Engine  # noqa: E402
+from ganmf_amd.synthetic import synthetic_urm  # noqa: E402
+from oracle.ganmf_oracle import DisGANMFOracle  # noqa: E402   (initial weights only: Glorot draws in the reference's tensor order)
+
+U, N, k, e, B = 6040, 3706, 250, 1024, 128
+hp = dict(d_lr=1e-4, g_lr=5.665e-4, d_reg=3.002e-5, g_reg=0.0, recon_coefficient=0.5)
+urm = synthetic_urm(U, N, 0.035, seed=1337)
+o = DisGANMFOracle(U, N, k, d_layers=1, d_nodes=e, d_hidden_act="linear", dtype=np.float32, seed=1337, **hp)
+perm = np.random.RandomState(0).permutation(U)[:B * 47]
+for mfma in (None, "f16", "bf16"):
+    eng = Engine(U, N, k, e, B, model=L.MODEL_DISGANMF, d_layers=1, d_act="linear", m=0.0, mfma=mfma, **hp)
+    eng.set_urm(urm)
+    for n, tid in {"W0": 0, "b0": 1, "Wo": 2, "bo": 3, "U": 100, "V": 101}.items():
+        eng.set_tensor(tid, o.p[n])
+    eng.train_epoch(perm[:B * 8], 1, 1)
+    best = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter()
+        eng.train_epoch(perm, 1, 1)
+        best = min(best, time.perf_counter() - t0)
+    print("C5 DisGANMF mfma=%-5s: %7.0f steps/s (%.1f us/step)" % (mfma or "auto", 94 / best, best / 94 * 1e6))
+    eng.close()
