@@ -1079,7 +1079,7 @@ int dis_d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float
       Scope s(h, T_DIS_HEAD, 0, 4.0 * 2 * nb * e * 3);
       GANMF_LAUNCH(dis_head_kernel, dim3((2 * nb + 3) / 4), dim3(256), 0, h->st, feat, h->lde, e + 1,
                          h->Wo.p, 0, 2 * nb, nb, inv_b, h->dlogit, h->lossrow);
-      GANMF_LAUNCH(dis_dz_top_kernel, dim3((e + 1 + 63) / 64), dim3(256), 0, h->st, feat, h->lde, e,
+      GANMF_LAUNCH(dis_dz_top_kernel, dim3(dis_dz_top_blocks(e)), dim3(DZ_COLS * DZ_GROUPS), 0, h->st, feat, h->lde, e,
                          h->Wo.p, h->dlogit, 0, 2 * nb, 0, 0.f, h->act, h->dz0, h->Wo.g, (float*)nullptr);
       HIP_TRY(hipGetLastError());
     }
@@ -1136,8 +1136,8 @@ int dis_g_step(ganmf_handle* h, const int* rows_dev, int nb, int start, int b_gl
       Scope s(h, T_DIS_HEAD, 0, 4.0 * 2 * nb * e * 3);
       GANMF_LAUNCH(dis_head_kernel, dim3((nb + 3) / 4), dim3(256), 0, h->st, feat, h->lde, e + 1, h->Wo.p,
                          nb, nb, nb, inv_b, h->dlogit, h->lossrow);
-      fmn = (e + 1 + 63) / 64;
-      GANMF_LAUNCH(dis_dz_top_kernel, dim3(fmn), dim3(256), 0, h->st, feat, h->lde, e, h->Wo.p, h->dlogit,
+      fmn = dis_dz_top_blocks(e);
+      GANMF_LAUNCH(dis_dz_top_kernel, dim3(fmn), dim3(DZ_COLS * DZ_GROUPS), 0, h->st, feat, h->lde, e, h->Wo.p, h->dlogit,
                          nb, nb, nb, fmc, h->act, h->dz0, (float*)nullptr, h->fmp);
       HIP_TRY(hipGetLastError());
     }
@@ -1438,7 +1438,7 @@ static int create_impl(const ganmf_cfg* cfg, ganmf_handle* h) {
   TRY(dalloc(&h->scal, S_COUNT));
   TRY(dalloc(&h->sqp, (size_t)2 * std::max(GEMM_RED_GRID, ((B + 63) / 64) * ((N + 63) / 64)) + 16));
   // FM partials: one per tile of the [B, e] dE output or per reduce block
-  TRY(dalloc(&h->fmp, std::max(RED_GRID, ((B + 63) / 64) * ((e + 63) / 64) + (e + 64) / 64 + 1)));
+  TRY(dalloc(&h->fmp, std::max({RED_GRID, ((B + 63) / 64) * ((e + 63) / 64) + (e + 64) / 64 + 1, dis_dz_top_blocks(e) + 1})));
   {
     auto t64 = [](int a, int b) { return ((a + 63) / 64) * ((b + 63) / 64); };
     h->reg_cap = std::max({ADAM_GRID, (int)GEMM_RED_GRID, t64(N + 2, e), t64(e + 1, N), t64(N, k), t64(B, N), t64(B, e)});

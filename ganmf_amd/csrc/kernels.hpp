@@ -408,18 +408,25 @@ __global__ __launch_bounds__(256) void dis_head_kernel(const float* __restrict__
 //   dz[r, j] = dh * act'(feat[r, j])                 (columns < e only)
 //   gwo[j] = sum_r feat[r, j] * dlogit[r]            (D-step; column e = 1 gives the bias gradient)
 //   fm partial = sum (feat_f - feat_r)^2             (G-step)
-__global__ __launch_bounds__(256) void dis_dz_top_kernel(const float* __restrict__ feat, int ld, int e,
-                                                         const float* __restrict__ wo,
-                                                         const float* __restrict__ dlogit, int row0, int nrows,
-                                                         int pair_off, float fmc, int act, float* __restrict__ dz,
-                                                         float* __restrict__ gwo, float* __restrict__ fm_partials) {
-  __shared__ float red[4][64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int g = threadIdx.x >> 6;
+// A block takes DZ_COLS columns and splits the rows over DZ_GROUPS row groups (thread = (group, column)): 65 blocks of 1024
+// threads at d_nodes = 1024 with two to four rows per thread, where round 1's 64-column blocks left 17 workgroups walking 64
+// rows each (30 us of a 127 us step).  The column sums add the groups in group order, the feature-matching partial the
+// waves in wave order: fixed, reproducible.
+constexpr int DZ_COLS = 16, DZ_GROUPS = 64;
+inline int dis_dz_top_blocks(int e) { return (e + 1 + DZ_COLS - 1) / DZ_COLS; }
+
+__global__ __launch_bounds__(DZ_COLS * DZ_GROUPS) void dis_dz_top_kernel(const float* __restrict__ feat, int ld, int e,
+                                                                          const float* __restrict__ wo,
+                                                                          const float* __restrict__ dlogit, int row0, int nrows,
+                                                                          int pair_off, float fmc, int act, float* __restrict__ dz,
+                                                                          float* __restrict__ gwo, float* __restrict__ fm_partials) {
+  __shared__ float red[DZ_GROUPS][DZ_COLS];
+  const int cl = threadIdx.x % DZ_COLS, g = threadIdx.x / DZ_COLS;
+  const int c = blockIdx.x * DZ_COLS + cl;
   float acc = 0.f, fm = 0.f;
   if (c <= e) {
     const float w = wo[c];
-    for (int r = row0 + g; r < row0 + nrows; r += 4) {
+    for (int r = row0 + g; r < row0 + nrows; r += DZ_GROUPS) {
       const float a = feat[(size_t)r * ld + c];
       const float dl = dlogit[r];
       acc += a * dl;
@@ -434,15 +441,25 @@ __global__ __launch_bounds__(256) void dis_dz_top_kernel(const float* __restrict
       }
     }
   }
-  red[g][threadIdx.x & 63] = acc;
+  red[g][cl] = acc;
   __syncthreads();
-  if (g == 0 && c <= e && gwo) gwo[c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  if (g == 0 && c <= e && gwo) {
+    float t = red[0][cl];
+#pragma unroll 8
+    for (int q = 1; q < DZ_GROUPS; ++q) t += red[q][cl];
+    gwo[c] = t;
+  }
   if (fm_partials) {
     __syncthreads();
     fm = wave_sum(fm);
-    if ((threadIdx.x & 63) == 0) red[0][g] = fm;
+    float* wsum = &red[0][0];
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = fm;
     __syncthreads();
-    if (threadIdx.x == 0) fm_partials[blockIdx.x] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    if (threadIdx.x == 0) {
+      float t = 0.f;
+      for (int q = 0; q < DZ_COLS * DZ_GROUPS / 64; ++q) t += wsum[q];
+      fm_partials[blockIdx.x] = t;
+    }
   }
 }
 

@@ -30,3 +30,16 @@ for mfma in (None, "f16", "bf16"):
         best = min(best, time.perf_counter() - t0)
     print("C5 DisGANMF mfma=%-5s: %7.0f steps/s (%.1f us/step)" % (mfma or "auto", 94 / best, best / 94 * 1e6))
     eng.close()
+    if mfma is None and "--profile" in sys.argv:
+        eng2 = Engine(U, N, k, e, B, model=L.MODEL_DISGANMF, d_layers=1, d_act="linear", m=0.0, **hp)
+        eng2.set_urm(urm)
+        for n, tid in {"W0": 0, "b0": 1, "Wo": 2, "bo": 3, "U": 100, "V": 101}.items():
+            eng2.set_tensor(tid, o.p[n])
+        eng2.train_epoch(perm[:B * 8], 1, 1)
+        eng2.profile(True)
+        eng2.train_epoch(perm[:B * 24], 1, 1)
+        rows = eng2.profile_read()
+        tot = sum(r["ms"] for r in rows)
+        for r in sorted(rows, key=lambda r: -r["ms"]):
+            print("   %-52s %4d launches %7.1f us/launch %5.1f %%" % (r["name"][:52], r["launches"], r["ms"] / r["launches"] * 1e3, 100 * r["ms"] / tot))
+        eng2.close()
