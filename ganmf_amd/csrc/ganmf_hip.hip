@@ -721,7 +721,7 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
     mr.e[1] = {h->sqp + sqn, sqn, S_SUM_FAKE, 0};
     {
       Scope s(h, T_MULTIRED, 0, 0);
-      GANMF_LAUNCH(multi_reduce_kernel, dim3(1), dim3(256), 0, h->st, mr);
+      GANMF_LAUNCH(multi_reduce_kernel, dim3(S_SUM_FAKE + 1), dim3(256), 0, h->st, mr);      // block = destination slot
       HIP_TRY(hipGetLastError());
     }
     TRY(allreduce(h, h->scal + S_SUM_REAL, 2));
@@ -1107,15 +1107,19 @@ int dis_d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float
     mr.e[0] = {h->lossrow, nb, 0, 0};
     mr.e[1] = {h->lossrow + nb, nb, 1, 0};
     mr.count = 2;
+    int first = 0;      // reg partials of the L + 1 tensors chain into parts[2]; as many as fit ride in the first launch
+    if (reg)
+      for (; first <= h->L && mr.count < MULTIRED_MAX; ++first)
+        mr.e[mr.count++] = {h->regp + (4 + first) * h->reg_cap, ADAM_GRID, 2, first ? 1 : 0};
     Scope s(h, T_MULTIRED, 0, 0);
-    GANMF_LAUNCH(multi_reduce_kernel, dim3(1), dim3(256), 0, h->st, mr);
+    GANMF_LAUNCH(multi_reduce_kernel, dim3(3), dim3(256), 0, h->st, mr);
     if (reg) {
-      for (int i = 0; i <= h->L; i += 6) {
+      for (int i = first; i <= h->L; i += MULTIRED_MAX) {
         MultiRed m2{};
         m2.out = parts;
-        m2.count = std::min(6, h->L + 1 - i);
-        for (int j = 0; j < m2.count; ++j) m2.e[j] = {h->regp + (4 + i + j) * h->reg_cap, ADAM_GRID, 2, (i + j) ? 1 : 0};
-        GANMF_LAUNCH(multi_reduce_kernel, dim3(1), dim3(256), 0, h->st, m2);
+        m2.count = std::min(MULTIRED_MAX, h->L + 1 - i);
+        for (int j = 0; j < m2.count; ++j) m2.e[j] = {h->regp + (4 + i + j) * h->reg_cap, ADAM_GRID, 2, 1};
+        GANMF_LAUNCH(multi_reduce_kernel, dim3(3), dim3(256), 0, h->st, m2);
       }
     }
     HIP_TRY(hipGetLastError());
@@ -1169,7 +1173,7 @@ int dis_g_step(ganmf_handle* h, const int* rows_dev, int nb, int start, int b_gl
       mr.count = 4;
     }
     Scope s(h, T_MULTIRED, 0, 0);
-    GANMF_LAUNCH(multi_reduce_kernel, dim3(1), dim3(256), 0, h->st, mr);
+    GANMF_LAUNCH(multi_reduce_kernel, dim3(4), dim3(256), 0, h->st, mr);
     HIP_TRY(hipGetLastError());
   }
   return 0;

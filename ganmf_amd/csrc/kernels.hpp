@@ -178,15 +178,19 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
   }
 }
 
-// Several reproducible sums in ONE launch (one block, entries processed in order):
+// Several reproducible sums in ONE launch:
 //   dst[e.dst] (+)= sum_i e.p[i], i < e.n     -- accumulate=0 overwrites, 1 adds
+// One block per destination (blockIdx.x = dst; launch max dst + 1 blocks): a block walks the entries of ITS destination in
+// entry order (the accumulate chain of a destination keeps its order), destinations run side by side.
 struct MultiRedEntry { const float* p; int n; int dst; int accumulate; };
-struct MultiRed { MultiRedEntry e[6]; int count; float* out; };
+constexpr int MULTIRED_MAX = 8;
+struct MultiRed { MultiRedEntry e[MULTIRED_MAX]; int count; float* out; };
 
 __global__ __launch_bounds__(256) void multi_reduce_kernel(const MultiRed mr) {
   __shared__ float red[4];
   for (int z = 0; z < mr.count; ++z) {
     const MultiRedEntry e = mr.e[z];
+    if (e.dst != (int)blockIdx.x) continue;      // uniform over the block
     float s = 0.f;
     for (int i = threadIdx.x; i < e.n; i += 256) s += e.p[i];
     const float t = block_sum_256(s, red);
