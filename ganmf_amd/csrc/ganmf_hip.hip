@@ -201,6 +201,8 @@ struct ganmf_handle {
   float* regp = nullptr;  // [slots][reg_cap] block partials of sum(theta^2): We_ext, Wd_ext, U, V, (DisGANMF layers)
   int reg_cap = 0;
   int pair_ring = 2;      // LDS ring depth of the gUb + gV launch (GANMF_PAIR_RING)
+  bool dis_fused0 = false; // DisGANMF: this step's layer-0 update ran in the epilogue of its gradient GEMM (dis_backprop_hidden)
+  int dis_regn0 = 0;       //           and left this many sum(theta^2) partials
   bool defer_gub = true;  // the split-K slabs of gUb are summed by adam_rows_kernel (no reduce launch)
   int multi = 15;         // combined launches (gemm_multi.hpp), bit 0: generator GEMM + CSR row expansion, bit 1: gUb + gV,
                           // bit 2: slab sum of dE inside the gWd launch, bit 3 (with bit 2): d_coef inside the dE launch (GANMF_MULTI)
@@ -1047,6 +1049,26 @@ int dis_backprop_hidden(ganmf_handle* h, int row0, int nrows, bool param_grads, 
       g.b_scale = gsc;
       const bool uid_apart = l == 0 && low_precision(h);
       if (uid_apart) g.M = N + 1;      // the float(uid) row of W_0_ext gets its gradient from the fp32 reduction below
+      // Layer 0 holds nearly all discriminator parameters ([N+2, e]) and nothing reads W_0 after its gradient in this step
+      // (the backward GEMMs below use W_l, l > 0): TF-Adam runs in the epilogue of its gradient GEMM, as for GANMF's two
+      // tensors -- the gradient is never stored, no adam_dense pass.  Not with a communicator (the gradient must be reduced
+      // first) and not in the low-precision modes (the uid row's gradient comes from the fp32 kernel below).
+      const bool fuse0 = l == 0 && h->fuse_adam && !h->has_comm && !uid_apart;
+      h->dis_fused0 = false;
+      if (fuse0) {
+        const bool regD = h->cfg.d_reg != 0.f;
+        g.epi.kind = EPI_ADAM; g.epi.adam_theta = h->Wl[0].p; g.epi.adam_m = h->Wl[0].m; g.epi.adam_v = h->Wl[0].v;
+        g.epi.adam_alpha = h->scal + S_ALPHA_D; g.epi.adam_reg = h->cfg.d_reg;
+        g.epi.sq_partials = regD ? h->regp + (size_t)4 * h->reg_cap : nullptr;
+        GemmTune ft;
+        ft.tile = 64; ft.ring = 2; ft.nsplit = 1;
+        ft.mode = h->tune.mode != MFMA_AUTO ? h->tune.mode : h->fused_mode;
+        ft.bk = h->fused_bk;
+        int regn0 = ADAM_GRID;
+        TRY(run_gemm(h, T_DIS_GW, T_RED_DIS_GW, g, true, true, &regn0, 24.0 * h->Wl[0].count(), 0, &ft));
+        h->dis_fused0 = true;
+        h->dis_regn0 = regn0;
+      } else
       TRY(run_gemm(h, T_DIS_GW, T_RED_DIS_GW, g, true, true));
       if (uid_apart) {
         GANMF_LAUNCH(dis_uid_grad_kernel, dim3((e + 255) / 256), dim3(256), 0, h->st, h->XF, h->ldN, N + 1, cur, h->lde,
@@ -1097,8 +1119,10 @@ int dis_d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float
       TRY(dp_update(h, T_ADAM_D, h->Wl[l], S_ALPHA_D, h->cfg.d_reg, reg ? h->regp + (4 + l) * h->reg_cap : nullptr, 0));
     TRY(dp_update(h, T_ADAM_D, h->Wo, S_ALPHA_D, h->cfg.d_reg, reg ? h->regp + (4 + h->L) * h->reg_cap : nullptr, 0));
   } else {
-    for (int l = 0; l < h->L; ++l)
+    for (int l = 0; l < h->L; ++l) {
+      if (l == 0 && nb > 0 && h->dis_fused0) continue;      // updated in the epilogue of its gradient GEMM
       TRY(adam_dense(h, T_ADAM_D, h->Wl[l], h->Wl[l].g, S_ALPHA_D, h->cfg.d_reg, reg ? h->regp + (4 + l) * h->reg_cap : nullptr));
+    }
     TRY(adam_dense(h, T_ADAM_D, h->Wo, h->Wo.g, S_ALPHA_D, h->cfg.d_reg, reg ? h->regp + (4 + h->L) * h->reg_cap : nullptr));
   }
   {  // parts = {sum sce(real), sum sce(fake), sum theta_D^2}
@@ -1110,7 +1134,8 @@ int dis_d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float
     int first = 0;      // reg partials of the L + 1 tensors chain into parts[2]; as many as fit ride in the first launch
     if (reg)
       for (; first <= h->L && mr.count < MULTIRED_MAX; ++first)
-        mr.e[mr.count++] = {h->regp + (4 + first) * h->reg_cap, ADAM_GRID, 2, first ? 1 : 0};
+        mr.e[mr.count++] = {h->regp + (4 + first) * h->reg_cap, (first == 0 && nb > 0 && h->dis_fused0) ? h->dis_regn0 : ADAM_GRID, 2,
+                            first ? 1 : 0};
     Scope s(h, T_MULTIRED, 0, 0);
     GANMF_LAUNCH(multi_reduce_kernel, dim3(3), dim3(256), 0, h->st, mr);
     if (reg) {

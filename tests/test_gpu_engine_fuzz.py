@@ -84,9 +84,21 @@ def test_disganmf_random_config(seed):
 
 
 def test_engine_create_destroy_does_not_leak():
-    """The tuner creates and destroys an engine per trial: device memory must return to the pool."""
-    import torch
+    """The tuner creates and destroys an engine per trial: device memory must return to the pool.
+    (hipMemGetInfo through the HIP runtime the library already loaded -- no second framework's device initialisation in
+    the middle of a test process.)"""
+    import ctypes
     from ganmf_amd.engine import Engine
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+    except OSError:
+        hip = ctypes.CDLL("/opt/rocm/lib/libamdhip64.so")
+
+    def free_bytes():
+        assert hip.hipDeviceSynchronize() == 0
+        free, total = ctypes.c_size_t(), ctypes.c_size_t()
+        assert hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0
+        return free.value
     rng = np.random.RandomState(0)
     urm = sps.csr_matrix((rng.rand(300, 500) < 0.05).astype(np.float32))
 
@@ -101,9 +113,7 @@ def test_engine_create_destroy_does_not_leak():
             eng.snapshot_best()
             eng.close()
     cycle(40)                                  # warm allocator / RCCL / HIP module state: what earlier tests of the same
-    torch.cuda.synchronize()                   # process left in the runtime's pools settles here, a leak keeps growing
-    free0, _ = torch.cuda.mem_get_info()
+    free0 = free_bytes()                       # process left in the runtime's pools settles here, a leak keeps growing
     cycle(40)
-    torch.cuda.synchronize()
-    free1, _ = torch.cuda.mem_get_info()
+    free1 = free_bytes()
     assert free0 - free1 < 8 << 20, "device memory shrank by %.1f MiB over 40 engine lifetimes" % ((free0 - free1) / 2 ** 20)
