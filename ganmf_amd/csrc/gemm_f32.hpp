@@ -807,6 +807,10 @@ inline GemmPlan gemm_plan(int M, int N, int K, int nbatch, bool wants_sq, const 
   for (const TileShape& ts : kTileShapes) {
     const int tile = ts.code;
     if (tune.tile && tune.tile != tile) continue;
+    // an output at most 64 rows or columns wide fills at most half of a 128 x 128 tile: twice the padded MFMA work and a row
+    // pass of 16 dependent load -> Adam -> store rounds on a handful of lanes (gV at the reference's default batch 32, k = 10:
+    // 36 us on 128-tiles, 10 us on 64-tiles) -- the model below only sees the workgroup count
+    if (!tune.tile && tile == 128 && (M <= 64 || N <= 64)) continue;
     const int tm = (M + ts.bm - 1) / ts.bm, tn = (N + ts.bn - 1) / ts.bn;
     const long long T = (long long)tm * tn * nbatch;
     const int bk = ts.bk;
