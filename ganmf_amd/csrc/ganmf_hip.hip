@@ -621,7 +621,9 @@ int rows_and_generator(ganmf_handle* h, const int* rows_dev, int nb, int which, 
   g.C = h->XF + (size_t)nb * h->ldN; g.ldc = h->ldN;
   g.M = nb; g.N = N; g.K = k; g.epi.kind = EPI_STORE; g.nbatch = 1;
   g.zero_page = h->zero_page;
-  GemmPlan pl = gemm_plan(g.M, g.N, g.K, 1, false, h->tune);
+  // K = num_factors is at most four K-tiles: a split would trade three of them for a reduce launch and keep the GEMM out of
+  // the combined launch (B = 64 at ML-1M shape: 4.5 + 5.2 + 4.6 us as three kernels, ~8 us as one)
+  GemmPlan pl = gemm_plan(g.M, g.N, g.K, 1, false, h->tune, /*no_split=*/(h->multi & 1) != 0 && k <= 256);
   pl.persist = gemm_persist_eligible(g, false, false, pl, h->tune.persist) ? 1 : 0;
   if ((h->multi & 1) && plan_is_f32_64_kg(pl, 4) && pl.nsplit == 1) {
     if (h->debug_plan) {
