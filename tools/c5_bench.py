@@ -13,14 +13,19 @@ from ganmf_amd.synthetic import synthetic_urm  # noqa: E402
 from oracle.ganmf_oracle import DisGANMFOracle  # noqa: E402   (initial weights only: Glorot draws in the reference's tensor order)
 
 U, N, k, e, B = 6040, 3706, 250, 1024, 128
+LAYERS = int(sys.argv[sys.argv.index("--layers") + 1]) if "--layers" in sys.argv else 1
+ACT = sys.argv[sys.argv.index("--act") + 1] if "--act" in sys.argv else "linear"
 hp = dict(d_lr=1e-4, g_lr=5.665e-4, d_reg=3.002e-5, g_reg=0.0, recon_coefficient=0.5)
 urm = synthetic_urm(U, N, 0.035, seed=1337)
-o = DisGANMFOracle(U, N, k, d_layers=1, d_nodes=e, d_hidden_act="linear", dtype=np.float32, seed=1337, **hp)
+o = DisGANMFOracle(U, N, k, d_layers=LAYERS, d_nodes=e, d_hidden_act=ACT, dtype=np.float32, seed=1337, **hp)
+IDS = {"U": 100, "V": 101, "Wo": 2 * LAYERS, "bo": 2 * LAYERS + 1}
+for _l in range(LAYERS):
+    IDS["W%d" % _l], IDS["b%d" % _l] = 2 * _l, 2 * _l + 1
 perm = np.random.RandomState(0).permutation(U)[:B * 47]
 for mfma in (None, "f16", "bf16"):
-    eng = Engine(U, N, k, e, B, model=L.MODEL_DISGANMF, d_layers=1, d_act="linear", m=0.0, mfma=mfma, **hp)
+    eng = Engine(U, N, k, e, B, model=L.MODEL_DISGANMF, d_layers=LAYERS, d_act=ACT, m=0.0, mfma=mfma, **hp)
     eng.set_urm(urm)
-    for n, tid in {"W0": 0, "b0": 1, "Wo": 2, "bo": 3, "U": 100, "V": 101}.items():
+    for n, tid in IDS.items():
         eng.set_tensor(tid, o.p[n])
     eng.train_epoch(perm[:B * 8], 1, 1)
     best = 1e9
@@ -31,9 +36,9 @@ for mfma in (None, "f16", "bf16"):
     print("C5 DisGANMF mfma=%-5s: %7.0f steps/s (%.1f us/step)" % (mfma or "auto", 94 / best, best / 94 * 1e6))
     eng.close()
     if mfma is None and "--profile" in sys.argv:
-        eng2 = Engine(U, N, k, e, B, model=L.MODEL_DISGANMF, d_layers=1, d_act="linear", m=0.0, **hp)
+        eng2 = Engine(U, N, k, e, B, model=L.MODEL_DISGANMF, d_layers=LAYERS, d_act=ACT, m=0.0, **hp)
         eng2.set_urm(urm)
-        for n, tid in {"W0": 0, "b0": 1, "Wo": 2, "bo": 3, "U": 100, "V": 101}.items():
+        for n, tid in IDS.items():
             eng2.set_tensor(tid, o.p[n])
         eng2.train_epoch(perm[:B * 8], 1, 1)
         eng2.profile(True)
