@@ -881,7 +881,11 @@ int gen_update(ganmf_handle* h, int nb, int start, int b_global, int* regn_v, fl
     ft.tile = 64; ft.ring = 2; ft.nsplit = 1;
     ft.mode = h->tune.mode != MFMA_AUTO ? h->tune.mode : h->fused_mode;
     ft.bk = h->fused_bk;
-    const bool staged_gv = env_int("GANMF_GV_STAGED", 0) != 0;   // measured: 18.1 us staged vs 17.2 us on the fp32 ring kernel (2 K-tiles: latency, not occupancy)
+    // the half-depth staged split-bf16 kernel of the other fused-Adam GEMMs once the output has at least two 64 x 64 tiles per
+    // CU (C4 width, N = 50 000: 136 -> 102 us, +2 .. 5 % steps/s); below that the fp32 ring kernel (C2: 17.2 vs 18.1 us, and it
+    // pairs with gUb in one launch).  GANMF_GV_STAGED = 0 / 1 forces either.
+    const long long gv_tiles = (long long)((N + 63) / 64) * ((k + 63) / 64);
+    const bool staged_gv = env_int("GANMF_GV_STAGED", gv_tiles >= 2 * GEMM_CUS ? 1 : 0) != 0;
     TRY(run_gemm(h, T_GEMM_GV, T_RED_GV, g, true, true, regn_v, fused ? 24.0 * h->V.count() : 0, 0, staged_gv ? &ft : nullptr));
     if (!fused) *regn_v = ADAM_GRID;
     return 0;
