@@ -1395,6 +1395,7 @@ static int create_impl(const ganmf_cfg* cfg, ganmf_handle* h) {
   h->tune.mode = env_mfma_mode((cfg->flags & GANMF_FLAG_MFMA_F16) ? MFMA_F16 : (cfg->flags & GANMF_FLAG_MFMA_BF16) ? MFMA_BF16 : (cfg->flags & GANMF_FLAG_MFMA_F32) ? MFMA_F32 : MFMA_DEFAULT);
   h->tune.persist = env_int("GANMF_PERSIST", -1);
   h->tune.kg = env_int("GANMF_KG", 0);
+  h->tune.tile_order = env_int("GANMF_TILE_ORDER", 0);
   if (h->tune.kg != 0 && h->tune.kg != 1 && h->tune.kg != 2 && h->tune.kg != 4) h->tune.kg = 0;
   h->debug_plan = env_int("GANMF_DEBUG_PLAN", 0) != 0;
   h->fused_mode = env_int("GANMF_FUSED_X3", 1) ? MFMA_BF16X3 : MFMA_F32;
@@ -2074,6 +2075,7 @@ int ganmf_gemm_f32(int device, const float* A, const float* B, float* C, int64_t
   if (tune.ring != 0 && tune.ring != 2 && tune.ring != 3 && tune.ring != 4) tune.ring = 0;
   tune.persist = env_int("GANMF_PERSIST", -1);
   tune.kg = env_int("GANMF_KG", 0);
+  tune.tile_order = env_int("GANMF_TILE_ORDER", 0);
   if (tune.kg != 0 && tune.kg != 1 && tune.kg != 2 && tune.kg != 4) tune.kg = 0;
   GemmPlan pl = gemm_plan(g.M, g.N, g.K, 1, false, tune);
   pl.persist = gemm_persist_eligible(g, a_kmajor, b_kmajor, pl, tune.persist) ? (tune.persist >= 2 ? tune.persist : 1) : 0;

@@ -160,11 +160,8 @@ __device__ __forceinline__ void gemm_bf16s_body(const GemmP& p, const int bid, c
   const int wr = wave >> 1, wc = wave & 1;
   const int li = lane & 31, lh = lane >> 5;
 
-  int t = xcd_remap(bid, nblk);
-  const int tm = t % p.tiles_m; t /= p.tiles_m;
-  const int tn = t % p.tiles_n; t /= p.tiles_n;
-  const int sp = t % p.nsplit;
-  const int bz = t / p.nsplit;
+  int tm, tn, sp, bz;
+  tile_coords(p, bid, nblk, tm, tn, sp, bz);
   const int m0 = tm * BM, n0 = tn * BN;
   const int kbeg = sp * p.k_per_split;
   const int kend = min(p.K, kbeg + p.k_per_split);

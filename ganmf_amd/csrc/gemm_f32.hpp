@@ -247,6 +247,11 @@ struct GemmP {
   const int* a_gather;          // K-contiguous A only: row r of A is A + a_gather[r] * lda (embedding lookup folded into the
                                 // operand fetch, GANMF.py:82); nullptr: row r is A + r * lda
   float a_scale, b_scale;       // MFMA_F16: powers of two applied to the operands at conversion (0 = 1); acc *= 1 / (a_scale * b_scale)
+  // Blocked tile order of the one-tile-per-workgroup kernels (0 = tm-fastest list order).  Plain products with many more
+  // tiles than CUs (the scoring GEMM): the tile grid is cut into xb_m x xb_n = 8 rectangles, one per XCD, and a rectangle
+  // is walked in bands of xb_band tile rows, M-innermost, so an XCD's L2 keeps its A band and streams its B panels once per
+  // band (tile_coords below; speed only, any order is correct).
+  int xb_m, xb_n, xb_band;
 };
 
 #define GANMF_WAIT_VMCNT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
@@ -363,6 +368,38 @@ __device__ inline int xcd_remap(int bid, int nwg) {
   // blocks b and b+8 share an XCD (observed round-robin dispatch; speed only, never correctness)
   const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+
+__host__ __device__ inline int part_begin(int n, int parts, int i) { return (int)(((long long)n * i) / parts); }
+
+// block id -> (tile row, tile column, K split, batch).  Default: list order, tm fastest, each XCD a contiguous range of the
+// list.  GemmP::xb_m > 0: the list is re-ordered rectangle by rectangle (rectangle r = (r % xb_m, r / xb_m) of the tile grid),
+// inside a rectangle band by band, inside a band M-innermost; XCD x still takes a contiguous range of the list, i.e. its own
+// rectangle up to a few tiles of drift where the rectangles' sizes differ.  Bijective for every shape.
+__device__ inline void tile_coords(const GemmP& p, int bid, int nblk, int& tm, int& tn, int& sp, int& bz) {
+  int t = xcd_remap(bid, nblk);
+  if (p.xb_m > 0) {
+    sp = 0; bz = 0;
+    int mb0 = 0, nb0 = 0, bm = 1, bn = 1;
+    for (int r = 0; r < 8; ++r) {
+      const int i = r % p.xb_m, j = r / p.xb_m;
+      mb0 = part_begin(p.tiles_m, p.xb_m, i); bm = part_begin(p.tiles_m, p.xb_m, i + 1) - mb0;
+      nb0 = part_begin(p.tiles_n, p.xb_n, j); bn = part_begin(p.tiles_n, p.xb_n, j + 1) - nb0;
+      if (t < bm * bn) break;
+      t -= bm * bn;
+    }
+    const int bh = min(max(p.xb_band, 1), bm);     // band height in tiles
+    const int band = t / (bh * bn);
+    const int r = t - band * bh * bn;
+    const int h = min(bh, bm - band * bh);          // the last band of a rectangle may be shorter
+    tm = mb0 + band * bh + r % h;
+    tn = nb0 + r / h;
+    return;
+  }
+  tm = t % p.tiles_m; t /= p.tiles_m;
+  tn = t % p.tiles_n; t /= p.tiles_n;
+  sp = t % p.nsplit;
+  bz = t / p.nsplit;
 }
 
 // ---- epilogue shared by every GEMM kernel.  C/D layout of the 32x32 MFMA: col = lane & 31,
@@ -557,11 +594,8 @@ __device__ __forceinline__ void gemm_f32_body(const GemmP& p, const int bid, con
   const int wr = (wave >> 1) & 1, wc = wave & 1;
   const int li = lane & 31, lh = lane >> 5;
 
-  int t = xcd_remap(bid, nblk);
-  const int tm = t % p.tiles_m; t /= p.tiles_m;
-  const int tn = t % p.tiles_n; t /= p.tiles_n;
-  const int sp = t % p.nsplit;
-  const int bz = t / p.nsplit;
+  int tm, tn, sp, bz;
+  tile_coords(p, bid, nblk, tm, tn, sp, bz);
 
   const int m0 = tm * BM, n0 = tn * BN;
   const int kbeg = sp * p.k_per_split;
@@ -767,6 +801,7 @@ struct GemmPlan {
   int bk = 0;                // staged bf16 kernels, 64 x 64 tiles: 32 = half-depth K-tiles (24 KiB of LDS: six workgroups per CU)
   int kg = 1;                // fp32 ring kernel, 64 x 64 tiles: K groups of four waves per workgroup (1, 2 or 4)
   int sq_count = 0;          // sq partial entries per batch this plan produces
+  int tile_order = 0;        // GemmTune::tile_order
   double est_us = 0;
 };
 
@@ -776,6 +811,11 @@ struct GemmTune {            // overrides (0 = automatic), settable from the env
   int persist = -1;          // persistent tile-walking kernel: -1 automatic, 0 never, 1 whenever the GEMM is eligible
   int bk = 0;                // GemmPlan::bk
   int kg = 0;                // GemmPlan::kg (0 = automatic)
+  int tile_order = 0;        // one-tile-per-workgroup kernels: 0 list order (default), 1 XCD-blocked order (GemmP::xb_m) when the
+                             // product has at least three tiles per CU, 2 blocked order for every unsplit, unbatched product (tests).
+                             // Measured on the split-bf16 scoring GEMM (6040 x 3706 x 250): operand fetch 150 -> 51 MB per launch,
+                             // time 93 -> 99 us -- the L2 misses it removes were MALL hits that the kernel was not waiting on, and
+                             // the list order keeps the eight XCDs on the same A rows at the same time.  Kept as an option.
 };
 
 inline void split_plan(int K, int want, int& nsplit, int& kps) {
@@ -843,6 +883,7 @@ inline GemmPlan gemm_plan(int M, int N, int K, int nbatch, bool wants_sq, const 
   // per workgroup that the split-bf16 loop wins on any grid (C4 shard: 955 vs 846 steps/s with every GEMM on it).
   best.mode = tune.mode != MFMA_AUTO ? tune.mode : (wgs >= 2 * GEMM_CUS || gflop >= 6.0 ? MFMA_BF16X3 : MFMA_F32);
   best.bk = tune.bk;
+  best.tile_order = tune.tile_order;
   // K groups: a 64 x 64 workgroup that has its CU to itself (ring 3: 96 KiB) runs 16 waves, four per SIMD (C2 step:
   // 6130 -> 6660 steps/s with two per SIMD, 6760-6830 with four); co-resident ring-2 workgroups already interleave
   best.kg = (best.tile == 64 && best.mode == MFMA_F32 && best.ring <= 3) ? (tune.kg ? tune.kg : (best.ring == 3 ? 4 : 1)) : 1;
@@ -904,8 +945,36 @@ inline hipError_t gemm_dispatch_staged(hipStream_t st, const GemmP& p, bool akm,
 
 inline hipError_t gemm_dispatch_persist(hipStream_t st, const GemmP& p, bool akm, bool bkm, const GemmPlan& pl);
 
-inline hipError_t gemm_dispatch(hipStream_t st, const GemmP& p, bool akm, bool bkm, const GemmPlan& pl) {
-  if (pl.persist) return gemm_dispatch_persist(st, p, akm, bkm, pl);
+// Blocked tile order for a plain product with many tiles (tile_coords): of the four cuts xb_m x xb_n = 8 take the one whose
+// eight L2s fetch the fewest operand bytes, with the rectangle walked in bands whose A rows fit ~1.5 MB of a 4 MB L2; B
+// panels are streamed once per band.
+inline void choose_tile_order(GemmP& p, const GemmPlan& pl) {
+  p.xb_m = p.xb_n = p.xb_band = 0;
+  if (pl.tile_order == 0 || pl.nsplit != 1 || p.nbatch != 1) return;
+  const long long tiles = (long long)pl.tiles_m * pl.tiles_n;
+  if (pl.tile_order == 1 && tiles < 3LL * GEMM_CUS) return;
+  const double tile_bytes = 4.0 * pl.tile * std::max(p.K, 1);
+  const int band = (int)std::max(1.0, std::min(1.5e6 / tile_bytes, 1e6));
+  double best = 1e300;
+  for (int xm = 1; xm <= 8; xm *= 2) {
+    const int xn = 8 / xm;
+    double fetch = 0;
+    for (int i = 0; i < xm; ++i)
+      for (int j = 0; j < xn; ++j) {
+        const int bm = part_begin(pl.tiles_m, xm, i + 1) - part_begin(pl.tiles_m, xm, i);
+        const int bn = part_begin(pl.tiles_n, xn, j + 1) - part_begin(pl.tiles_n, xn, j);
+        const int bands = (bm + band - 1) / std::max(band, 1);
+        fetch += tile_bytes * (bm + (double)bands * bn);
+      }
+    if (fetch < best) { best = fetch; p.xb_m = xm; p.xb_n = xn; }
+  }
+  p.xb_band = band;
+}
+
+inline hipError_t gemm_dispatch(hipStream_t st, const GemmP& p0, bool akm, bool bkm, const GemmPlan& pl) {
+  if (pl.persist) return gemm_dispatch_persist(st, p0, akm, bkm, pl);
+  GemmP p = p0;
+  choose_tile_order(p, pl);
   if (pl.mode == MFMA_BF16 || pl.mode == MFMA_BF16X3 || pl.mode == MFMA_F16) return gemm_dispatch_staged(st, p, akm, bkm, pl);
   if (pl.tile == 128) return pl.ring >= 3 ? gemm_launch_t<128, 128, 32, 3>(st, p, akm, bkm) : gemm_launch_t<128, 128, 32, 2>(st, p, akm, bkm);
   if (pl.kg == 2) return pl.ring == 3 ? gemm_launch_t<64, 64, 64, 3, 2>(st, p, akm, bkm) : gemm_launch_t<64, 64, 64, 2, 2>(st, p, akm, bkm);

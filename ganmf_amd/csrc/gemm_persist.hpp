@@ -40,7 +40,6 @@ struct PersistP {
 __device__ inline float4 lds_read_f4(const float* __restrict__ p) { return *reinterpret_cast<const float4*>(p); }
 
 // tiles [b0, b1) of `n` split into `parts` nearly equal contiguous ranges
-__host__ __device__ inline int part_begin(int n, int parts, int i) { return (int)(((long long)n * i) / parts); }
 
 template <int BM, int BN, int BK, int NS, int WGM, int WGN, bool AKM, bool BKM>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_f32_persist(const GemmP p, const PersistP q) {

@@ -107,3 +107,25 @@ def test_gemm_k_groups(akm, bkm, kg, ring, shape, nsplit, monkeypatch):
     assert np.all(err <= 4e-7 * bound * np.sqrt(K) + 1e-30), float((err / (bound + 1e-30)).max())
     again, _ = gemm_f32(A, B, akm, bkm, tile=64, nsplit=nsplit)
     np.testing.assert_array_equal(out, again)
+
+
+@pytest.mark.parametrize("mfma", ["f32", "bf16x3"])
+@pytest.mark.parametrize("tile", [64, 128])
+@pytest.mark.parametrize("shape", [(1, 1, 1), (700, 900, 250), (129, 4100, 40), (5000, 131, 8), (1300, 1500, 70), (64 * 9, 64 * 7, 3000)])
+def test_gemm_blocked_tile_order(mfma, tile, shape, monkeypatch):
+    """GANMF_TILE_ORDER=2 forces the XCD-blocked block -> tile map (gemm_f32.hpp tile_coords: eight rectangles of the tile
+    grid, banded, M-innermost) on every unsplit product; the map must be a bijection for ragged tile grids (fewer than 8 tiles,
+    rectangles of unequal size, bands taller than a rectangle), so the result equals the list-order launch bit for bit."""
+    from ganmf_amd.engine import gemm_f32
+    M, N, K = shape
+    rng = np.random.RandomState(M + 3 * N + 7 * K)
+    A, B, ref, bound = _mk(rng, M, N, K, False, False)
+    monkeypatch.setenv("GANMF_MFMA", mfma)
+    monkeypatch.setenv("GANMF_PERSIST", "0")
+    monkeypatch.setenv("GANMF_TILE_ORDER", "0")
+    plain, _ = gemm_f32(A, B, False, False, tile=tile, nsplit=1)
+    monkeypatch.setenv("GANMF_TILE_ORDER", "2")
+    out, _ = gemm_f32(A, B, False, False, tile=tile, nsplit=1)
+    np.testing.assert_array_equal(out, plain)
+    err = np.abs(out - ref)
+    assert np.all(err <= 4e-7 * bound * np.sqrt(K) + 1e-30), float((err / (bound + 1e-30)).max())
