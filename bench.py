@@ -251,7 +251,7 @@ def main():
                        "arithmetic": "float32 tensors throughout; GEMM K loops on the fp32 MFMA (16-wave workgroups), except the "
                                      "two fused-Adam weight-gradient GEMMs of the D-step, which run the fp32-accurate split-bf16 "
                                      "loop (3 exact bf16 pieces per operand, 6 piece products, fp32 accumulate)",
-                       "launches": "D-step 7, G-step 11 (generator GEMM + CSR rows, dE + d_coef, gWd + slab sum of dE, gUb + gV share a launch)",
+                       "launches": "D-step 7, G-step 11 (generator GEMM + CSR rows, dE + d_coef, gWd + gWe, gUb + gV share a launch)",
                        "global_steps_per_s": round(done / el, 2), "rows_per_s": round(world * done * w["B"] / el, 1),
                        "parallelism": "dp%d (users sharded row-wise; RCCL reduce-scatter of the D and V gradients, Adam on the rank's "
                                       "slice, all-gather of the parameters)" % world},

@@ -107,7 +107,7 @@ enum Tag : int {
   T_DENSIFY, T_GEMM_GEN, T_RED_GEN, T_GEMM_ENC, T_RED_ENC, T_GEMM_DEC, T_RED_DEC, T_DCOEF, T_GEMM_DE, T_RED_DE,
   T_GEMM_GWD, T_RED_GWD, T_GEMM_GWE, T_RED_GWE, T_ADAM_D, T_GEMM_DF, T_RED_DF, T_GEMM_GUB, T_RED_GUB, T_GEMM_GV,
   T_RED_GV, T_ADAM_V, T_ADAM_U, T_MULTIRED, T_ALLREDUCE, T_SCORE_GEMM, T_RED_SCORE, T_DIS_FWD, T_RED_DIS_FWD, T_DIS_HEAD,
-  T_DIS_GW, T_RED_DIS_GW, T_DIS_BWD, T_RED_DIS_BWD, T_FRONT, T_GWD_RED, T_PAIR, T_DE_DCOEF, T_COUNT
+  T_DIS_GW, T_RED_DIS_GW, T_DIS_BWD, T_RED_DIS_BWD, T_FRONT, T_GWD_RED, T_PAIR, T_DE_DCOEF, T_WPAIR, T_COUNT
 };
 const char* const kTagName[T_COUNT] = {
   "densify_rows+gather", "gemm_generator[B,k]x[N,k]^T", "reduce_generator", "gemm_encode[2B,N]x[N,e]",
@@ -117,7 +117,8 @@ const char* const kTagName[T_COUNT] = {
   "adam_dense_V", "adam_rows_U", "multi_reduce", "rccl_allreduce", "gemm_scores", "reduce_scores",
   "gemm_dis_layer_fwd", "reduce_dis_layer_fwd", "dis_head", "gemm_dis_gW", "reduce_dis_gW", "gemm_dis_bwd",
   "reduce_dis_bwd", "gemm_generator[B,k]x[N,k]^T + CSR rows (one launch)", "gemm_gWd[2B,e]^Tx[2B,N] + reduce_dE (one launch)",
-  "gemm_gUb[B,N]x[N,k] + gemm_gV[B,N]^Tx[B,k] (one launch)", "gemm_dE[2B,N]x[e,N]^T + d_coef (one launch)"};
+  "gemm_gUb[B,N]x[N,k] + gemm_gV[B,N]^Tx[B,k] (one launch)", "gemm_dE[2B,N]x[e,N]^T + d_coef (one launch)",
+  "gemm_gWd[2B,e]^Tx[2B,N] + gemm_gWe[2B,N]^Tx[2B,e] (one launch)"};
 
 struct ProfRec { int tag; hipEvent_t a, b; double flops, bytes; };
 
@@ -204,8 +205,9 @@ struct ganmf_handle {
   bool dis_fused0 = false; // DisGANMF: this step's layer-0 update ran in the epilogue of its gradient GEMM (dis_backprop_hidden)
   int dis_regn0 = 0;       //           and left this many sum(theta^2) partials
   bool defer_gub = true;  // the split-K slabs of gUb are summed by adam_rows_kernel (no reduce launch)
-  int multi = 15;         // combined launches (gemm_multi.hpp), bit 0: generator GEMM + CSR row expansion, bit 1: gUb + gV,
-                          // bit 2: slab sum of dE inside the gWd launch, bit 3 (with bit 2): d_coef inside the dE launch (GANMF_MULTI)
+  int multi = 31;         // combined launches (gemm_multi.hpp), bit 0: generator GEMM + CSR row expansion, bit 1: gUb + gV,
+                          // bit 2: slab sum of dE inside the gWd launch, bit 3 (with bit 2): d_coef inside the dE launch,
+                          // bit 4 (with bit 2): gWd + gWe in one launch behind a stand-alone slab sum of dE (GANMF_MULTI)
   float* V_alt = nullptr; // second parameter buffer of item_embeddings: the fused gV update is written there while gUb
                           // still reads the old V in the same launch; swapped with V.p after the launch
   bool fuse_adam = true;  // single GPU: Adam runs in the epilogue of the weight-gradient GEMMs
@@ -815,8 +817,42 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
       TRY(adam_dense(h, T_ADAM_D, h->Wd, h->Wd.g, aslot, h->cfg.d_reg, regD ? regWd : nullptr, 1, off, slice));
       TRY(all_gather(h, h->Wd.p, h->Wd.cap, 1));
     }
-    if (!dist) TRY(gemm_gWd());
-    {  // gWe_ext = [X;F | 1]^T . dE       -> rows 0..N-1 = gWe, row N = gbe
+    bool wpair = false;
+    if (!dist && fused && (h->multi & 16) && dE_red.part) {
+      // both weight-gradient products in ONE launch (wgrad_pair_kernel); the slab sum of dE, which gWe reads, gets its own
+      // launch in front
+      GemmP g0{}, g1{};
+      g0.A = h->Es; g0.lda = h->lde; g0.B = h->Dl; g0.ldb = h->ldN;
+      g0.C = h->Wd.g; g0.ldc = h->ldN; g0.M = e + 1; g0.N = N; g0.K = 2 * nb; g0.nbatch = 1; g0.zero_page = h->zero_page;
+      g0.a_scale = grad_scale(h, b_global);
+      g0.epi.kind = EPI_ADAM; g0.epi.adam_theta = h->Wd.p; g0.epi.adam_m = h->Wd.m; g0.epi.adam_v = h->Wd.v;
+      g0.epi.adam_alpha = h->scal + aslot; g0.epi.adam_reg = h->cfg.d_reg; g0.epi.sq_partials = regD ? regWd : nullptr;
+      g1.A = h->XF; g1.lda = h->ldN; g1.B = h->dE; g1.ldb = h->lde;
+      g1.C = h->We.g; g1.ldc = h->lde; g1.M = N + 1; g1.N = e; g1.K = 2 * nb; g1.nbatch = 1; g1.zero_page = h->zero_page;
+      g1.b_scale = grad_scale(h, b_global);
+      g1.epi.kind = EPI_ADAM; g1.epi.adam_theta = h->We.p; g1.epi.adam_m = h->We.m; g1.epi.adam_v = h->We.v;
+      g1.epi.adam_alpha = h->scal + aslot; g1.epi.adam_reg = h->cfg.d_reg; g1.epi.sq_partials = regD ? regWe : nullptr;
+      GemmPlan p0 = gemm_plan(g0.M, g0.N, g0.K, 1, regD, ft, true), p1 = gemm_plan(g1.M, g1.N, g1.K, 1, regD, ft, true);
+      auto staged = [](const GemmPlan& pl) { return pl.mode == MFMA_BF16X3 && pl.tile == 64 && pl.bk == 32 && pl.nsplit == 1; };
+      if (staged(p0) && staged(p1)) {
+        {
+          Scope s(h, T_RED_DE, 0, 4.0 * (dE_red.nsplit + 1) * dE_red.M * dE_red.N);
+          GANMF_LAUNCH(splitk_reduce_kernel, dim3(GEMM_RED_GRID, 1), dim3(256), 0, h->st, dE_red);
+          HIP_TRY(hipGetLastError());
+        }
+        fill_plan(g0, p0);
+        fill_plan(g1, p1);
+        regn[1] = p0.sq_count; regn[0] = p1.sq_count;
+        const int n0 = p0.tiles_m * p0.tiles_n, n1 = p1.tiles_m * p1.tiles_n;
+        Scope s(h, T_WPAIR, gemm_flops(g0.M, g0.N, g0.K) + gemm_flops(g1.M, g1.N, g1.K),
+                gemm_bytes(g0.M, g0.N, g0.K) + gemm_bytes(g1.M, g1.N, g1.K) + 24.0 * (h->Wd.count() + h->We.count()));
+        GANMF_LAUNCH(wgrad_pair_kernel, dim3(n0 + n1), dim3(256), 0, h->st, g0, g1);
+        HIP_TRY(hipGetLastError());
+        wpair = true;
+      }
+    }
+    if (!dist && !wpair) TRY(gemm_gWd());
+    if (!wpair) {  // gWe_ext = [X;F | 1]^T . dE       -> rows 0..N-1 = gWe, row N = gbe
       GemmP g{};
       g.A = h->XF; g.lda = h->ldN; g.B = h->dE; g.ldb = h->lde;
       g.C = h->We.g; g.ldc = h->lde; g.M = N + 1; g.N = e; g.K = 2 * nb; g.epi.kind = EPI_STORE;
@@ -1408,7 +1444,7 @@ static int create_impl(const ganmf_cfg* cfg, ganmf_handle* h) {
   HIP_TRY(hipEventCreateWithFlags(&h->ev_mid, hipEventDisableTiming));
   h->fuse_adam = env_int("GANMF_FUSE_ADAM", 1) != 0;
   h->defer_gub = env_int("GANMF_DEFER_GUB", 1) != 0;
-  h->multi = env_int("GANMF_MULTI", 15);
+  h->multi = env_int("GANMF_MULTI", 31);
   h->pair_ring = env_int("GANMF_PAIR_RING", 2) == 3 ? 3 : 2;
   h->inkernel_reduce = env_int("GANMF_INKERNEL_REDUCE", 0) != 0;   // measured slower than the chip-wide reduce kernel
   h->inlaunch_max = env_int("GANMF_INLAUNCH_MAX", 4);

@@ -14,6 +14,9 @@
 //                      the slabs are scaled when they are summed, one launch later                        (GANMF.py:131-132)
 //   gemm_bf16s_red     gWd_ext = Es^T.Delta with the fused Adam epilogue + the slab sum / row scale of dE = rs (.) (Delta.Wd^T),
 //                      which the previous launch left as split-K slabs and only the NEXT launch (gWe) reads (GANMF.py:138)
+//   wgrad_pair_kernel  gWd_ext + gWe_ext, both with the fused Adam epilogue, behind a stand-alone slab sum of dE: 2 088 workgroups
+//                      where the chip holds 1 536, so the K phase of the second round runs under the Adam streams of the
+//                      first (58.5 us as two launches with everything resident and in phase, 48.3 + 4.5 us this way)  (GANMF.py:138)
 // The bodies are the ordinary kernels' bodies (gemm_f32_body, gemm_bf16s_body, splitk_reduce_body): same arithmetic, same
 // summation order, bit-identical results to the separate launches.
 #pragma once
@@ -61,6 +64,17 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16s_red(const GemmP g, const Re
   const int ng = g.tiles_m * g.tiles_n * g.nsplit * g.nbatch;
   if ((int)blockIdx.x < ng) gemm_bf16s_body<64, 64, 32, true, true, 3>(g, (int)blockIdx.x, ng, smem);
   else splitk_reduce_body(r, (int)blockIdx.x - ng, nred, 0, smem);
+}
+
+// blocks [0, n0): g0; blocks [n0, n0 + n1): g1 -- two independent 64 x 64 x 32 TN split-bf16 products with the fused Adam
+// epilogue (gWd_ext and gWe_ext of the discriminator step).  The launch has more workgroups than the chip holds at once, so
+// the K phase of the later workgroups runs under the Adam streams of the earlier ones.
+__global__ __launch_bounds__(256, 2) void wgrad_pair_kernel(const GemmP g0, const GemmP g1) {
+  __shared__ __attribute__((aligned(16))) float smem[Bf16sLds<64, 64, 32, 3>::DW];
+  const int n0 = g0.tiles_m * g0.tiles_n * g0.nsplit * g0.nbatch;
+  const int n1 = g1.tiles_m * g1.tiles_n * g1.nsplit * g1.nbatch;
+  if ((int)blockIdx.x < n0) gemm_bf16s_body<64, 64, 32, true, true, 3>(g0, (int)blockIdx.x, n0, smem);
+  else gemm_bf16s_body<64, 64, 32, true, true, 3>(g1, (int)blockIdx.x - n0, n1, smem);
 }
 
 // ---- host side: can this plan ride in the combined launch?

@@ -2,7 +2,7 @@
 
 A combined launch runs the bodies of the ordinary kernels as block ranges of one grid (generator GEMM + CSR row expansion;
 gUb + gV with the update of V written to a second buffer; the slab sum of dE inside the gWd launch; d_coef inside the dE
-launch; the gUb slabs summed by adam_rows_kernel), so it must reproduce the separate launches BIT FOR BIT: same arithmetic, same summation order.  GANMF_MULTI
+launch; gWd + gWe as block ranges of one grid; the gUb slabs summed by adam_rows_kernel), so it must reproduce the separate launches BIT FOR BIT: same arithmetic, same summation order.  GANMF_MULTI
 / GANMF_DEFER_GUB are read when a handle is created."""
 import numpy as np
 import pytest
@@ -47,7 +47,7 @@ def test_combined_launches_bit_identical(shape, g_reg, monkeypatch):
     U, N, k, e, B = shape
     hp = dict(d_lr=1e-4, g_lr=2e-4, d_reg=1e-4, g_reg=g_reg, m=10.0, recon_coefficient=0.05)
     ref, ref_l = _run(monkeypatch, 0, 0, U, N, k, e, B, hp, epochs=2)
-    for multi, defer in ((15, 1), (1, 0), (2, 1), (4, 0), (12, 0), (7, 1)):
+    for multi, defer in ((31, 1), (15, 1), (1, 0), (2, 1), (4, 0), (12, 0), (7, 1), (20, 0), (28, 1)):
         got, got_l = _run(monkeypatch, multi, defer, U, N, k, e, B, hp, epochs=2)
         for (dl, gl), (dr, gr) in zip(got_l, ref_l):
             np.testing.assert_array_equal(dl, dr, err_msg="D losses, GANMF_MULTI=%d" % multi)

@@ -21,6 +21,9 @@ G_STEP = ["void ganmf::front_kernel<4>(ganmf::GemmP, ganmf::DensP)", F32, "ganmf
 NEW_D_STEP = ["void ganmf::front_kernel<4>(ganmf::GemmP, ganmf::DensP)", F32, "ganmf::splitk_reduce_kernel(ganmf::RedP)", F32,
               "void ganmf::de_dcoef_kernel<4>(ganmf::GemmP, ganmf::DCoefP, int)", "ganmf::gemm_bf16s_red(ganmf::GemmP, ganmf::RedP, int)",
               "void ganmf::gemm_bf16s_mfma<64, 64, 32, true, true, 3, false>(ganmf::GemmP)"]
+WPAIR_D_STEP = ["void ganmf::front_kernel<4>(ganmf::GemmP, ganmf::DensP)", F32, "ganmf::splitk_reduce_kernel(ganmf::RedP)", F32,
+                "void ganmf::de_dcoef_kernel<4>(ganmf::GemmP, ganmf::DCoefP, int)", "ganmf::splitk_reduce_kernel(ganmf::RedP)",
+                "ganmf::wgrad_pair_kernel(ganmf::GemmP, ganmf::GemmP)"]
 OLD_G_STEP = ["ganmf::densify_rows_kernel(ganmf::DensP)", F32, F32, "ganmf::splitk_reduce_kernel(ganmf::RedP)", F32, F32, F32, F32,
               "ganmf::splitk_reduce_kernel(ganmf::RedP)", F32, "ganmf::adam_rows_kernel(float*)"]
 
@@ -46,7 +49,7 @@ def _write(path, steps, counter=None):
 def test_labels_follow_dispatch_order(tmp_path):
     from step_classes import label, load
     p = tmp_path / "trace.csv"
-    _write(p, [D_STEP, G_STEP, D_STEP, OLD_G_STEP, NEW_D_STEP, D_STEP[:4]])      # the last step is truncated and must be dropped
+    _write(p, [D_STEP, G_STEP, D_STEP, OLD_G_STEP, NEW_D_STEP, WPAIR_D_STEP, D_STEP[:4]])      # the last step is truncated and must be dropped
     lab = [k for k, _ in label(load(str(p)))]
     assert lab[:8] == ["D:gen+rows", "D:encode", "D:reduce(encode)", "D:decode", "D:d_coef", "D:dE",
                        "D:gWd+adam+reduce(dE)", "D:gWe+adam"]
@@ -56,7 +59,8 @@ def test_labels_follow_dispatch_order(tmp_path):
     assert old == ["G:densify+gather", "G:gen", "G:encode", "G:reduce(encode)", "G:decode", "G:dE", "G:dF", "G:gUb",
                    "G:reduce(gUb)", "G:gV+adam", "G:adam_rows_U"]
     assert lab[38:45] == ["D:gen+rows", "D:encode", "D:reduce(encode)", "D:decode", "D:dE+d_coef", "D:gWd+adam+reduce(dE)", "D:gWe+adam"]
-    assert len(lab) == 8 + 11 + 8 + 11 + 7
+    assert lab[45:52] == ["D:gen+rows", "D:encode", "D:reduce(encode)", "D:decode", "D:dE+d_coef", "D:reduce(dE)", "D:gWd+gWe+adam"]
+    assert len(lab) == 8 + 11 + 8 + 11 + 7 + 7
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "step_classes.py"), str(p)], capture_output=True, text=True)
     assert out.returncode == 0 and "| D:encode |" in out.stdout and "D+G pair" in out.stdout
 
@@ -64,7 +68,7 @@ def test_labels_follow_dispatch_order(tmp_path):
 def test_traffic_per_class(tmp_path):
     for name, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
         os.makedirs(tmp_path / name / "run")
-        _write(tmp_path / name / "run" / "1_counter_collection.csv", [D_STEP, G_STEP], counter)
+        _write(tmp_path / name / "run" / "1_counter_collection.csv", [D_STEP, G_STEP, WPAIR_D_STEP], counter)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "collect_traffic.py"), str(tmp_path / "fetch"),
                           str(tmp_path / "write")], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
@@ -74,5 +78,6 @@ def test_traffic_per_class(tmp_path):
     assert enc["algorithmic_bytes"] == 4 * (256 * 3707 + 3707 * 992 + 256 * 992)
     gw = d["gemm_gWd[2B,e]^Tx[2B,N] + reduce_dE (D-step)"]
     assert gw["algorithmic_bytes"] >= 24 * 993 * 3706       # the six Adam streams are counted
+    assert d["gemm_gWd[2B,e]^Tx[2B,N] + gemm_gWe[2B,N]^Tx[2B,e] (D-step)"]["algorithmic_bytes"] >= 24 * (993 * 3706 + 3707 * 992)
     assert "gemm_gUb[B,N]x[N,k] + gemm_gV[B,N]^Tx[B,k] (G-step)" in d
     assert len({v["class"] for v in d.values()}) == len(d)      # no entry shared between classes

@@ -26,7 +26,8 @@ TAG = {"gen": "gemm_generator[B,k]x[N,k]^T", "encode": "gemm_encode[2B,N]x[N,e]"
        "dF": "gemm_dF[B,e]x[N,e]^T", "gUb": "gemm_gUb[B,N]x[N,k]", "gV+adam": "gemm_gV[B,N]^Tx[B,k]",
        "densify+gather": "densify_rows+gather", "d_coef": "d_coef+scale", "adam_rows_U": "adam_rows_U",
        "gen+rows": "gemm_generator[B,k]x[N,k]^T + CSR rows", "gUb+gV+adam": "gemm_gUb[B,N]x[N,k] + gemm_gV[B,N]^Tx[B,k]",
-       "gWd+adam+reduce(dE)": "gemm_gWd[2B,e]^Tx[2B,N] + reduce_dE", "dE+d_coef": "gemm_dE[2B,N]x[e,N]^T + d_coef"}
+       "gWd+adam+reduce(dE)": "gemm_gWd[2B,e]^Tx[2B,N] + reduce_dE", "dE+d_coef": "gemm_dE[2B,N]x[e,N]^T + d_coef",
+       "gWd+gWe+adam": "gemm_gWd[2B,e]^Tx[2B,N] + gemm_gWe[2B,N]^Tx[2B,e]"}
 
 
 def algorithmic(cls, B, N, k, e, U):
@@ -37,6 +38,8 @@ def algorithmic(cls, B, N, k, e, U):
     if name == "dE+d_coef": return g(2 * B, e, N) + 8 * 2 * B * e
     if name == "gUb+gV+adam": return g(B, k, N) + 4 * (B * N + B * k) + 24 * N * k
     if name.startswith("gWd+adam+reduce"): return 4 * (2 * B * (e + 1) + 2 * B * N) + 24 * (e + 1) * N + 4 * 2 * B * e
+    if name == "gWd+gWe+adam":
+        return 4 * (2 * B * (e + 1) + 2 * B * N) + 24 * (e + 1) * N + 4 * (2 * B * (N + 1) + 2 * B * e) + 24 * (N + 1) * e
     if name == "encode": return g(2 * B, e, N + 1)
     if name == "decode": return (2 if step == "D" else 1) * (4 * (B * (e + 1) + 2 * B * N)) + 4 * (e + 1) * N   # + the subtracted input
     if name == "dE": return g(2 * B, e, N) if step == "D" else g(B, e, N) + 8 * B * e

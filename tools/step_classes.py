@@ -8,7 +8,7 @@ launches a step in a fixed order (ganmf_hip.hip d_step / g_step):
   D-step: densify, gen, encode[, reduce], decode[, reduce], d_coef, dE[, reduce], gWd+Adam, gWe+Adam
   G-step: densify, gen, encode[, reduce], decode[, reduce], dE[, reduce], dF[, reduce], gUb[, reduce], gV+Adam, adam_rows_U
 with the combined launches of gemm_multi.hpp standing in for their parts: `front_kernel` = densify + gen, `pair_kernel` =
-gUb + gV+Adam, `gemm_bf16s_red` = gWd+Adam + reduce(dE), `de_dcoef_kernel` = dE + d_coef.
+gUb + gV+Adam, `gemm_bf16s_red` = gWd+Adam + reduce(dE), `de_dcoef_kernel` = dE + d_coef, `wgrad_pair_kernel` = gWd+Adam + gWe+Adam.
 
 A step starts at `densify_rows_kernel` / `sparse_front_kernel` / `front_kernel`; it is a D-step when it contains `d_coef_kernel` or `de_dcoef_kernel`.
 
@@ -39,7 +39,7 @@ def load(path):
 
 
 def _gemm_like(n):
-    return "gemm_" in n or "front_kernel" in n or "pair_kernel" in n or "de_dcoef_kernel" in n
+    return "gemm_" in n or "front_kernel" in n or "pair_kernel" in n or "de_dcoef_kernel" in n      # ("wgrad_pair_kernel" contains "pair_kernel")
 
 
 def label(disp):
@@ -64,10 +64,13 @@ def label(disp):
             out.append(("S:scoring 6040x3706x250 (split-bf16)", d))
     for st in steps:
         is_d = any("d_coef_kernel" in d["name"] or "de_dcoef_kernel" in d["name"] for d in st)
-        paired = any("pair_kernel" in d["name"] for d in st)
+        paired = any("pair_kernel" in d["name"] and "wgrad" not in d["name"] for d in st)
+        wpaired = any("wgrad_pair_kernel" in d["name"] for d in st)
         names = list(D_GEMMS if is_d else G_GEMMS)
         if paired:
             names = names[:5] + ["gUb+gV+adam"]
+        if wpaired:
+            names = names[:4] + ["gWd+gWe+adam"]
         gi, last = 0, None
         kind = "D" if is_d else "G"
         if sum(1 for d in st if _gemm_like(d["name"])) != len(names):
