@@ -1094,8 +1094,8 @@ int dis_backprop_hidden(ganmf_handle* h, int row0, int nrows, bool param_grads, 
       // Layer 0 holds nearly all discriminator parameters ([N+2, e]) and nothing reads W_0 after its gradient in this step
       // (the backward GEMMs below use W_l, l > 0): TF-Adam runs in the epilogue of its gradient GEMM, as for GANMF's two
       // tensors -- the gradient is never stored, no adam_dense pass.  Not with a communicator (the gradient must be reduced
-      // first) and not in the low-precision modes (the uid row's gradient comes from the fp32 kernel below).
-      const bool fuse0 = l == 0 && h->fuse_adam && !h->has_comm && !uid_apart;
+      // first).  In the low-precision modes the float(uid) row is left out of the GEMM and updated by the fp32 kernel below.
+      const bool fuse0 = l == 0 && h->fuse_adam && !h->has_comm;
       h->dis_fused0 = false;
       if (fuse0) {
         const bool regD = h->cfg.d_reg != 0.f;
@@ -1113,9 +1113,17 @@ int dis_backprop_hidden(ganmf_handle* h, int row0, int nrows, bool param_grads, 
       } else
       TRY(run_gemm(h, T_DIS_GW, T_RED_DIS_GW, g, true, true));
       if (uid_apart) {
-        GANMF_LAUNCH(dis_uid_grad_kernel, dim3((e + 255) / 256), dim3(256), 0, h->st, h->XF, h->ldN, N + 1, cur, h->lde,
-                           nrows, e, h->Wl[0].g + (size_t)(N + 1) * h->lde);
+        const size_t ro = (size_t)(N + 1) * h->lde;      // the float(uid) row of W_0_ext
+        const int nblk = (e + 63) / 64;
+        const bool apply = h->dis_fused0 && h->dis_regn0 + nblk <= h->reg_cap;
+        if (h->dis_fused0 && !apply) return fail(-1, "dis_backprop_hidden: no room for the uid row's sum(theta^2) partials");
+        const bool regD = h->cfg.d_reg != 0.f;
+        GANMF_LAUNCH(dis_uid_grad_kernel, dim3(nblk), dim3(64 * UIDG_GROUPS), 0, h->st, h->XF, h->ldN, N + 1, cur, h->lde,
+                           nrows, e, h->Wl[0].g + ro, apply ? h->Wl[0].p + ro : nullptr, h->Wl[0].m + ro, h->Wl[0].v + ro,
+                           h->scal, (int)S_ALPHA_D, h->cfg.d_reg,
+                           (apply && regD) ? h->regp + (size_t)4 * h->reg_cap + h->dis_regn0 : nullptr);
         HIP_TRY(hipGetLastError());
+        if (apply && regD) h->dis_regn0 += nblk;
       }
     }
     if (l > 0) {
@@ -1514,7 +1522,7 @@ static int create_impl(const ganmf_cfg* cfg, ganmf_handle* h) {
   {
     auto t64 = [](int a, int b) { return ((a + 63) / 64) * ((b + 63) / 64); };
     h->reg_cap = std::max({ADAM_GRID, (int)GEMM_RED_GRID, t64(N + 2, e), t64(e + 1, N), t64(N, k), t64(B, N), t64(B, e)});
-    h->reg_cap = round_up(h->reg_cap, 64);
+    h->reg_cap = round_up(h->reg_cap + (e + 63) / 64, 64);      // + the float(uid) row's partials (dis_uid_grad_kernel)
   }
   TRY(dalloc(&h->regp, (size_t)(4 + 17 + 1) * h->reg_cap));
   const float pw[4] = {ADAM_B1, ADAM_B2, ADAM_B1, ADAM_B2};

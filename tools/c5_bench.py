@@ -1,5 +1,6 @@
 """Steps/s of BASELINE configs[4] -- DisGANMF on ML-1M shape (6040 x 3706, k=250, d_nodes=1024, one linear layer, B=128) -- in the
-three arithmetic modes: fp32-accurate (default), fp16 MFMA as the config is written, bf16 MFMA.  Usage: python tools/c5_bench.py"""
+three arithmetic modes: fp32-accurate (default), fp16 MFMA as the config is written, bf16 MFMA.
+Usage: python tools/c5_bench.py [--mode auto,f16,bf16] [--layers L] [--act linear|tanh|relu|sigmoid] [--profile | --profile-all]"""
 import os
 import sys
 import time
@@ -22,7 +23,8 @@ IDS = {"U": 100, "V": 101, "Wo": 2 * LAYERS, "bo": 2 * LAYERS + 1}
 for _l in range(LAYERS):
     IDS["W%d" % _l], IDS["b%d" % _l] = 2 * _l, 2 * _l + 1
 perm = np.random.RandomState(0).permutation(U)[:B * 47]
-for mfma in (None, "f16", "bf16"):
+MODES = [None if m == "auto" else m for m in sys.argv[sys.argv.index("--mode") + 1].split(",")] if "--mode" in sys.argv else [None, "f16", "bf16"]
+for mfma in MODES:
     eng = Engine(U, N, k, e, B, model=L.MODEL_DISGANMF, d_layers=LAYERS, d_act=ACT, m=0.0, mfma=mfma, **hp)
     eng.set_urm(urm)
     for n, tid in IDS.items():
@@ -35,8 +37,8 @@ for mfma in (None, "f16", "bf16"):
         best = min(best, time.perf_counter() - t0)
     print("C5 DisGANMF mfma=%-5s: %7.0f steps/s (%.1f us/step)" % (mfma or "auto", 94 / best, best / 94 * 1e6))
     eng.close()
-    if mfma is None and "--profile" in sys.argv:
-        eng2 = Engine(U, N, k, e, B, model=L.MODEL_DISGANMF, d_layers=LAYERS, d_act=ACT, m=0.0, **hp)
+    if (mfma is None and "--profile" in sys.argv) or "--profile-all" in sys.argv:
+        eng2 = Engine(U, N, k, e, B, model=L.MODEL_DISGANMF, d_layers=LAYERS, d_act=ACT, m=0.0, mfma=mfma, **hp)
         eng2.set_urm(urm)
         for n, tid in IDS.items():
             eng2.set_tensor(tid, o.p[n])
