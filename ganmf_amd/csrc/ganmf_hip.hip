@@ -988,7 +988,7 @@ int gen_update(ganmf_handle* h, int nb, int start, int b_global, int* regn_v, fl
   {
     Scope s(h, T_ADAM_U, 0, 24.0 * h->Ue.count());
     GANMF_LAUNCH(adam_rows_kernel, dim3(ADAM_GRID), dim3(256), 0, h->st, h->Ue.p, h->Ue.m, h->Ue.v, gub.p,
-                       gub.nsplit, gub.split_stride, h->pos, start, nb, h->U, h->ldk, h->scal, S_ALPHA_G, h->cfg.g_reg,
+                       gub.nsplit, gub.split_stride, reduce_groups((long long)nb * ((k + 3) >> 2), gub.nsplit), h->pos, start, nb, h->U, h->ldk, h->scal, S_ALPHA_G, h->cfg.g_reg,
                        reg ? reg_u : nullptr);
     HIP_TRY(hipGetLastError());
   }

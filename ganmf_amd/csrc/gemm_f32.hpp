@@ -739,7 +739,17 @@ struct RedP {
   EpiD epi;
 };
 
-// (bx of nbx blocks of 256 threads walk the elements of batch bz; `red` = 4 floats of LDS)
+// Slab groups of the reduce: a small output behind a deep split (the reference's defaults on LastFM: 64 x 32 outputs, K = 17 632,
+// 250 slabs) leaves two workgroups summing 250 slabs one after the other (9.4 us).  Then G threads share an output element:
+// thread group g sums slabs g, g + G, ... and the G partial sums meet in LDS, added in group order.  G depends on the shape
+// only (never on the grid), so every launch that carries this reduce forms the same sums.
+__host__ __device__ inline int reduce_groups(long long total4, int nsplit) {
+  if (nsplit >= 64 && total4 <= 8192) return 16;
+  if (nsplit >= 16 && total4 <= 32768) return 4;
+  return 1;
+}
+
+// (bx of nbx blocks of NT threads walk the elements of batch bz; `red` = 4 + 4 * NT floats of LDS)
 template <int NT = 256>
 __device__ __forceinline__ void splitk_reduce_body(const RedP& p, const int bx, const int nbx, const int bz, float* __restrict__ red) {
   const int n4 = (p.N + 3) >> 2;
@@ -749,15 +759,7 @@ __device__ __forceinline__ void splitk_reduce_body(const RedP& p, const int bx, 
   const EpiD& e = p.epi;
   const float* __restrict__ aux = e.aux ? e.aux + (size_t)bz * e.aux_batch_stride : nullptr;
   float sq = 0.f;
-  for (long long idx = (long long)bx * NT + threadIdx.x; idx < total; idx += (long long)nbx * NT) {
-    const int m = (int)(idx / n4), c = (int)(idx % n4) * 4;
-    const size_t off = (size_t)m * p.ld + c;
-    float4 s = *reinterpret_cast<const float4*>(part + off);
-#pragma unroll 8
-    for (int k = 1; k < p.nsplit; ++k) {   // independent loads: keep several slabs in flight
-      const float4 q = *reinterpret_cast<const float4*>(part + (size_t)k * p.split_stride + off);
-      s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
-    }
+  auto finish = [&](float4 s, int m, int c, size_t off) {
     float o[4] = {s.x, s.y, s.z, s.w};
     if (c + 3 < p.N) {
 #pragma unroll
@@ -765,6 +767,47 @@ __device__ __forceinline__ void splitk_reduce_body(const RedP& p, const int bx, 
       *reinterpret_cast<float4*>(out + off) = make_float4(o[0], o[1], o[2], o[3]);
     } else {
       for (int j = 0; j < 4 && c + j < p.N; ++j) out[off + j] = epi_apply(e, o[j], m, c + j, p.ld, aux, sq);
+    }
+  };
+  const int G = reduce_groups(total, p.nsplit);
+  if (G > 1) {
+    float4* const meet = reinterpret_cast<float4*>(red + 4);      // [G][NT / G]
+    const int epb = NT / G, g = threadIdx.x / epb, el = threadIdx.x % epb;
+    for (long long base = (long long)bx * epb; base < total; base += (long long)nbx * epb) {      // uniform per workgroup
+      const long long idx = base + el;
+      const bool live = idx < total;
+      const int m = live ? (int)(idx / n4) : 0, c = live ? (int)(idx % n4) * 4 : 0;
+      const size_t off = (size_t)m * p.ld + c;
+      float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (live) {
+#pragma unroll 8
+        for (int k = g; k < p.nsplit; k += G) {
+          const float4 q = *reinterpret_cast<const float4*>(part + (size_t)k * p.split_stride + off);
+          s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
+        }
+      }
+      meet[threadIdx.x] = s;
+      __syncthreads();
+      if (g == 0 && live) {
+        for (int q = 1; q < G; ++q) {
+          const float4 t = meet[q * epb + el];
+          s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+        }
+        finish(s, m, c, off);
+      }
+      __syncthreads();
+    }
+  } else {
+    for (long long idx = (long long)bx * NT + threadIdx.x; idx < total; idx += (long long)nbx * NT) {
+      const int m = (int)(idx / n4), c = (int)(idx % n4) * 4;
+      const size_t off = (size_t)m * p.ld + c;
+      float4 s = *reinterpret_cast<const float4*>(part + off);
+#pragma unroll 8
+      for (int k = 1; k < p.nsplit; ++k) {   // independent loads: keep several slabs in flight
+        const float4 q = *reinterpret_cast<const float4*>(part + (size_t)k * p.split_stride + off);
+        s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
+      }
+      finish(s, m, c, off);
     }
   }
   if (e.sq_partials) {
@@ -782,7 +825,7 @@ __device__ __forceinline__ void splitk_reduce_body(const RedP& p, const int bx, 
 }
 
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const RedP p) {
-  __shared__ float red[4];
+  __shared__ __attribute__((aligned(16))) float red[4 + 4 * 256];
   splitk_reduce_body(p, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y, red);
 }
 

@@ -129,3 +129,21 @@ def test_gemm_blocked_tile_order(mfma, tile, shape, monkeypatch):
     np.testing.assert_array_equal(out, plain)
     err = np.abs(out - ref)
     assert np.all(err <= 4e-7 * bound * np.sqrt(K) + 1e-30), float((err / (bound + 1e-30)).max())
+
+
+@pytest.mark.parametrize("akm,bkm", LAYOUTS)
+@pytest.mark.parametrize("shape,nsplit", [((64, 32, 17633), 0), ((64, 32, 17633), 250), ((33, 10, 9000), 100), ((200, 130, 5000), 20),
+                                           ((256, 250, 3706), 29)])
+def test_gemm_deep_split_small_output(akm, bkm, shape, nsplit):
+    """Deep split-K behind a small output (LastFM at the reference's defaults: 64 x 32, K = 17 632): the slab sum runs with 4 or
+    16 threads per output element (gemm_f32.hpp reduce_groups), partial sums added in group order -- fp32 bound and run-to-run
+    identical, ragged column tails included."""
+    from ganmf_amd.engine import gemm_f32
+    M, N, K = shape
+    rng = np.random.RandomState(M + 3 * N + 7 * K + nsplit)
+    A, B, ref, bound = _mk(rng, M, N, K, akm, bkm)
+    out, _ = gemm_f32(A, B, akm, bkm, tile=64, nsplit=nsplit)
+    err = np.abs(out - ref)
+    assert np.all(err <= 4e-7 * bound * np.sqrt(K) + 1e-30), float((err / (bound + 1e-30)).max())
+    again, _ = gemm_f32(A, B, akm, bkm, tile=64, nsplit=nsplit)
+    np.testing.assert_array_equal(out, again)
