@@ -118,7 +118,7 @@ const char* const kTagName[T_COUNT] = {
   "gemm_dis_layer_fwd", "reduce_dis_layer_fwd", "dis_head", "gemm_dis_gW", "reduce_dis_gW", "gemm_dis_bwd",
   "reduce_dis_bwd", "gemm_generator[B,k]x[N,k]^T + CSR rows (one launch)", "gemm_gWd[2B,e]^Tx[2B,N] + reduce_dE (one launch)",
   "gemm_gUb[B,N]x[N,k] + gemm_gV[B,N]^Tx[B,k] (one launch)", "gemm_dE[2B,N]x[e,N]^T + d_coef (one launch)",
-  "gemm_gWd[2B,e]^Tx[2B,N] + gemm_gWe[2B,N]^Tx[2B,e] (one launch)"};
+  "gemm_gWd + gemm_gWe, fused Adam (one launch)"};
 
 struct ProfRec { int tag; hipEvent_t a, b; double flops, bytes; };
 
@@ -469,7 +469,9 @@ int run_gemm(ganmf_handle* h, int tag_gemm, int tag_red, GemmP g, bool akm, bool
   GemmPlan pl = gemm_plan(g.M, g.N, g.K, g.nbatch, g.epi.sq_partials != nullptr, tn, g.epi.kind == EPI_ADAM);
   pl.persist = gemm_persist_eligible(g, akm, bkm, pl, tn.persist) ? (tn.persist >= 2 ? tn.persist : 1) : 0;
   if (defer) *defer = SlabRef{g.C, 1, 0};
-  const bool deferred = defer && pl.nsplit > 1 && g.epi.kind == EPI_STORE && g.nbatch == 1;
+  // (a deep split behind a small output is summed 16 threads per element by the reduce kernel: not left to the consumer)
+  const bool deferred = defer && pl.nsplit > 1 && g.epi.kind == EPI_STORE && g.nbatch == 1 &&
+                        reduce_groups((long long)g.M * ((g.N + 3) >> 2), pl.nsplit) == 1;
   const int slab_lane = deferred ? 1 : lane;
   if (pl.nsplit > 1) TRY(ensure_slab(h, gemm_slab_elems(pl, g.M, g.ldc, g.nbatch), slab_lane));
   float* slab = slab_lane ? h->slab2 : h->slab;
@@ -845,7 +847,8 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
         regn[1] = p0.sq_count; regn[0] = p1.sq_count;
         const int n0 = p0.tiles_m * p0.tiles_n, n1 = p1.tiles_m * p1.tiles_n;
         Scope s(h, T_WPAIR, gemm_flops(g0.M, g0.N, g0.K) + gemm_flops(g1.M, g1.N, g1.K),
-                gemm_bytes(g0.M, g0.N, g0.K) + gemm_bytes(g1.M, g1.N, g1.K) + 24.0 * (h->Wd.count() + h->We.count()));
+                // operands once + the six Adam streams; the gradients themselves never reach HBM
+                4.0 * ((double)g0.K * (g0.M + g0.N) + (double)g1.K * (g1.M + g1.N)) + 24.0 * ((double)g0.M * g0.N + (double)g1.M * g1.N));
         GANMF_LAUNCH(wgrad_pair_kernel, dim3(n0 + n1), dim3(256), 0, h->st, g0, g1);
         HIP_TRY(hipGetLastError());
         wpair = true;
@@ -956,7 +959,8 @@ int gen_update(ganmf_handle* h, int nb, int start, int b_global, int* regn_v, fl
       g1.epi.sq_partials = reg ? reg_v : nullptr;
       GemmPlan p0 = gemm_plan(g0.M, g0.N, g0.K, 1, false, h->tune);
       GemmPlan p1 = gemm_plan(g1.M, g1.N, g1.K, 1, g1.epi.sq_partials != nullptr, h->tune, true);
-      if (plan_is_f32_64_kg(p0, 4) && plan_is_f32_64_kg(p1, 4) && p1.nsplit == 1) {
+      if (plan_is_f32_64_kg(p0, 4) && plan_is_f32_64_kg(p1, 4) && p1.nsplit == 1 &&
+          reduce_groups((long long)g0.M * ((g0.N + 3) >> 2), p0.nsplit) == 1) {
         if (p0.nsplit > 1) {
           TRY(ensure_slab(h, gemm_slab_elems(p0, g0.M, g0.ldc, 1), 1));
           g0.C = h->slab2; g0.c_split_stride = (long long)g0.M * g0.ldc;
@@ -988,7 +992,7 @@ int gen_update(ganmf_handle* h, int nb, int start, int b_global, int* regn_v, fl
   {
     Scope s(h, T_ADAM_U, 0, 24.0 * h->Ue.count());
     GANMF_LAUNCH(adam_rows_kernel, dim3(ADAM_GRID), dim3(256), 0, h->st, h->Ue.p, h->Ue.m, h->Ue.v, gub.p,
-                       gub.nsplit, gub.split_stride, reduce_groups((long long)nb * ((k + 3) >> 2), gub.nsplit), h->pos, start, nb, h->U, h->ldk, h->scal, S_ALPHA_G, h->cfg.g_reg,
+                       gub.nsplit, gub.split_stride, h->pos, start, nb, h->U, h->ldk, h->scal, S_ALPHA_G, h->cfg.g_reg,
                        reg ? reg_u : nullptr);
     HIP_TRY(hipGetLastError());
   }

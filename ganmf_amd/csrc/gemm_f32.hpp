@@ -740,13 +740,11 @@ struct RedP {
 };
 
 // Slab groups of the reduce: a small output behind a deep split (the reference's defaults on LastFM: 64 x 32 outputs, K = 17 632,
-// 250 slabs) leaves two workgroups summing 250 slabs one after the other (9.4 us).  Then G threads share an output element:
+// 250 slabs) leaves two workgroups summing 250 slabs one after the other (9.4 us).  Then G = 16 threads share an output element:
 // thread group g sums slabs g, g + G, ... and the G partial sums meet in LDS, added in group order.  G depends on the shape
 // only (never on the grid), so every launch that carries this reduce forms the same sums.
 __host__ __device__ inline int reduce_groups(long long total4, int nsplit) {
-  if (nsplit >= 64 && total4 <= 8192) return 16;
-  if (nsplit >= 16 && total4 <= 32768) return 4;
-  return 1;
+  return (nsplit >= 64 && total4 <= 8192) ? 16 : 1;      // (shallower splits finish inside the launch floor anyway)
 }
 
 // (bx of nbx blocks of NT threads walk the elements of batch bz; `red` = 4 + 4 * NT floats of LDS)

@@ -336,11 +336,11 @@ __global__ __launch_bounds__(256) void adam_dense_kernel(float* __restrict__ th,
 //   m = m*b1 + g'(1-b1) ; v = v*b2 + g'^2(1-b2) ; theta -= alpha*m/(sqrt(v)+eps)
 // pos[r] = position of row r in this epoch's permutation (-1 if absent); batch = [start, start+nb).
 // The batch gradient arrives as gsplit split-K slabs of the gUb GEMM (slab s at gb + s * gstride), summed here in split
-// order -- exactly what splitk_reduce_kernel would have written (ggroups = its reduce_groups: same association), without its
-// launch.
+// order -- exactly what splitk_reduce_kernel would have written, without its launch (only splits that kernel sums one thread
+// per element, reduce_groups == 1: a deep split behind this small output keeps its reduce launch).
 __global__ __launch_bounds__(256) void adam_rows_kernel(float* __restrict__ th, float* __restrict__ mo,
                                                         float* __restrict__ vo, const float* __restrict__ gb,
-                                                        int gsplit, long long gstride, int ggroups,
+                                                        int gsplit, long long gstride,
                                                         const int* __restrict__ pos, int start, int nb,
                                                         int nrows, int ld, const float* __restrict__ scal,
                                                         int alpha_idx, float reg, float* __restrict__ sq_partials) {
@@ -356,24 +356,11 @@ __global__ __launch_bounds__(256) void adam_rows_kernel(float* __restrict__ th, 
     float4 gg = make_float4(0.f, 0.f, 0.f, 0.f);
     if (slot >= 0 && slot < nb) {
       const float* gp0 = gb + (size_t)slot * ld + 4 * c;
-      if (ggroups <= 1) {
-        gg = *reinterpret_cast<const float4*>(gp0);
+      gg = *reinterpret_cast<const float4*>(gp0);
 #pragma unroll 8
-        for (int sp = 1; sp < gsplit; ++sp) {   // independent loads: several slabs in flight
-          const float4 q = *reinterpret_cast<const float4*>(gp0 + (size_t)sp * gstride);
-          gg.x += q.x; gg.y += q.y; gg.z += q.z; gg.w += q.w;
-        }
-      } else {      // the association of the grouped slab sum (gemm_f32.hpp reduce_groups): group sums, added in group order
-        for (int g = 0; g < ggroups; ++g) {
-          float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 4
-          for (int sp = g; sp < gsplit; sp += ggroups) {
-            const float4 q = *reinterpret_cast<const float4*>(gp0 + (size_t)sp * gstride);
-            s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
-          }
-          if (g == 0) gg = s;
-          else { gg.x += s.x; gg.y += s.y; gg.z += s.z; gg.w += s.w; }
-        }
+      for (int sp = 1; sp < gsplit; ++sp) {   // independent loads: several slabs in flight
+        const float4 q = *reinterpret_cast<const float4*>(gp0 + (size_t)sp * gstride);
+        gg.x += q.x; gg.y += q.y; gg.z += q.z; gg.w += q.w;
       }
     }
     float4 t = reinterpret_cast<float4*>(th)[i];

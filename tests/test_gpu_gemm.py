@@ -135,7 +135,7 @@ def test_gemm_blocked_tile_order(mfma, tile, shape, monkeypatch):
 @pytest.mark.parametrize("shape,nsplit", [((64, 32, 17633), 0), ((64, 32, 17633), 250), ((33, 10, 9000), 100), ((200, 130, 5000), 20),
                                            ((256, 250, 3706), 29)])
 def test_gemm_deep_split_small_output(akm, bkm, shape, nsplit):
-    """Deep split-K behind a small output (LastFM at the reference's defaults: 64 x 32, K = 17 632): the slab sum runs with 4 or
+    """Deep split-K behind a small output (LastFM at the reference's defaults: 64 x 32, K = 17 632): the slab sum runs with
     16 threads per output element (gemm_f32.hpp reduce_groups), partial sums added in group order -- fp32 bound and run-to-run
     identical, ragged column tails included."""
     from ganmf_amd.engine import gemm_f32

@@ -78,6 +78,6 @@ def test_traffic_per_class(tmp_path):
     assert enc["algorithmic_bytes"] == 4 * (256 * 3707 + 3707 * 992 + 256 * 992)
     gw = d["gemm_gWd[2B,e]^Tx[2B,N] + reduce_dE (D-step)"]
     assert gw["algorithmic_bytes"] >= 24 * 993 * 3706       # the six Adam streams are counted
-    assert d["gemm_gWd[2B,e]^Tx[2B,N] + gemm_gWe[2B,N]^Tx[2B,e] (D-step)"]["algorithmic_bytes"] >= 24 * (993 * 3706 + 3707 * 992)
+    assert d["gemm_gWd + gemm_gWe, fused Adam (D-step)"]["algorithmic_bytes"] >= 24 * (993 * 3706 + 3707 * 992)
     assert "gemm_gUb[B,N]x[N,k] + gemm_gV[B,N]^Tx[B,k] (G-step)" in d
     assert len({v["class"] for v in d.values()}) == len(d)      # no entry shared between classes

@@ -27,7 +27,7 @@ TAG = {"gen": "gemm_generator[B,k]x[N,k]^T", "encode": "gemm_encode[2B,N]x[N,e]"
        "densify+gather": "densify_rows+gather", "d_coef": "d_coef+scale", "adam_rows_U": "adam_rows_U",
        "gen+rows": "gemm_generator[B,k]x[N,k]^T + CSR rows", "gUb+gV+adam": "gemm_gUb[B,N]x[N,k] + gemm_gV[B,N]^Tx[B,k]",
        "gWd+adam+reduce(dE)": "gemm_gWd[2B,e]^Tx[2B,N] + reduce_dE", "dE+d_coef": "gemm_dE[2B,N]x[e,N]^T + d_coef",
-       "gWd+gWe+adam": "gemm_gWd[2B,e]^Tx[2B,N] + gemm_gWe[2B,N]^Tx[2B,e]"}
+       "gWd+gWe+adam": "gemm_gWd + gemm_gWe, fused Adam"}
 
 
 def algorithmic(cls, B, N, k, e, U):
