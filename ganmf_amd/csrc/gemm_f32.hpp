@@ -402,6 +402,10 @@ __device__ inline void tile_coords(const GemmP& p, int bid, int nblk, int& tm, i
   bz = t / p.nsplit;
 }
 
+#ifndef GANMF_ADAM_HOIST
+#define GANMF_ADAM_HOIST 1
+#endif
+
 // ---- epilogue shared by every GEMM kernel.  C/D layout of the 32x32 MFMA: col = lane & 31,
 // row = (reg&3) + 8*(reg>>2) + 4*(lane>>5), i.e. a lane owns a column.  `smem` must hold BM*BN floats and be idle.
 struct TileCoord { int tm, tn, sp, bz, m0, n0; };
@@ -448,6 +452,56 @@ __device__ inline void gemm_epilogue(const GemmP& p, const f32x16 (&acc)[TM][TN]
   const bool publish = deferred && p.counters != nullptr;
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   const __amdgpu_buffer_rsrc_t slab_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)C, (short)0, 0x7fffffff, 0x00020000);
+  if (adam && GANMF_ADAM_HOIST) {
+    // The tile is a gradient: parameter and moments are updated in place, the gradient is never stored.  theta / m / v of up to
+    // four row steps are fetched BEFORE the first of them is written back: written as one loop the stores of step j and the
+    // loads of step j + 1 go through the same pointers, so the compiler keeps them in order and the row pass becomes four
+    // dependent load -> update -> store rounds of HBM latency each.
+    constexpr int J = BM / RPP, JC = J < 4 ? J : 4;
+    static_assert(J % JC == 0, "row steps in whole chunks");
+    for (int j0 = 0; j0 < J; j0 += JC) {
+      float4 t4[JC], m4[JC], v4[JC];
+#pragma unroll
+      for (int jj = 0; jj < JC; ++jj) {
+        const int row = m0 + tr + (j0 + jj) * RPP;
+        if (row < p.M && col + 3 < p.N) {
+          const size_t off = (size_t)row * p.ldc + col;
+          t4[jj] = *reinterpret_cast<const float4*>(e.adam_theta + off);
+          m4[jj] = *reinterpret_cast<const float4*>(e.adam_m + off);
+          v4[jj] = *reinterpret_cast<const float4*>(e.adam_v + off);
+        }
+      }
+#pragma unroll
+      for (int jj = 0; jj < JC; ++jj) {
+        const int row_l = tr + (j0 + jj) * RPP, row = m0 + row_l;
+        if (row < p.M && col < p.N) {
+          float4 v = *reinterpret_cast<const float4*>(ct + row_l * BN + tc * 4);
+#pragma unroll
+          for (int g = 1; g < KG; ++g) {
+            const float4 w = *reinterpret_cast<const float4*>(ct + g * (BM * BN) + row_l * BN + tc * 4);
+            v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+          }
+          const size_t off = (size_t)row * p.ldc + col;
+          if (col + 3 < p.N) {
+            adam_update(v.x, alpha, e.adam_reg, t4[jj].x, m4[jj].x, v4[jj].x, sq);
+            adam_update(v.y, alpha, e.adam_reg, t4[jj].y, m4[jj].y, v4[jj].y, sq);
+            adam_update(v.z, alpha, e.adam_reg, t4[jj].z, m4[jj].z, v4[jj].z, sq);
+            adam_update(v.w, alpha, e.adam_reg, t4[jj].w, m4[jj].w, v4[jj].w, sq);
+            *reinterpret_cast<float4*>(theta_out + off) = t4[jj];
+            *reinterpret_cast<float4*>(e.adam_m + off) = m4[jj];
+            *reinterpret_cast<float4*>(e.adam_v + off) = v4[jj];
+          } else {
+            const float o[4] = {v.x, v.y, v.z, v.w};
+            for (int q = 0; q < 4 && col + q < p.N; ++q) {
+              float th = e.adam_theta[off + q];
+              adam_update(o[q], alpha, e.adam_reg, th, e.adam_m[off + q], e.adam_v[off + q], sq);
+              theta_out[off + q] = th;
+            }
+          }
+        }
+      }
+    }
+  } else
 #pragma unroll 4
   for (int j = 0; j < BM / RPP; ++j) {
     const int row_l = tr + j * RPP, row = m0 + row_l;
