@@ -232,7 +232,7 @@ def main():
                 roofline["traffic_source"] = os.path.basename(tf)
                 roofline["algorithmic_bytes_per_launch"] = best["algorithmic_bytes"]
             if roofline_fused:
-                fc = [v for k, v in json.load(open(tf)).items() if any(k.startswith(p["name"]) for p in fused)]
+                fc = [v for k, v in json.load(open(tf)).items() if any(k.startswith(p["name"].replace(" (one launch)", "")) for p in fused)]
                 if fc:
                     roofline_fused["traffic"] = sum(v["hbm_bytes_per_launch"] for v in fc)
                     roofline_fused["traffic_source"] = os.path.basename(tf)
