@@ -398,7 +398,8 @@ __global__ __launch_bounds__(256) void dis_head_kernel(const float* __restrict__
   if (r >= row0 + nrows) return;
   const int lane = threadIdx.x & 63;
   float s = 0.f;
-  for (int j = lane; j < e1; j += 64) s += feat[(size_t)r * ld + j] * wo[j];
+#pragma unroll 8
+  for (int j = lane; j < e1; j += 64) s += feat[(size_t)r * ld + j] * wo[j];      // (loads of eight rounds in flight)
   s = wave_sum(s);
   if (lane == 0) {
     const float z = r < n_real ? 1.f : 0.f;
