@@ -202,8 +202,8 @@ struct ganmf_handle {
   float* regp = nullptr;  // [slots][reg_cap] block partials of sum(theta^2): We_ext, Wd_ext, U, V, (DisGANMF layers)
   int reg_cap = 0;
   int pair_ring = 2;      // LDS ring depth of the gUb + gV launch (GANMF_PAIR_RING)
-  bool dis_fused0 = false; // DisGANMF: this step's layer-0 update ran in the epilogue of its gradient GEMM (dis_backprop_hidden)
-  int dis_regn0 = 0;       //           and left this many sum(theta^2) partials
+  std::vector<char> dis_fused;  // DisGANMF, per layer: this step's update ran in the epilogue of its gradient GEMM (dis_backprop_hidden)
+  std::vector<int> dis_regn;    //           and left this many sum(theta^2) partials
   bool defer_gub = true;  // the split-K slabs of gUb are summed by adam_rows_kernel (no reduce launch)
   int multi = 31;         // combined launches (gemm_multi.hpp), bit 0: generator GEMM + CSR row expansion, bit 1: gUb + gV,
                           // bit 2: slab sum of dE inside the gWd launch, bit 3 (with bit 2): d_coef inside the dE launch,
@@ -211,6 +211,7 @@ struct ganmf_handle {
   float* V_alt = nullptr; // second parameter buffer of item_embeddings: the fused gV update is written there while gUb
                           // still reads the old V in the same launch; swapped with V.p after the launch
   bool fuse_adam = true;  // single GPU: Adam runs in the epilogue of the weight-gradient GEMMs
+  bool dis_fuse_hidden = true;   // DisGANMF: also for the hidden layers l > 0 (GANMF_DIS_FUSE_HIDDEN)
   float *d_parts = nullptr, *g_parts = nullptr;  // [cap][4]
   float* colbuf = nullptr;                       // [cap] one column of d_parts on its way through an all-reduce
   float *d_arena = nullptr, *g_arena = nullptr;  // [cap][4][reg_cap] per-step block partials (GANMF), reduced once per epoch
@@ -1085,6 +1086,15 @@ int dis_backprop_hidden(ganmf_handle* h, int row0, int nrows, bool param_grads, 
   const int N = h->N, e = h->e;
   float* cur = h->dz0;   // dz_{L-1} was written here by dis_dz_top_kernel
   float* nxt = h->dz1;
+  auto backward = [&](int l) -> int {      // dz_{l-1} = (dz_l . W_l[0:e]^T) * act'(a_{l-1}): cur -> nxt
+    GemmP g{};
+    g.A = cur + (size_t)row0 * h->lde; g.lda = h->lde; g.B = h->Wl[l].p; g.ldb = h->lde;
+    g.C = nxt + (size_t)row0 * h->lde; g.ldc = h->lde; g.M = nrows; g.N = e; g.K = e;
+    g.epi.kind = EPI_MUL_ACTGRAD; g.epi.act = h->act;
+    g.epi.aux = h->Al[l - 1] + (size_t)row0 * h->lde; g.epi.ldaux = h->lde;
+    g.a_scale = gsc;
+    return run_gemm(h, T_DIS_BWD, T_RED_DIS_BWD, g, false, false);
+  };
   for (int l = h->L - 1; l >= 0; --l) {
     if (param_grads) {  // gW_l_ext = [a_{l-1} | 1 (| uid)]^T . dz_l  (all 2B rows: row0 = 0)
       GemmP g{};
@@ -1095,49 +1105,46 @@ int dis_backprop_hidden(ganmf_handle* h, int row0, int nrows, bool param_grads, 
       g.b_scale = gsc;
       const bool uid_apart = l == 0 && low_precision(h);
       if (uid_apart) g.M = N + 1;      // the float(uid) row of W_0_ext gets its gradient from the fp32 reduction below
-      // Layer 0 holds nearly all discriminator parameters ([N+2, e]) and nothing reads W_0 after its gradient in this step
-      // (the backward GEMMs below use W_l, l > 0): TF-Adam runs in the epilogue of its gradient GEMM, as for GANMF's two
-      // tensors -- the gradient is never stored, no adam_dense pass.  Not with a communicator (the gradient must be reduced
-      // first).  In the low-precision modes the float(uid) row is left out of the GEMM and updated by the fp32 kernel below.
-      const bool fuse0 = l == 0 && h->fuse_adam && !h->has_comm;
-      h->dis_fused0 = false;
-      if (fuse0) {
+      // TF-Adam runs in the epilogue of the gradient GEMM, as for GANMF's two tensors -- the gradient is never stored, no
+      // adam_dense pass.  Layer 0 holds nearly all discriminator parameters ([N+2, e]) and nothing reads W_0 after its gradient
+      // in this step; a hidden layer's W_l is read once more, by the backward product dz_{l-1} = dz_l . W_l^T, which therefore
+      // goes FIRST (below).  Not with a communicator (the gradient must be reduced first).  In the low-precision modes the
+      // float(uid) row of layer 0 is left out of the GEMM and updated by the fp32 kernel below.
+      const bool fuse = h->fuse_adam && !h->has_comm && (l == 0 || h->dis_fuse_hidden);
+      h->dis_fused[l] = 0;
+      if (l > 0 && fuse) TRY(backward(l));
+      if (fuse) {
         const bool regD = h->cfg.d_reg != 0.f;
-        g.epi.kind = EPI_ADAM; g.epi.adam_theta = h->Wl[0].p; g.epi.adam_m = h->Wl[0].m; g.epi.adam_v = h->Wl[0].v;
+        g.epi.kind = EPI_ADAM; g.epi.adam_theta = h->Wl[l].p; g.epi.adam_m = h->Wl[l].m; g.epi.adam_v = h->Wl[l].v;
         g.epi.adam_alpha = h->scal + S_ALPHA_D; g.epi.adam_reg = h->cfg.d_reg;
-        g.epi.sq_partials = regD ? h->regp + (size_t)4 * h->reg_cap : nullptr;
+        g.epi.sq_partials = regD ? h->regp + (size_t)(4 + l) * h->reg_cap : nullptr;
         GemmTune ft;
         ft.tile = 64; ft.ring = 2; ft.nsplit = 1;
         ft.mode = h->tune.mode != MFMA_AUTO ? h->tune.mode : h->fused_mode;
         ft.bk = h->fused_bk;
-        int regn0 = ADAM_GRID;
-        TRY(run_gemm(h, T_DIS_GW, T_RED_DIS_GW, g, true, true, &regn0, 24.0 * h->Wl[0].count(), 0, &ft));
-        h->dis_fused0 = true;
-        h->dis_regn0 = regn0;
+        int regn = ADAM_GRID;
+        TRY(run_gemm(h, T_DIS_GW, T_RED_DIS_GW, g, true, true, &regn, 24.0 * h->Wl[l].count(), 0, &ft));
+        h->dis_fused[l] = 1;
+        h->dis_regn[l] = regn;
+        if (l > 0) { std::swap(cur, nxt); continue; }      // (the backward product of this layer is done)
       } else
       TRY(run_gemm(h, T_DIS_GW, T_RED_DIS_GW, g, true, true));
       if (uid_apart) {
         const size_t ro = (size_t)(N + 1) * h->lde;      // the float(uid) row of W_0_ext
         const int nblk = (e + 63) / 64;
-        const bool apply = h->dis_fused0 && h->dis_regn0 + nblk <= h->reg_cap;
-        if (h->dis_fused0 && !apply) return fail(-1, "dis_backprop_hidden: no room for the uid row's sum(theta^2) partials");
+        const bool apply = h->dis_fused[0] && h->dis_regn[0] + nblk <= h->reg_cap;
+        if (h->dis_fused[0] && !apply) return fail(-1, "dis_backprop_hidden: no room for the uid row's sum(theta^2) partials");
         const bool regD = h->cfg.d_reg != 0.f;
         GANMF_LAUNCH(dis_uid_grad_kernel, dim3(nblk), dim3(64 * UIDG_GROUPS), 0, h->st, h->XF, h->ldN, N + 1, cur, h->lde,
                            nrows, e, h->Wl[0].g + ro, apply ? h->Wl[0].p + ro : nullptr, h->Wl[0].m + ro, h->Wl[0].v + ro,
                            h->scal, (int)S_ALPHA_D, h->cfg.d_reg,
-                           (apply && regD) ? h->regp + (size_t)4 * h->reg_cap + h->dis_regn0 : nullptr);
+                           (apply && regD) ? h->regp + (size_t)4 * h->reg_cap + h->dis_regn[0] : nullptr);
         HIP_TRY(hipGetLastError());
-        if (apply && regD) h->dis_regn0 += nblk;
+        if (apply && regD) h->dis_regn[0] += nblk;
       }
     }
     if (l > 0) {
-      GemmP g{};
-      g.A = cur + (size_t)row0 * h->lde; g.lda = h->lde; g.B = h->Wl[l].p; g.ldb = h->lde;
-      g.C = nxt + (size_t)row0 * h->lde; g.ldc = h->lde; g.M = nrows; g.N = e; g.K = e;
-      g.epi.kind = EPI_MUL_ACTGRAD; g.epi.act = h->act;
-      g.epi.aux = h->Al[l - 1] + (size_t)row0 * h->lde; g.epi.ldaux = h->lde;
-      g.a_scale = gsc;
-      TRY(run_gemm(h, T_DIS_BWD, T_RED_DIS_BWD, g, false, false));
+      TRY(backward(l));
       std::swap(cur, nxt);
     }
   }
@@ -1174,7 +1181,7 @@ int dis_d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float
     TRY(dp_update(h, T_ADAM_D, h->Wo, S_ALPHA_D, h->cfg.d_reg, reg ? h->regp + (4 + h->L) * h->reg_cap : nullptr, 0));
   } else {
     for (int l = 0; l < h->L; ++l) {
-      if (l == 0 && nb > 0 && h->dis_fused0) continue;      // updated in the epilogue of its gradient GEMM
+      if (nb > 0 && h->dis_fused[l]) continue;      // updated in the epilogue of its gradient GEMM
       TRY(adam_dense(h, T_ADAM_D, h->Wl[l], h->Wl[l].g, S_ALPHA_D, h->cfg.d_reg, reg ? h->regp + (4 + l) * h->reg_cap : nullptr));
     }
     TRY(adam_dense(h, T_ADAM_D, h->Wo, h->Wo.g, S_ALPHA_D, h->cfg.d_reg, reg ? h->regp + (4 + h->L) * h->reg_cap : nullptr));
@@ -1188,7 +1195,7 @@ int dis_d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float
     int first = 0;      // reg partials of the L + 1 tensors chain into parts[2]; as many as fit ride in the first launch
     if (reg)
       for (; first <= h->L && mr.count < MULTIRED_MAX; ++first)
-        mr.e[mr.count++] = {h->regp + (4 + first) * h->reg_cap, (first == 0 && nb > 0 && h->dis_fused0) ? h->dis_regn0 : ADAM_GRID, 2,
+        mr.e[mr.count++] = {h->regp + (4 + first) * h->reg_cap, (first < h->L && nb > 0 && h->dis_fused[first]) ? h->dis_regn[first] : ADAM_GRID, 2,
                             first ? 1 : 0};
     Scope s(h, T_MULTIRED, 0, 0);
     GANMF_LAUNCH(multi_reduce_kernel, dim3(3), dim3(256), 0, h->st, mr);
@@ -1197,7 +1204,8 @@ int dis_d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float
         MultiRed m2{};
         m2.out = parts;
         m2.count = std::min(MULTIRED_MAX, h->L + 1 - i);
-        for (int j = 0; j < m2.count; ++j) m2.e[j] = {h->regp + (4 + i + j) * h->reg_cap, ADAM_GRID, 2, 1};
+        for (int j = 0; j < m2.count; ++j)
+          m2.e[j] = {h->regp + (4 + i + j) * h->reg_cap, (i + j < h->L && nb > 0 && h->dis_fused[i + j]) ? h->dis_regn[i + j] : ADAM_GRID, 2, 1};
         GANMF_LAUNCH(multi_reduce_kernel, dim3(3), dim3(256), 0, h->st, m2);
       }
     }
@@ -1457,6 +1465,7 @@ static int create_impl(const ganmf_cfg* cfg, ganmf_handle* h) {
   h->fuse_adam = env_int("GANMF_FUSE_ADAM", 1) != 0;
   h->defer_gub = env_int("GANMF_DEFER_GUB", 1) != 0;
   h->multi = env_int("GANMF_MULTI", 31);
+  h->dis_fuse_hidden = env_int("GANMF_DIS_FUSE_HIDDEN", 1) != 0;
   h->pair_ring = env_int("GANMF_PAIR_RING", 2) == 3 ? 3 : 2;
   h->inkernel_reduce = env_int("GANMF_INKERNEL_REDUCE", 0) != 0;   // measured slower than the chip-wide reduce kernel
   h->inlaunch_max = env_int("GANMF_INLAUNCH_MAX", 4);
@@ -1479,6 +1488,8 @@ static int create_impl(const ganmf_cfg* cfg, ganmf_handle* h) {
   } else {
     h->L = cfg->d_layers; h->act = cfg->d_act;
     h->Wl.resize(h->L);
+    h->dis_fused.assign(h->L, 0);
+    h->dis_regn.assign(h->L, ADAM_GRID);
     h->gD_elems = 0;
     for (int l = 0; l < h->L; ++l) {
       TRY(alloc_tensor(h->Wl[l], l == 0 ? N + 2 : e + 1, e, false, world));
