@@ -1155,6 +1155,7 @@ int dis_backprop_hidden(ganmf_handle* h, int row0, int nrows, bool param_grads, 
 int dis_d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* parts) {
   const int e = h->e;
   const float inv_b = 1.0f / (float)b_global;
+  const bool fuse_wo = h->fuse_adam && !h->has_comm && h->dis_fuse_hidden;      // output layer updated by the kernel that forms its gradient
   if (nb > 0) {
     TRY(dis_forward(h, rows_dev, nb, 0));
     float* feat = h->Al[h->L - 1];
@@ -1163,7 +1164,9 @@ int dis_d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float
       GANMF_LAUNCH(dis_head_kernel, dim3((2 * nb + 3) / 4), dim3(256), 0, h->st, feat, h->lde, e + 1,
                          h->Wo.p, 0, 2 * nb, nb, inv_b, h->dlogit, h->lossrow);
       GANMF_LAUNCH(dis_dz_top_kernel, dim3(dis_dz_top_blocks(e)), dim3(DZ_COLS * DZ_GROUPS), 0, h->st, feat, h->lde, e,
-                         h->Wo.p, h->dlogit, 0, 2 * nb, 0, 0.f, h->act, h->dz0, h->Wo.g, (float*)nullptr);
+                         h->Wo.p, h->dlogit, 0, 2 * nb, 0, 0.f, h->act, h->dz0, h->Wo.g, (float*)nullptr,
+                         fuse_wo ? h->Wo.p : nullptr, h->Wo.m, h->Wo.v, h->scal, (int)S_ALPHA_D, h->cfg.d_reg,
+                         (fuse_wo && h->cfg.d_reg != 0.f) ? h->regp + (size_t)(4 + h->L) * h->reg_cap : nullptr);
       HIP_TRY(hipGetLastError());
     }
     float* dz0;
@@ -1184,7 +1187,8 @@ int dis_d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float
       if (nb > 0 && h->dis_fused[l]) continue;      // updated in the epilogue of its gradient GEMM
       TRY(adam_dense(h, T_ADAM_D, h->Wl[l], h->Wl[l].g, S_ALPHA_D, h->cfg.d_reg, reg ? h->regp + (4 + l) * h->reg_cap : nullptr));
     }
-    TRY(adam_dense(h, T_ADAM_D, h->Wo, h->Wo.g, S_ALPHA_D, h->cfg.d_reg, reg ? h->regp + (4 + h->L) * h->reg_cap : nullptr));
+    if (!(nb > 0 && fuse_wo))      // (else: updated by dis_dz_top_kernel, which forms its gradient)
+      TRY(adam_dense(h, T_ADAM_D, h->Wo, h->Wo.g, S_ALPHA_D, h->cfg.d_reg, reg ? h->regp + (4 + h->L) * h->reg_cap : nullptr));
   }
   {  // parts = {sum sce(real), sum sce(fake), sum theta_D^2}
     MultiRed mr{};
@@ -1192,11 +1196,15 @@ int dis_d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float
     mr.e[0] = {h->lossrow, nb, 0, 0};
     mr.e[1] = {h->lossrow + nb, nb, 1, 0};
     mr.count = 2;
+    auto regn_of = [&](int t) -> int {      // sum(theta^2) partials tensor t (L = the output layer) left in its segment
+      if (nb <= 0) return ADAM_GRID;
+      if (t < h->L) return h->dis_fused[t] ? h->dis_regn[t] : ADAM_GRID;
+      return fuse_wo ? dis_dz_top_blocks(e) : ADAM_GRID;
+    };
     int first = 0;      // reg partials of the L + 1 tensors chain into parts[2]; as many as fit ride in the first launch
     if (reg)
       for (; first <= h->L && mr.count < MULTIRED_MAX; ++first)
-        mr.e[mr.count++] = {h->regp + (4 + first) * h->reg_cap, (first < h->L && nb > 0 && h->dis_fused[first]) ? h->dis_regn[first] : ADAM_GRID, 2,
-                            first ? 1 : 0};
+        mr.e[mr.count++] = {h->regp + (4 + first) * h->reg_cap, regn_of(first), 2, first ? 1 : 0};
     Scope s(h, T_MULTIRED, 0, 0);
     GANMF_LAUNCH(multi_reduce_kernel, dim3(3), dim3(256), 0, h->st, mr);
     if (reg) {
@@ -1205,7 +1213,7 @@ int dis_d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float
         m2.out = parts;
         m2.count = std::min(MULTIRED_MAX, h->L + 1 - i);
         for (int j = 0; j < m2.count; ++j)
-          m2.e[j] = {h->regp + (4 + i + j) * h->reg_cap, (i + j < h->L && nb > 0 && h->dis_fused[i + j]) ? h->dis_regn[i + j] : ADAM_GRID, 2, 1};
+          m2.e[j] = {h->regp + (4 + i + j) * h->reg_cap, regn_of(i + j), 2, 1};
         GANMF_LAUNCH(multi_reduce_kernel, dim3(3), dim3(256), 0, h->st, m2);
       }
     }
@@ -1229,7 +1237,8 @@ int dis_g_step(ganmf_handle* h, const int* rows_dev, int nb, int start, int b_gl
                          nb, nb, nb, inv_b, h->dlogit, h->lossrow);
       fmn = dis_dz_top_blocks(e);
       GANMF_LAUNCH(dis_dz_top_kernel, dim3(fmn), dim3(DZ_COLS * DZ_GROUPS), 0, h->st, feat, h->lde, e, h->Wo.p, h->dlogit,
-                         nb, nb, nb, fmc, h->act, h->dz0, (float*)nullptr, h->fmp);
+                         nb, nb, nb, fmc, h->act, h->dz0, (float*)nullptr, h->fmp, (float*)nullptr, (float*)nullptr, (float*)nullptr,
+                         h->scal, 0, 0.f, (float*)nullptr);
       HIP_TRY(hipGetLastError());
     }
     float* dz0;

@@ -422,10 +422,15 @@ constexpr int DZ_COLS = 16, DZ_GROUPS = 64;
 inline int dis_dz_top_blocks(int e) { return (e + 1 + DZ_COLS - 1) / DZ_COLS; }
 
 __global__ __launch_bounds__(DZ_COLS * DZ_GROUPS) void dis_dz_top_kernel(const float* __restrict__ feat, int ld, int e,
-                                                                          const float* __restrict__ wo,
+                                                                          const float* wo /* may alias th */,
                                                                           const float* __restrict__ dlogit, int row0, int nrows,
                                                                           int pair_off, float fmc, int act, float* __restrict__ dz,
-                                                                          float* __restrict__ gwo, float* __restrict__ fm_partials) {
+                                                                          float* __restrict__ gwo, float* __restrict__ fm_partials,
+                                                                          float* th, float* __restrict__ mo,
+                                                                          float* __restrict__ vo, const float* __restrict__ scal,
+                                                                          int alpha_idx, float reg, float* __restrict__ sq_partials) {
+  // th != nullptr (D-step, single GPU): gwo is not stored -- TF-Adam on the output layer's column right here (this block is the
+  // only reader of wo[c], and the logits were formed by the previous kernel); sum(theta_old^2) of the block -> sq_partials[block]
   __shared__ float red[DZ_GROUPS][DZ_COLS];
   const int cl = threadIdx.x % DZ_COLS, g = threadIdx.x / DZ_COLS;
   const int c = blockIdx.x * DZ_COLS + cl;
@@ -449,11 +454,27 @@ __global__ __launch_bounds__(DZ_COLS * DZ_GROUPS) void dis_dz_top_kernel(const f
   }
   red[g][cl] = acc;
   __syncthreads();
-  if (g == 0 && c <= e && gwo) {
+  float sqv = 0.f;
+  if (g == 0 && c <= e && (gwo || th)) {
     float t = red[0][cl];
 #pragma unroll 8
     for (int q = 1; q < DZ_GROUPS; ++q) t += red[q][cl];
-    gwo[c] = t;
+    if (th) {
+      const float x = th[c];
+      sqv = x * x;
+      const float gr = t + reg * x;
+      float mm = mo[c], vv = vo[c];
+      mm += (gr - mm) * (1.f - ADAM_B1);
+      vv += (gr * gr - vv) * (1.f - ADAM_B2);
+      mo[c] = mm; vo[c] = vv;
+      th[c] = x - (mm * scal[alpha_idx]) / (sqrtf(vv) + ADAM_EPS);
+    } else {
+      gwo[c] = t;
+    }
+  }
+  if (th && sq_partials && threadIdx.x < 64) {
+    sqv = wave_sum(sqv);
+    if (threadIdx.x == 0) sq_partials[blockIdx.x] = sqv;
   }
   if (fm_partials) {
     __syncthreads();
