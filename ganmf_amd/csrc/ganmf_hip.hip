@@ -91,7 +91,6 @@ int env_mfma_mode(int dflt) {
 }
 
 constexpr int ADAM_GRID = 1024;
-constexpr int RED_GRID = GEMM_RED_GRID;
 constexpr int COUNTER_CAP = 1 << 16;
 
 struct Tensor {
@@ -167,7 +166,7 @@ struct ganmf_handle {
   std::vector<Tensor> Wl;   // l = 0: [N+2, e] rows 0..N-1 profile weights, row N bias, row N+1 the float(uid) weight; l > 0: [e+1, e]
   Tensor Wo;                // [1, e+1]: output kernel (e) then output bias
   std::vector<float*> Al;   // layer outputs [2B, lde] with the ones column at e
-  float *dz0 = nullptr, *dz1 = nullptr, *dlogit = nullptr, *lossrow = nullptr;
+  float *dz0 = nullptr, *dz1 = nullptr, *dlogit = nullptr;
   Tensor We, Wd, Ue, V;   // We = We_ext [N+1, e] (row N = encoder bias), Wd = Wd_ext [e+1, N] (row e = decoder bias)
   float* gD = nullptr;  // contiguous [gWe_ext | gWd_ext] (one all-reduce)
   size_t gD_elems = 0;
@@ -198,10 +197,10 @@ struct ganmf_handle {
   float* scal = nullptr;
   float *sqp = nullptr;  // [2][max_tiles]
   int sqp_stride = 0;
-  float* fmp = nullptr;   // [RED_GRID]
-  float* regp = nullptr;  // [slots][reg_cap] block partials of sum(theta^2): We_ext, Wd_ext, U, V, (DisGANMF layers)
   int reg_cap = 0;
   int pair_ring = 2;      // LDS ring depth of the gUb + gV launch (GANMF_PAIR_RING)
+  int dis_cap = 0;              // DisGANMF: floats per segment of a step's arena slot (5 + L segments, finish_dis_parts_kernel)
+  float* dis_slot = nullptr;    //           slot of the step in flight
   std::vector<char> dis_fused;  // DisGANMF, per layer: this step's update ran in the epilogue of its gradient GEMM (dis_backprop_hidden)
   std::vector<int> dis_regn;    //           and left this many sum(theta^2) partials
   bool defer_gub = true;  // the split-K slabs of gUb are summed by adam_rows_kernel (no reduce launch)
@@ -1117,7 +1116,7 @@ int dis_backprop_hidden(ganmf_handle* h, int row0, int nrows, bool param_grads, 
         const bool regD = h->cfg.d_reg != 0.f;
         g.epi.kind = EPI_ADAM; g.epi.adam_theta = h->Wl[l].p; g.epi.adam_m = h->Wl[l].m; g.epi.adam_v = h->Wl[l].v;
         g.epi.adam_alpha = h->scal + S_ALPHA_D; g.epi.adam_reg = h->cfg.d_reg;
-        g.epi.sq_partials = regD ? h->regp + (size_t)(4 + l) * h->reg_cap : nullptr;
+        g.epi.sq_partials = regD ? h->dis_slot + (size_t)(4 + l) * h->dis_cap : nullptr;
         GemmTune ft;
         ft.tile = 64; ft.ring = 2; ft.nsplit = 1;
         ft.mode = h->tune.mode != MFMA_AUTO ? h->tune.mode : h->fused_mode;
@@ -1132,13 +1131,13 @@ int dis_backprop_hidden(ganmf_handle* h, int row0, int nrows, bool param_grads, 
       if (uid_apart) {
         const size_t ro = (size_t)(N + 1) * h->lde;      // the float(uid) row of W_0_ext
         const int nblk = (e + 63) / 64;
-        const bool apply = h->dis_fused[0] && h->dis_regn[0] + nblk <= h->reg_cap;
+        const bool apply = h->dis_fused[0] && h->dis_regn[0] + nblk <= h->dis_cap;
         if (h->dis_fused[0] && !apply) return fail(-1, "dis_backprop_hidden: no room for the uid row's sum(theta^2) partials");
         const bool regD = h->cfg.d_reg != 0.f;
         GANMF_LAUNCH(dis_uid_grad_kernel, dim3(nblk), dim3(64 * UIDG_GROUPS), 0, h->st, h->XF, h->ldN, N + 1, cur, h->lde,
                            nrows, e, h->Wl[0].g + ro, apply ? h->Wl[0].p + ro : nullptr, h->Wl[0].m + ro, h->Wl[0].v + ro,
                            h->scal, (int)S_ALPHA_D, h->cfg.d_reg,
-                           (apply && regD) ? h->regp + (size_t)4 * h->reg_cap + h->dis_regn[0] : nullptr);
+                           (apply && regD) ? h->dis_slot + (size_t)4 * h->dis_cap + h->dis_regn[0] : nullptr);
         HIP_TRY(hipGetLastError());
         if (apply && regD) h->dis_regn[0] += nblk;
       }
@@ -1162,11 +1161,11 @@ int dis_d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float
     {
       Scope s(h, T_DIS_HEAD, 0, 4.0 * 2 * nb * e * 3);
       GANMF_LAUNCH(dis_head_kernel, dim3((2 * nb + 3) / 4), dim3(256), 0, h->st, feat, h->lde, e + 1,
-                         h->Wo.p, 0, 2 * nb, nb, inv_b, h->dlogit, h->lossrow);
+                         h->Wo.p, 0, 2 * nb, nb, inv_b, h->dlogit, h->dis_slot, h->dis_slot + h->dis_cap);
       GANMF_LAUNCH(dis_dz_top_kernel, dim3(dis_dz_top_blocks(e)), dim3(DZ_COLS * DZ_GROUPS), 0, h->st, feat, h->lde, e,
                          h->Wo.p, h->dlogit, 0, 2 * nb, 0, 0.f, h->act, h->dz0, h->Wo.g, (float*)nullptr,
                          fuse_wo ? h->Wo.p : nullptr, h->Wo.m, h->Wo.v, h->scal, (int)S_ALPHA_D, h->cfg.d_reg,
-                         (fuse_wo && h->cfg.d_reg != 0.f) ? h->regp + (size_t)(4 + h->L) * h->reg_cap : nullptr);
+                         (fuse_wo && h->cfg.d_reg != 0.f) ? h->dis_slot + (size_t)(4 + h->L) * h->dis_cap : nullptr);
       HIP_TRY(hipGetLastError());
     }
     float* dz0;
@@ -1175,50 +1174,22 @@ int dis_d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float
     GANMF_LAUNCH(open_step_kernel, dim3(1), dim3(64), 0, h->st, h->scal, 0, S_ALPHA_D, h->cfg.d_lr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemsetAsync(h->gD, 0, h->gD_elems * sizeof(float), h->st));
-    HIP_TRY(hipMemsetAsync(h->lossrow, 0, (size_t)2 * h->B * sizeof(float), h->st));
   }
   const bool reg = h->cfg.d_reg != 0.f;
   if (h->has_comm) {
     for (int l = 0; l < h->L; ++l)
-      TRY(dp_update(h, T_ADAM_D, h->Wl[l], S_ALPHA_D, h->cfg.d_reg, reg ? h->regp + (4 + l) * h->reg_cap : nullptr, 0));
-    TRY(dp_update(h, T_ADAM_D, h->Wo, S_ALPHA_D, h->cfg.d_reg, reg ? h->regp + (4 + h->L) * h->reg_cap : nullptr, 0));
+      TRY(dp_update(h, T_ADAM_D, h->Wl[l], S_ALPHA_D, h->cfg.d_reg, reg ? h->dis_slot + (size_t)(4 + l) * h->dis_cap : nullptr, 0));
+    TRY(dp_update(h, T_ADAM_D, h->Wo, S_ALPHA_D, h->cfg.d_reg, reg ? h->dis_slot + (size_t)(4 + h->L) * h->dis_cap : nullptr, 0));
   } else {
     for (int l = 0; l < h->L; ++l) {
       if (nb > 0 && h->dis_fused[l]) continue;      // updated in the epilogue of its gradient GEMM
-      TRY(adam_dense(h, T_ADAM_D, h->Wl[l], h->Wl[l].g, S_ALPHA_D, h->cfg.d_reg, reg ? h->regp + (4 + l) * h->reg_cap : nullptr));
+      TRY(adam_dense(h, T_ADAM_D, h->Wl[l], h->Wl[l].g, S_ALPHA_D, h->cfg.d_reg, reg ? h->dis_slot + (size_t)(4 + l) * h->dis_cap : nullptr));
     }
     if (!(nb > 0 && fuse_wo))      // (else: updated by dis_dz_top_kernel, which forms its gradient)
-      TRY(adam_dense(h, T_ADAM_D, h->Wo, h->Wo.g, S_ALPHA_D, h->cfg.d_reg, reg ? h->regp + (4 + h->L) * h->reg_cap : nullptr));
+      TRY(adam_dense(h, T_ADAM_D, h->Wo, h->Wo.g, S_ALPHA_D, h->cfg.d_reg, reg ? h->dis_slot + (size_t)(4 + h->L) * h->dis_cap : nullptr));
   }
-  {  // parts = {sum sce(real), sum sce(fake), sum theta_D^2}
-    MultiRed mr{};
-    mr.out = parts;
-    mr.e[0] = {h->lossrow, nb, 0, 0};
-    mr.e[1] = {h->lossrow + nb, nb, 1, 0};
-    mr.count = 2;
-    auto regn_of = [&](int t) -> int {      // sum(theta^2) partials tensor t (L = the output layer) left in its segment
-      if (nb <= 0) return ADAM_GRID;
-      if (t < h->L) return h->dis_fused[t] ? h->dis_regn[t] : ADAM_GRID;
-      return fuse_wo ? dis_dz_top_blocks(e) : ADAM_GRID;
-    };
-    int first = 0;      // reg partials of the L + 1 tensors chain into parts[2]; as many as fit ride in the first launch
-    if (reg)
-      for (; first <= h->L && mr.count < MULTIRED_MAX; ++first)
-        mr.e[mr.count++] = {h->regp + (4 + first) * h->reg_cap, regn_of(first), 2, first ? 1 : 0};
-    Scope s(h, T_MULTIRED, 0, 0);
-    GANMF_LAUNCH(multi_reduce_kernel, dim3(3), dim3(256), 0, h->st, mr);
-    if (reg) {
-      for (int i = first; i <= h->L; i += MULTIRED_MAX) {
-        MultiRed m2{};
-        m2.out = parts;
-        m2.count = std::min(MULTIRED_MAX, h->L + 1 - i);
-        for (int j = 0; j < m2.count; ++j)
-          m2.e[j] = {h->regp + (4 + i + j) * h->reg_cap, regn_of(i + j), 2, 1};
-        GANMF_LAUNCH(multi_reduce_kernel, dim3(3), dim3(256), 0, h->st, m2);
-      }
-    }
-    HIP_TRY(hipGetLastError());
-  }
+  // parts = {sum sce(real), sum sce(fake), sum theta_D^2}: summed from the slot once per epoch (arenas_finish)
+  (void)parts; (void)reg;
   return 0;
 }
 
@@ -1234,10 +1205,10 @@ int dis_g_step(ganmf_handle* h, const int* rows_dev, int nb, int start, int b_gl
     {  // generator loss = loss_fake + alpha * FM  (DisGANMF.py:135-136): generated rows only, label 0
       Scope s(h, T_DIS_HEAD, 0, 4.0 * 2 * nb * e * 3);
       GANMF_LAUNCH(dis_head_kernel, dim3((nb + 3) / 4), dim3(256), 0, h->st, feat, h->lde, e + 1, h->Wo.p,
-                         nb, nb, nb, inv_b, h->dlogit, h->lossrow);
+                         nb, nb, nb, inv_b, h->dlogit, (float*)nullptr, h->dis_slot);      // generated rows only -> seg 0
       fmn = dis_dz_top_blocks(e);
       GANMF_LAUNCH(dis_dz_top_kernel, dim3(fmn), dim3(DZ_COLS * DZ_GROUPS), 0, h->st, feat, h->lde, e, h->Wo.p, h->dlogit,
-                         nb, nb, nb, fmc, h->act, h->dz0, (float*)nullptr, h->fmp, (float*)nullptr, (float*)nullptr, (float*)nullptr,
+                         nb, nb, nb, fmc, h->act, h->dz0, (float*)nullptr, h->dis_slot + h->dis_cap, (float*)nullptr, (float*)nullptr, (float*)nullptr,
                          h->scal, 0, 0.f, (float*)nullptr);
       HIP_TRY(hipGetLastError());
     }
@@ -1256,49 +1227,48 @@ int dis_g_step(ganmf_handle* h, const int* rows_dev, int nb, int start, int b_gl
   }
   const bool reg = h->cfg.g_reg != 0.f;
   int regn_v = ADAM_GRID;
-  TRY(gen_update(h, nb, start, b_global, &regn_v, h->regp + 2 * h->reg_cap, h->regp + 3 * h->reg_cap));
-  {  // parts = {sum sce(fake), sum (feat_f - feat_r)^2, sum U^2, sum V^2}
-    MultiRed mr{};
-    mr.out = parts;
-    mr.e[0] = {h->lossrow + nb, nb, 0, 0};
-    mr.e[1] = {h->fmp, fmn, 1, 0};
-    mr.count = 2;
-    if (reg) {
-      mr.e[2] = {h->regp + 2 * h->reg_cap, ADAM_GRID, 2, 0};
-      mr.e[3] = {h->regp + 3 * h->reg_cap, regn_v, 3, 0};
-      mr.count = 4;
-    }
-    Scope s(h, T_MULTIRED, 0, 0);
-    GANMF_LAUNCH(multi_reduce_kernel, dim3(4), dim3(256), 0, h->st, mr);
-    HIP_TRY(hipGetLastError());
-  }
+  TRY(gen_update(h, nb, start, b_global, &regn_v, h->dis_slot + (size_t)2 * h->dis_cap, h->dis_slot + (size_t)3 * h->dis_cap));
+  // parts = {sum sce(fake), sum (feat_f - feat_r)^2, sum U^2, sum V^2}: summed from the slot once per epoch (arenas_finish)
+  (void)parts; (void)reg; (void)fmn;
   return 0;
 }
 
 // model dispatch
+inline size_t arena_stride(const ganmf_handle* h) {      // floats per step: GANMF 4 segments of reg_cap, DisGANMF 5 + L of dis_cap
+  return h->cfg.model == GANMF_MODEL_GANMF ? (size_t)4 * h->reg_cap : (size_t)(5 + h->L) * h->dis_cap;
+}
 int any_d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, int64_t idx) {
   float* parts = h->d_parts + 4 * idx;
-  return h->cfg.model == GANMF_MODEL_GANMF ? d_step(h, rows_dev, nb, b_global, parts, h->d_arena + (size_t)idx * 4 * h->reg_cap)
-                                           : dis_d_step(h, rows_dev, nb, b_global, parts);
+  float* slot = h->d_arena + (size_t)idx * arena_stride(h);
+  if (h->cfg.model == GANMF_MODEL_GANMF) return d_step(h, rows_dev, nb, b_global, parts, slot);
+  h->dis_slot = slot;
+  return dis_d_step(h, rows_dev, nb, b_global, parts);
 }
 int any_g_step(ganmf_handle* h, const int* rows_dev, int nb, int start, int b_global, int64_t idx) {
   float* parts = h->g_parts + 4 * idx;
-  return h->cfg.model == GANMF_MODEL_GANMF ? g_step(h, rows_dev, nb, start, b_global, parts, h->g_arena + (size_t)idx * 4 * h->reg_cap)
-                                           : dis_g_step(h, rows_dev, nb, start, b_global, parts);
+  float* slot = h->g_arena + (size_t)idx * arena_stride(h);
+  if (h->cfg.model == GANMF_MODEL_GANMF) return g_step(h, rows_dev, nb, start, b_global, parts, slot);
+  h->dis_slot = slot;
+  return dis_g_step(h, rows_dev, nb, start, b_global, parts);
 }
 
 // zero the per-step arenas before a pass / reduce them into the loss parts after it (GANMF)
 int arenas_begin(ganmf_handle* h, int64_t nd, int64_t ng) {
-  if (h->cfg.model != GANMF_MODEL_GANMF) return 0;
-  if (nd > 0) HIP_TRY(hipMemsetAsync(h->d_arena, 0, (size_t)nd * 4 * h->reg_cap * sizeof(float), h->st));
-  if (ng > 0) HIP_TRY(hipMemsetAsync(h->g_arena, 0, (size_t)ng * 4 * h->reg_cap * sizeof(float), h->st));
+  const size_t stride = arena_stride(h);
+  if (nd > 0) HIP_TRY(hipMemsetAsync(h->d_arena, 0, (size_t)nd * stride * sizeof(float), h->st));
+  if (ng > 0) HIP_TRY(hipMemsetAsync(h->g_arena, 0, (size_t)ng * stride * sizeof(float), h->st));
   return 0;
 }
 int arenas_finish(ganmf_handle* h, int64_t nd, int64_t ng) {
-  if (h->cfg.model != GANMF_MODEL_GANMF) return 0;
-  Scope s(h, T_MULTIRED, 0, 4.0 * (nd + ng) * 4 * h->reg_cap);
-  if (nd > 0) GANMF_LAUNCH(finish_parts_kernel, dim3((int)nd), dim3(256), 0, h->st, h->d_arena, h->reg_cap, 0, h->d_parts);
-  if (ng > 0) GANMF_LAUNCH(finish_parts_kernel, dim3((int)ng), dim3(256), 0, h->st, h->g_arena, h->reg_cap, 1, h->g_parts);
+  const size_t stride = arena_stride(h);
+  Scope s(h, T_MULTIRED, 0, 4.0 * (nd + ng) * stride);
+  if (h->cfg.model == GANMF_MODEL_GANMF) {
+    if (nd > 0) GANMF_LAUNCH(finish_parts_kernel, dim3((int)nd), dim3(256), 0, h->st, h->d_arena, h->reg_cap, 0, h->d_parts);
+    if (ng > 0) GANMF_LAUNCH(finish_parts_kernel, dim3((int)ng), dim3(256), 0, h->st, h->g_arena, h->reg_cap, 1, h->g_parts);
+  } else {
+    if (nd > 0) GANMF_LAUNCH(finish_dis_parts_kernel, dim3((int)nd), dim3(256), 0, h->st, h->d_arena, (long long)stride, h->dis_cap, 5 + h->L, 0, h->d_parts);
+    if (ng > 0) GANMF_LAUNCH(finish_dis_parts_kernel, dim3((int)ng), dim3(256), 0, h->st, h->g_arena, (long long)stride, h->dis_cap, 5 + h->L, 1, h->g_parts);
+  }
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -1333,10 +1303,8 @@ int ensure_parts(ganmf_handle* h, int64_t steps) {
   TRY(dalloc(&h->d_parts, (size_t)cap * 4));
   TRY(dalloc(&h->g_parts, (size_t)cap * 4));
   TRY(dalloc(&h->colbuf, (size_t)cap));
-  if (h->cfg.model == GANMF_MODEL_GANMF) {
-    TRY(dalloc(&h->d_arena, (size_t)cap * 4 * h->reg_cap));
-    TRY(dalloc(&h->g_arena, (size_t)cap * 4 * h->reg_cap));
-  }
+  TRY(dalloc(&h->d_arena, (size_t)cap * arena_stride(h)));
+  TRY(dalloc(&h->g_arena, (size_t)cap * arena_stride(h)));
   h->parts_cap = cap;
   return 0;
 }
@@ -1536,19 +1504,17 @@ static int create_impl(const ganmf_cfg* cfg, ganmf_handle* h) {
     TRY(dalloc(&h->dz0, (size_t)2 * B * h->lde));
     TRY(dalloc(&h->dz1, (size_t)2 * B * h->lde));
     TRY(dalloc(&h->dlogit, (size_t)2 * B));
-    TRY(dalloc(&h->lossrow, (size_t)2 * B));
   }
   TRY(dalloc(&h->rs, (size_t)2 * B));
   TRY(dalloc(&h->scal, S_COUNT));
   TRY(dalloc(&h->sqp, (size_t)2 * std::max(GEMM_RED_GRID, ((B + 63) / 64) * ((N + 63) / 64)) + 16));
-  // FM partials: one per tile of the [B, e] dE output or per reduce block
-  TRY(dalloc(&h->fmp, std::max({RED_GRID, ((B + 63) / 64) * ((e + 63) / 64) + (e + 64) / 64 + 1, dis_dz_top_blocks(e) + 1})));
   {
     auto t64 = [](int a, int b) { return ((a + 63) / 64) * ((b + 63) / 64); };
     h->reg_cap = std::max({ADAM_GRID, (int)GEMM_RED_GRID, t64(N + 2, e), t64(e + 1, N), t64(N, k), t64(B, N), t64(B, e)});
     h->reg_cap = round_up(h->reg_cap + (e + 63) / 64, 64);      // + the float(uid) row's partials (dis_uid_grad_kernel)
+    // DisGANMF: a segment also holds the per-row cross-entropies of a batch half or the feature-matching partials
+    h->dis_cap = round_up(std::max({h->reg_cap, B, dis_dz_top_blocks(e) + 1}), 64);
   }
-  TRY(dalloc(&h->regp, (size_t)(4 + 17 + 1) * h->reg_cap));
   const float pw[4] = {ADAM_B1, ADAM_B2, ADAM_B1, ADAM_B2};
   HIP_TRY(hipMemcpy(h->scal, pw, sizeof pw, hipMemcpyHostToDevice));
   HIP_TRY(hipDeviceSynchronize());
@@ -1569,16 +1535,16 @@ int ganmf_destroy(ganmf_handle* h) {
   for (auto& t : h->Wl) free_tensor(t, false);
   free_tensor(h->Wo, false);
   for (float* a : h->Al) hipFree(a);
-  hipFree(h->dz0); hipFree(h->dz1); hipFree(h->dlogit); hipFree(h->lossrow);
+  hipFree(h->dz0); hipFree(h->dz1); hipFree(h->dlogit);
   free_tensor(h->Ue, false); free_tensor(h->V, true); hipFree(h->V_alt);
   hipFree(h->gD); hipFree(h->indptr); hipFree(h->indices); hipFree(h->data); hipFree(h->perm);
   if (h->stage_i) hipHostFree(h->stage_i);
   if (h->stage_f) hipHostFree(h->stage_f);
   hipFree(h->test_indptr); hipFree(h->test_indices); hipFree(h->test_gain); hipFree(h->eval_buf);
   hipFree(h->XF); hipFree(h->Ub); hipFree(h->E); hipFree(h->Dl); hipFree(h->dE); hipFree(h->dF); hipFree(h->gUb);
-  hipFree(h->slab); hipFree(h->rs); hipFree(h->scal); hipFree(h->sqp); hipFree(h->fmp);
+  hipFree(h->slab); hipFree(h->rs); hipFree(h->scal); hipFree(h->sqp);
   hipFree(h->seen_indptr); hipFree(h->seen_indices); hipFree(h->topk_items); hipFree(h->topk_vals); hipFree(h->sc_ids);
-  hipFree(h->regp); hipFree(h->colbuf); hipFree(h->d_parts); hipFree(h->g_parts); hipFree(h->d_arena); hipFree(h->g_arena); hipFree(h->sc_rows); hipFree(h->sc_out);
+  hipFree(h->colbuf); hipFree(h->d_parts); hipFree(h->g_parts); hipFree(h->d_arena); hipFree(h->g_arena); hipFree(h->sc_rows); hipFree(h->sc_out);
   for (auto& r : h->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
   if (h->st2) hipStreamSynchronize(h->st2);
   if (h->ev_fork) hipEventDestroy(h->ev_fork);

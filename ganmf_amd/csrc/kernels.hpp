@@ -220,6 +220,33 @@ __global__ __launch_bounds__(256) void finish_parts_kernel(const float* __restri
   }
 }
 
+// DisGANMF: block = step; its arena slot holds nseg segments of cap floats (zero where nothing was written):
+//   discriminator step (mode 0): seg 0 / 1 = per-row cross-entropies of the real / generated rows, seg 4 + t = sum(theta^2)
+//                                partials of tensor t  ->  parts = {sum seg 0, sum seg 1, sum over the tensors in order}
+//   generator step (mode 1):     seg 0 = cross-entropies of the generated rows, seg 1 = feature-matching partials,
+//                                seg 2 / 3 = sum(U^2) / sum(V^2) partials  ->  parts = the four segment sums
+__global__ __launch_bounds__(256) void finish_dis_parts_kernel(const float* __restrict__ arena, long long stride, int cap,
+                                                               int nseg, int mode, float* __restrict__ parts) {
+  __shared__ float red[4];
+  const float* a = arena + (size_t)blockIdx.x * stride;
+  float out[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int sgm = 0; sgm < nseg; ++sgm) {
+    if (mode == 0 && (sgm == 2 || sgm == 3)) continue;
+    if (mode == 1 && sgm >= 4) break;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < cap; i += 256) s += a[(size_t)sgm * cap + i];
+    const float t = block_sum_256(s, red);
+    __syncthreads();
+    if (mode == 1 || sgm < 2) out[sgm] = t;
+    else out[2] += t;
+  }
+  if (threadIdx.x == 0) {
+    float* p = parts + (size_t)blockIdx.x * 4;
+    p[0] = out[0]; p[1] = out[1]; p[2] = out[2];
+    if (mode == 1) p[3] = out[3];
+  }
+}
+
 // column `col` of a [n][4] parts array <-> a contiguous vector (data-parallel: only the partial-sum columns are all-reduced)
 __global__ void col_copy_kernel(float* __restrict__ parts, float* __restrict__ vec, long long n, int col, int to_vec) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
@@ -393,7 +420,7 @@ __global__ __launch_bounds__(256) void adam_rows_kernel(float* __restrict__ th, 
 __global__ __launch_bounds__(256) void dis_head_kernel(const float* __restrict__ feat, int ld, int e1,
                                                        const float* __restrict__ wo, int row0, int nrows,
                                                        int n_real, float inv_b, float* __restrict__ dlogit,
-                                                       float* __restrict__ loss_row) {
+                                                       float* __restrict__ loss_real, float* __restrict__ loss_fake) {
   const int r = row0 + blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= row0 + nrows) return;
   const int lane = threadIdx.x & 63;
@@ -404,7 +431,9 @@ __global__ __launch_bounds__(256) void dis_head_kernel(const float* __restrict__
   if (lane == 0) {
     const float z = r < n_real ? 1.f : 0.f;
     // max(x,0) - x*z + log1p(exp(-|x|))   (tf.nn.sigmoid_cross_entropy_with_logits)
-    loss_row[r] = fmaxf(s, 0.f) - s * z + log1pf(expf(-fabsf(s)));
+    const float l = fmaxf(s, 0.f) - s * z + log1pf(expf(-fabsf(s)));
+    if (r < n_real) loss_real[r] = l;            // the two label groups are summed separately, once per epoch
+    else loss_fake[r - n_real] = l;              // (finish_dis_parts_kernel)
     dlogit[r] = (1.f / (1.f + expf(-s)) - z) * inv_b;
   }
 }
