@@ -116,7 +116,8 @@ def test_hip_matches_oracle_end_to_end(golden_dir, case):
     distribution -- the eight-initialisation test above measures its spread, MAP@5 0.115 .. 0.150 -- so the band there is
     that spread, 0.035 (after the late round-2 kernel changes the HIP run of seed 1337 moved from 0.129 to 0.150, the
     published row is 0.148, the numpy oracle's run 0.135; the per-step agreement that pins the arithmetic is
-    tests/test_gpu_disganmf.py, the reference-held pin tests/test_gpu_trial_logs.py)."""
+    tests/test_gpu_disganmf.py, the reference-held pin tests/test_gpu_trial_logs.py; tools/chaos_check.py shows two builds that
+    agree bit for bit after one D and one G step 26 % apart element-wise in U after 20 epochs, with equal norms and losses)."""
     fx = json.load(open(os.path.join(golden_dir, "oracle_end_to_end.json")))
     if case not in fx:
         pytest.skip("oracle run %s not committed" % case)
@@ -139,7 +140,8 @@ def test_hip_matches_oracle_end_to_end(golden_dir, case):
         assert abs(res[5][metric] - ref["5"][metric]) <= tol, (metric, res[5][metric], ref["5"][metric])
     for c in (10, 20, 50):
         assert abs(res[c]["MAP"] - ref[str(c)]["MAP"]) <= tol, (c, res[c]["MAP"], ref[str(c)]["MAP"])
-    norm_tol = 0.01 if o["model"] == "GANMF" else 0.06
+    # DisGANMF: |U| of the eight initialisations spreads 21.1 .. 25.4 around the oracle run's 23.05 (tools/chaos_check.py norms)
+    norm_tol = 0.01 if o["model"] == "GANMF" else 0.12
     for name, got in (("U", model.user_factors()), ("V", model.item_factors())):
         want = o["factor_norms"][name]
         assert abs(np.linalg.norm(got.astype(np.float64)) - want) <= norm_tol * want, (name, np.linalg.norm(got), want)
