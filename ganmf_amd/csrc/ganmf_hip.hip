@@ -211,6 +211,7 @@ struct ganmf_handle {
                           // still reads the old V in the same launch; swapped with V.p after the launch
   bool fuse_adam = true;  // single GPU: Adam runs in the epilogue of the weight-gradient GEMMs
   bool dis_fuse_hidden = true;   // DisGANMF: also for the hidden layers l > 0 (GANMF_DIS_FUSE_HIDDEN)
+  bool dcoef_spread = true;      // de_dcoef_kernel: d_coef shared out over the GEMM's workgroups instead of extra ones (GANMF_DCOEF_SPREAD)
   float *d_parts = nullptr, *g_parts = nullptr;  // [cap][4]
   float* colbuf = nullptr;                       // [cap] one column of d_parts on its way through an all-reduce
   float *d_arena = nullptr, *g_arena = nullptr;  // [cap][4][reg_cap] per-step block partials (GANMF), reduced once per epoch
@@ -754,7 +755,7 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
       fill_plan(q, pde);
       q.C = h->slab; q.c_split_stride = (long long)gde.M * gde.ldc; q.c_batch_stride = (long long)gde.M * gde.ldc;
       const int ng = pde.tiles_m * pde.tiles_n * pde.nsplit;
-      const int nd = (int)std::max<long long>(1, std::min<long long>(32, (dc_total + 4095) / 4096));
+      const int nd = h->dcoef_spread ? 0 : (int)std::max<long long>(1, std::min<long long>(32, (dc_total + 4095) / 4096));
       GANMF_LAUNCH(de_dcoef_kernel<4>, dim3(ng + nd), dim3(1024), 0, h->st, q, dc, nd);
       HIP_TRY(hipGetLastError());
       dcoef_done = true;
@@ -1443,6 +1444,7 @@ static int create_impl(const ganmf_cfg* cfg, ganmf_handle* h) {
   h->defer_gub = env_int("GANMF_DEFER_GUB", 1) != 0;
   h->multi = env_int("GANMF_MULTI", 31);
   h->dis_fuse_hidden = env_int("GANMF_DIS_FUSE_HIDDEN", 1) != 0;
+  h->dcoef_spread = env_int("GANMF_DCOEF_SPREAD", 1) != 0;
   h->pair_ring = env_int("GANMF_PAIR_RING", 2) == 3 ? 3 : 2;
   h->inkernel_reduce = env_int("GANMF_INKERNEL_REDUCE", 0) != 0;   // measured slower than the chip-wide reduce kernel
   h->inlaunch_max = env_int("GANMF_INLAUNCH_MAX", 4);

@@ -42,6 +42,15 @@ template <int KG>
 __global__ __launch_bounds__(256 * KG) void de_dcoef_kernel(const GemmP g, const DCoefP d, const int nd) {
   __shared__ __attribute__((aligned(16))) float smem[3 * (64 + 64) * 64];
   const int ng = g.tiles_m * g.tiles_n * g.nsplit * g.nbatch;
+  if (nd == 0) {
+    // every GEMM workgroup first does its 1 / ng share of d_coef (a few hundred float4 of Es; the two scalar sums are formed
+    // by each workgroup alike, block 0 publishes them): extra d_coef workgroups would need a 96-KiB slot of their own and run
+    // as a tail behind the GEMM's (24.8 vs 21.6 us for the same product without them)
+    d_coef_body(d, (int)blockIdx.x, ng, smem);
+    __syncthreads();
+    gemm_f32_body<64, 64, 64, 3, false, false, KG>(g, (int)blockIdx.x, ng, smem);
+    return;
+  }
   if ((int)blockIdx.x < ng) gemm_f32_body<64, 64, 64, 3, false, false, KG>(g, (int)blockIdx.x, ng, smem);
   else d_coef_body(d, (int)blockIdx.x - ng, nd, smem);
 }
