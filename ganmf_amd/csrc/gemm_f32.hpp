@@ -951,7 +951,7 @@ inline GemmPlan gemm_plan(int M, int N, int K, int nbatch, bool wants_sq, const 
     const int bk = ts.bk;
     const double cyc_tile = ts.cyc_tile;
     const int max_split = no_split ? 1 : std::max(1, (K + GEMM_K_ALIGN - 1) / GEMM_K_ALIGN);
-    for (int want = 1; want <= max_split; want = want < 4 ? want + 1 : want + (want + 3) / 4) {
+    for (int want = 1; want <= max_split; want = want < 8 ? want + 1 : want + (want + 3) / 4) {      // 1 .. 8, 10, 13, 17, ...
       if (tune.nsplit) want = std::min(tune.nsplit, max_split);   // forced: evaluate exactly this one
       int ns, kps;
       split_plan(K, want, ns, kps);

@@ -27,7 +27,7 @@ G = sum(v for k, v in cls.items() if k.startswith("G:"))
 rows = [("generator GEMM + CSR rows (one launch)", "D:gen+rows", "generator GEMM + CSR rows", "G:gen+rows", None, None),
         ("encode `[2B,N+1]×[N+1,e]`, split 4", "D:encode", "encode", "G:encode", "D:reduce(encode)", "G:reduce(encode)"),
         ("decode + Δ + Σ² (two paths)", "D:decode", "decode (generated half), split 2", "G:decode", None, "G:reduce(decode)"),
-        ("dE, split 4 (slabs only) + d_coef (one launch); slab sum", "D:dE+d_coef", "dE, split 7", "G:dE", "D:reduce(dE)", "G:reduce(dE)"),
+        ("dE, split 4 (slabs only) + d_coef (one launch); slab sum", "D:dE+d_coef", "dE, split 8", "G:dE", "D:reduce(dE)", "G:reduce(dE)"),
         ("gWd_ext + gWe_ext, both + Adam (one launch)", "D:gWd+gWe+adam", "dF, split 2", "G:dF", None, "G:reduce(dF)"),
         (None, None, "gUb (split 29) + gV + Adam (one launch)", "G:gUb+gV+adam", None, None),
         (None, None, "all-rows Adam on U (sums gUb's slabs)", "G:adam_rows_U", None, None)]
