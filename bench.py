@@ -22,7 +22,7 @@ updates all ranks processed per second (= N x synchronous global steps/s).
 
 Extra objects on the JSON line: `roofline` (dominant kernel of the step = the 16-wave fp32 ring GEMM, on its largest
 class; `roofline_fused_adam` = the HBM-bound launch of the two fused-Adam weight-gradient GEMMs; HIP-event timed on the
-library's stream in a profiled repeat of the same K steps right after the timed region — events
+library's stream in a profiled repeat of the same steps (at least 96) right after the timed region — events
 stay out of the timed region so that `value` is not perturbed), `cpu_baseline` (the numpy fp32
 oracle = a port of the reference's per-step procedure, timed on this box's host cores on a
 bounded sample), `kernels` (per-kernel-class table) and `scoring_gemm` (the 6040x3706x250
@@ -164,6 +164,35 @@ def main():
         if world > 1:
             dist.barrier()
 
+    # ---- side measurement first: the generator / scoring GEMM (every rank runs it, rank 0 reports it).  ~20 ms of sustained GPU
+    # work right before the warm-up: the timed region then starts at the clocks a training run holds -- a short K would
+    # otherwise be timed on the power-management ramp of a GPU that has just been handed its first kernels (20 steps: 2.83 ms
+    # cold against 2.66 ms after 96 warm-up steps and 2.60 ms in a tight loop, tools/epoch_overhead.py)
+    try:
+        e32 = Engine(w["U"], w["N"], w["k"], w["e"], w["B"], device=local_rank, mfma="f32", **w["hp"])
+        e32.set_tensor(100, params["U"])
+        e32.set_tensor(101, params["V"])
+        e32.bench_scores(w["U"], transposed=False, iters=100)
+        ms32 = e32.bench_scores(w["U"], transposed=False, iters=100)
+        e32.close()
+        tf32 = 2.0 * w["U"] * w["N"] * w["k"] / ms32 / 1e9
+        plain32 = {"ms": round(ms32, 4), "achieved": round(tf32, 2),
+                                     "frac": round(tf32 / PEAK_F32_MFMA_TFLOPS, 4)}
+    except Exception as ex:   # never lose the bench line to the side measurement
+        plain32 = {"error": str(ex)}
+    # (the engine that trains goes last: nothing but its own kernels between this loop and the warm-up steps)
+    eng.bench_scores(w["U"], transposed=False, iters=100)          # (clock ramp: the first ~20 ms of work on an idle GPU run slower)
+    ms_sc = eng.bench_scores(w["U"], transposed=False, iters=100)
+    sc_tf = 2.0 * w["U"] * w["N"] * w["k"] / ms_sc / 1e9
+    scoring = {"shape": [w["U"], w["N"], w["k"]], "ms": round(ms_sc, 4), "achieved": round(sc_tf, 2),
+               "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(sc_tf / PEAK_F32_MFMA_TFLOPS, 4),
+               "arithmetic": "f32 in/out; K loop = 3-way exact bf16 split, 6 piece products on "
+                             "v_mfma_f32_32x32x16_bf16, f32 accumulate",
+               "executed_bf16_tflops": round(6 * sc_tf, 1), "peak_bf16": PEAK_BF16_MFMA_TFLOPS,
+               "frac_of_bf16_peak": round(6 * sc_tf / PEAK_BF16_MFMA_TFLOPS, 4)}
+    scoring["plain_f32_mfma"] = plain32
+    scoring_pre = scoring
+
     perm = np.random.RandomState(1337 + rank).permutation(w["U"]).astype(np.int32)
     if warmup:
         run_steps(eng, perm, w["B"], warmup)
@@ -179,7 +208,7 @@ def main():
 
     # ---- profiled repeat (HIP events around every launch, on the library's stream) --------------
     eng.profile(True)
-    run_steps(eng, perm, w["B"], steps)
+    run_steps(eng, perm, w["B"], max(steps, 96))      # (at least 48 launches per class: a short K alone averages over too few)
     prof = eng.profile_read()
     eng.profile(False)
 
@@ -246,25 +275,7 @@ def main():
         # products of weight >= 2^-16 accumulated in fp32 (fp32-accurate: tests/test_gpu_mfma_modes.py); `achieved`
         # counts the ALGORITHMIC 2MNK flops against the fp32 MFMA roof (the dtype of operands and result); the
         # executed bf16 flops (6x) against the bf16 roof and the plain fp32-MFMA kernel are reported beside it.
-        ms_sc = eng.bench_scores(w["U"], transposed=False, iters=20)
-        sc_tf = 2.0 * w["U"] * w["N"] * w["k"] / ms_sc / 1e9
-        scoring = {"shape": [w["U"], w["N"], w["k"]], "ms": round(ms_sc, 4), "achieved": round(sc_tf, 2),
-                   "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(sc_tf / PEAK_F32_MFMA_TFLOPS, 4),
-                   "arithmetic": "f32 in/out; K loop = 3-way exact bf16 split, 6 piece products on "
-                                 "v_mfma_f32_32x32x16_bf16, f32 accumulate",
-                   "executed_bf16_tflops": round(6 * sc_tf, 1), "peak_bf16": PEAK_BF16_MFMA_TFLOPS,
-                   "frac_of_bf16_peak": round(6 * sc_tf / PEAK_BF16_MFMA_TFLOPS, 4)}
-        try:
-            e32 = Engine(w["U"], w["N"], w["k"], w["e"], w["B"], device=local_rank, mfma="f32", **w["hp"])
-            e32.set_tensor(100, params["U"])
-            e32.set_tensor(101, params["V"])
-            ms32 = e32.bench_scores(w["U"], transposed=False, iters=20)
-            e32.close()
-            tf32 = 2.0 * w["U"] * w["N"] * w["k"] / ms32 / 1e9
-            scoring["plain_f32_mfma"] = {"ms": round(ms32, 4), "achieved": round(tf32, 2),
-                                         "frac": round(tf32 / PEAK_F32_MFMA_TFLOPS, 4)}
-        except Exception as ex:   # never lose the bench line to the side measurement
-            scoring["plain_f32_mfma"] = {"error": str(ex)}
+        scoring = scoring_pre
         out = {
             "metric": "GANMF training steps/sec", "value": round(world * done / el, 2), "unit": "steps/s",
             "n_gpus": world, "steps": done, "warmup": warmup, "ms_per_step": round(el / done * 1e3, 4),

@@ -1689,6 +1689,10 @@ int ganmf_train_epoch(ganmf_handle* h, const int32_t* perm, int64_t n, int32_t d
   const bool dist = h->has_comm && h->cfg.world_size > 1;
   if (dist && !global_batch_rows) return fail(-1, "ganmf_train_epoch: global_batch_rows required when world_size > 1");
   HIP_TRY(hipSetDevice(h->dev));
+  static const bool time_it = getenv("GANMF_TIME_EPOCH") != nullptr;
+  const auto tp0 = std::chrono::steady_clock::now();
+  auto since = [&]() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tp0).count(); };
+  double t_prep = 0, t_first = 0, t_enq = 0, t_sync = 0;
   const int B = h->B;
   const int64_t local_steps = (n + B - 1) / B;
   const int64_t per_pass = std::max(local_steps, n_steps_per_pass);
@@ -1714,12 +1718,14 @@ int ganmf_train_epoch(ganmf_handle* h, const int32_t* perm, int64_t n, int32_t d
     bglob[i] = global_batch_rows ? global_batch_rows[i] : nb;
     if (bglob[i] < nb || bglob[i] < 1) return fail(-1, "ganmf_train_epoch: global_batch_rows[%lld]=%d < local %d", (long long)i, bglob[i], nb);
   }
+  t_prep = since();
   HIP_TRY(hipMemcpyAsync(h->perm, stage_perm, (size_t)2 * h->U * sizeof(int), hipMemcpyHostToDevice, h->st));   // perm | pos, contiguous on both sides
   const int64_t nd = (int64_t)d_steps * per_pass, ng = (int64_t)g_steps * per_pass;
   TRY(ensure_parts(h, std::max(nd, ng)));
   HIP_TRY(hipMemsetAsync(h->d_parts, 0, (size_t)std::max<int64_t>(nd, 1) * 4 * sizeof(float), h->st));
   HIP_TRY(hipMemsetAsync(h->g_parts, 0, (size_t)std::max<int64_t>(ng, 1) * 4 * sizeof(float), h->st));
   TRY(arenas_begin(h, nd, ng));
+  t_first = since();
   int64_t idx = 0;
   for (int p = 0; p < d_steps; ++p)
     for (int64_t i = 0; i < per_pass; ++i, ++idx) {
@@ -1755,9 +1761,14 @@ int ganmf_train_epoch(ganmf_handle* h, const int32_t* perm, int64_t n, int32_t d
   TRY(ensure_stage(h, 0, ndp + ngp));
   HIP_TRY(hipMemcpyAsync(h->stage_f, h->d_parts, ndp * sizeof(float), hipMemcpyDeviceToHost, h->st));
   HIP_TRY(hipMemcpyAsync(h->stage_f + ndp, h->g_parts, ngp * sizeof(float), hipMemcpyDeviceToHost, h->st));
+  t_enq = since();
   HIP_TRY(hipStreamSynchronize(h->st));
+  t_sync = since();
   const std::vector<float> dp(h->stage_f, h->stage_f + ndp), gp(h->stage_f + ndp, h->stage_f + ndp + ngp);
   finish_losses(h, dp, gp, bglob, nd, ng, per_pass, d_losses, g_losses);
+  if (time_it)
+    fprintf(stderr, "[ganmf epoch] %lld D + %lld G steps: host prep %.0f us, first step enqueued at %.0f, all enqueued at %.0f, synced at %.0f, done at %.0f us\n",
+            (long long)nd, (long long)ng, t_prep, t_first, t_enq, t_sync, since());
   return 0;
 }
 
