@@ -212,7 +212,8 @@ struct ganmf_handle {
   bool fuse_adam = true;  // single GPU: Adam runs in the epilogue of the weight-gradient GEMMs
   bool dis_fuse_hidden = true;   // DisGANMF: also for the hidden layers l > 0 (GANMF_DIS_FUSE_HIDDEN)
   bool dcoef_spread = true;      // de_dcoef_kernel: d_coef shared out over the GEMM's workgroups instead of extra ones (GANMF_DCOEF_SPREAD)
-  float *d_parts = nullptr, *g_parts = nullptr;  // [cap][4]
+  float* parts_all = nullptr;                    // ONE allocation: [d_parts | g_parts | d_arena | g_arena], packed per call (parts_begin)
+  float *d_parts = nullptr, *g_parts = nullptr;  // [steps][4]
   float* colbuf = nullptr;                       // [cap] one column of d_parts on its way through an all-reduce
   float *d_arena = nullptr, *g_arena = nullptr;  // [cap][4][reg_cap] per-step block partials (GANMF), reduced once per epoch
   int64_t parts_cap = 0;
@@ -1254,10 +1255,19 @@ int any_g_step(ganmf_handle* h, const int* rows_dev, int nb, int start, int b_gl
 }
 
 // zero the per-step arenas before a pass / reduce them into the loss parts after it (GANMF)
-int arenas_begin(ganmf_handle* h, int64_t nd, int64_t ng) {
+int ensure_parts(ganmf_handle* h, int64_t steps);
+// Loss parts and per-step arenas of one call, packed into the front of parts_all and zeroed by ONE memset (the call starts on an
+// idle queue: every separate fill costs its launch latency; a 20-step call is 2.6 ms of GPU work).
+int parts_begin(ganmf_handle* h, int64_t nd, int64_t ng) {
+  TRY(ensure_parts(h, std::max<int64_t>(std::max(nd, ng), 1)));
   const size_t stride = arena_stride(h);
-  if (nd > 0) HIP_TRY(hipMemsetAsync(h->d_arena, 0, (size_t)nd * stride * sizeof(float), h->st));
-  if (ng > 0) HIP_TRY(hipMemsetAsync(h->g_arena, 0, (size_t)ng * stride * sizeof(float), h->st));
+  const size_t ndp = (size_t)std::max<int64_t>(nd, 1) * 4, ngp = (size_t)std::max<int64_t>(ng, 1) * 4;
+  h->d_parts = h->parts_all;
+  h->g_parts = h->d_parts + ndp;
+  h->d_arena = h->g_parts + ngp;
+  h->g_arena = h->d_arena + (size_t)std::max<int64_t>(nd, 0) * stride;
+  const size_t total = ndp + ngp + (size_t)(std::max<int64_t>(nd, 0) + std::max<int64_t>(ng, 0)) * stride;
+  HIP_TRY(hipMemsetAsync(h->parts_all, 0, total * sizeof(float), h->st));
   return 0;
 }
 int arenas_finish(ganmf_handle* h, int64_t nd, int64_t ng) {
@@ -1297,15 +1307,12 @@ int ensure_parts(ganmf_handle* h, int64_t steps) {
   HIP_TRY(hipStreamSynchronize(h->st));
   // capacity is only published once every buffer of the new size exists: a failing dalloc leaves cap 0 and null
   // pointers, so the next call allocates again instead of running on freed memory
-  hipFree(h->d_parts); hipFree(h->g_parts); hipFree(h->d_arena); hipFree(h->g_arena); hipFree(h->colbuf);
-  h->d_parts = h->g_parts = h->d_arena = h->g_arena = h->colbuf = nullptr;
+  hipFree(h->parts_all); hipFree(h->colbuf);
+  h->parts_all = h->d_parts = h->g_parts = h->d_arena = h->g_arena = h->colbuf = nullptr;
   h->parts_cap = 0;
   const int64_t cap = steps + 64;
-  TRY(dalloc(&h->d_parts, (size_t)cap * 4));
-  TRY(dalloc(&h->g_parts, (size_t)cap * 4));
+  TRY(dalloc(&h->parts_all, (size_t)cap * 2 * (4 + arena_stride(h))));
   TRY(dalloc(&h->colbuf, (size_t)cap));
-  TRY(dalloc(&h->d_arena, (size_t)cap * arena_stride(h)));
-  TRY(dalloc(&h->g_arena, (size_t)cap * arena_stride(h)));
   h->parts_cap = cap;
   return 0;
 }
@@ -1546,7 +1553,7 @@ int ganmf_destroy(ganmf_handle* h) {
   hipFree(h->XF); hipFree(h->Ub); hipFree(h->E); hipFree(h->Dl); hipFree(h->dE); hipFree(h->dF); hipFree(h->gUb);
   hipFree(h->slab); hipFree(h->rs); hipFree(h->scal); hipFree(h->sqp);
   hipFree(h->seen_indptr); hipFree(h->seen_indices); hipFree(h->topk_items); hipFree(h->topk_vals); hipFree(h->sc_ids);
-  hipFree(h->colbuf); hipFree(h->d_parts); hipFree(h->g_parts); hipFree(h->d_arena); hipFree(h->g_arena); hipFree(h->sc_rows); hipFree(h->sc_out);
+  hipFree(h->colbuf); hipFree(h->parts_all); hipFree(h->sc_rows); hipFree(h->sc_out);
   for (auto& r : h->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
   if (h->st2) hipStreamSynchronize(h->st2);
   if (h->ev_fork) hipEventDestroy(h->ev_fork);
@@ -1721,10 +1728,7 @@ int ganmf_train_epoch(ganmf_handle* h, const int32_t* perm, int64_t n, int32_t d
   t_prep = since();
   HIP_TRY(hipMemcpyAsync(h->perm, stage_perm, (size_t)2 * h->U * sizeof(int), hipMemcpyHostToDevice, h->st));   // perm | pos, contiguous on both sides
   const int64_t nd = (int64_t)d_steps * per_pass, ng = (int64_t)g_steps * per_pass;
-  TRY(ensure_parts(h, std::max(nd, ng)));
-  HIP_TRY(hipMemsetAsync(h->d_parts, 0, (size_t)std::max<int64_t>(nd, 1) * 4 * sizeof(float), h->st));
-  HIP_TRY(hipMemsetAsync(h->g_parts, 0, (size_t)std::max<int64_t>(ng, 1) * 4 * sizeof(float), h->st));
-  TRY(arenas_begin(h, nd, ng));
+  TRY(parts_begin(h, nd, ng));
   t_first = since();
   int64_t idx = 0;
   for (int p = 0; p < d_steps; ++p)
@@ -1759,8 +1763,7 @@ int ganmf_train_epoch(ganmf_handle* h, const int32_t* perm, int64_t n, int32_t d
   if (dist && ng > 0) TRY(allreduce(h, h->g_parts, (size_t)ng * 4));
   const size_t ndp = (size_t)std::max<int64_t>(nd, 1) * 4, ngp = (size_t)std::max<int64_t>(ng, 1) * 4;
   TRY(ensure_stage(h, 0, ndp + ngp));
-  HIP_TRY(hipMemcpyAsync(h->stage_f, h->d_parts, ndp * sizeof(float), hipMemcpyDeviceToHost, h->st));
-  HIP_TRY(hipMemcpyAsync(h->stage_f + ndp, h->g_parts, ngp * sizeof(float), hipMemcpyDeviceToHost, h->st));
+  HIP_TRY(hipMemcpyAsync(h->stage_f, h->d_parts, (ndp + ngp) * sizeof(float), hipMemcpyDeviceToHost, h->st));   // d_parts | g_parts, contiguous
   t_enq = since();
   HIP_TRY(hipStreamSynchronize(h->st));
   t_sync = since();
@@ -1785,12 +1788,9 @@ int ganmf_train_step(ganmf_handle* h, int kind, const int32_t* uids, int32_t n, 
     if (pos[uids[i]] != -1) return fail(-1, "ganmf_train_step: duplicate row id %d", uids[i]);
     pos[uids[i]] = i;
   }
-  TRY(ensure_parts(h, 1));
   HIP_TRY(hipMemcpyAsync(h->perm, uids, n * sizeof(int), hipMemcpyHostToDevice, h->st));
   HIP_TRY(hipMemcpyAsync(h->pos, pos.data(), (size_t)h->U * sizeof(int), hipMemcpyHostToDevice, h->st));
-  HIP_TRY(hipMemsetAsync(h->d_parts, 0, 4 * sizeof(float), h->st));
-  HIP_TRY(hipMemsetAsync(h->g_parts, 0, 4 * sizeof(float), h->st));
-  TRY(arenas_begin(h, kind == 0, kind == 1));
+  TRY(parts_begin(h, kind == 0, kind == 1));
   if (kind == 0) TRY(any_d_step(h, h->perm, n, n, 0));
   else TRY(any_g_step(h, h->perm, n, 0, n, 0));
   TRY(dp_join(h));
