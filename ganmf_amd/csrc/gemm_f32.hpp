@@ -976,7 +976,10 @@ inline GemmPlan gemm_plan(int M, int N, int K, int nbatch, bool wants_sq, const 
   // (256x3706x2048 on 232 workgroups: 48 vs 57 us).  Every K-heavy 128/256-row GEMM of the C2 step is planned onto
   // <= 256 workgroups and stays fp32.  GEMMs of >= 6 GFLOP (the C4-sized steps: K or N = 50 000) run long enough
   // per workgroup that the split-bf16 loop wins on any grid (C4 shard: 955 vs 846 steps/s with every GEMM on it).
-  best.mode = tune.mode != MFMA_AUTO ? tune.mode : (wgs >= 2 * GEMM_CUS || gflop >= 6.0 ? MFMA_BF16X3 : MFMA_F32);
+  // (128 x 128 tiles have no 16-wave form: from 1.5 workgroups per CU on the staged kernel already leads -- generator GEMM at
+  // C4 width, 128 x 50 000 x 250 on 391 workgroups: 49.5 -> 34.4 us)
+  const bool many = wgs >= 2 * GEMM_CUS || (best.tile == 128 && 2 * wgs >= 3 * GEMM_CUS);
+  best.mode = tune.mode != MFMA_AUTO ? tune.mode : (many || gflop >= 6.0 ? MFMA_BF16X3 : MFMA_F32);
   best.bk = tune.bk;
   best.tile_order = tune.tile_order;
   // K groups: a 64 x 64 workgroup that has its CU to itself (ring 3: 96 KiB) runs 16 waves, four per SIMD (C2 step:
