@@ -649,7 +649,8 @@ int rows_and_generator(ganmf_handle* h, const int* rows_dev, int nb, int which, 
   }
   {
     Scope s(h, T_DENSIFY, 0, 4.0 * nb * (N + 2 * k));
-    GANMF_LAUNCH(densify_rows_kernel, dim3(nb), dim3(256), 0, h->st, d);
+    d.nseg = std::max(1, std::min(16, (h->ldN + 8191) / 8192));      // wide rows (C4: 50 000 columns): several workgroups per row
+    GANMF_LAUNCH(densify_rows_kernel, dim3(nb * d.nseg), dim3(256), 0, h->st, d);
     HIP_TRY(hipGetLastError());
   }
   return run_gemm(h, T_GEMM_GEN, T_RED_GEN, g, false, false);

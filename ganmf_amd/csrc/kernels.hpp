@@ -56,11 +56,14 @@ struct DensP {
   int which, alpha_idx;
   float lr;
   int uid_col, row_offset;
+  int nseg;                      // > 1 (stand-alone launch on wide rows): nseg workgroups per row, one column segment each
 };
 
 // (block b of the row expansion, any block size: also runs as extra workgroups of the generator GEMM's launch, gemm_multi.hpp)
-__device__ __forceinline__ void densify_row_body(const DensP& d, const int b) {
-  if (b == 0 && threadIdx.x == 0) {
+__device__ __forceinline__ void densify_row_body(const DensP& d, const int bid) {
+  const int nseg = d.nseg > 1 ? d.nseg : 1;
+  const int b = bid / nseg, seg = bid % nseg;
+  if (bid == 0 && threadIdx.x == 0) {
     const int o = d.which ? S_B1P_G : S_B1P_D;
     const float b1p = d.scal[o], b2p = d.scal[o + 1];
     d.scal[d.alpha_idx] = d.lr * sqrtf(1.f - b2p) / (1.f - b1p);
@@ -68,21 +71,29 @@ __device__ __forceinline__ void densify_row_body(const DensP& d, const int b) {
     d.scal[o + 1] = b2p * ADAM_B2;
   }
   const int r = d.rows[b];
-  float4* xr = reinterpret_cast<float4*>(d.X + (size_t)b * d.ldx);
-  for (int c = threadIdx.x; c < d.ldx / 4; c += blockDim.x) xr[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-  const float4* us = reinterpret_cast<const float4*>(d.Uemb + (size_t)r * d.ldk);
-  float4* ud = reinterpret_cast<float4*>(d.Ub + (size_t)b * d.ldk);
-  for (int c = threadIdx.x; c < d.ldk / 4; c += blockDim.x) ud[c] = us[c];
+  // this workgroup's columns [c0, c1) of the row (a multiple of four floats; the whole padded row when nseg == 1)
+  const int segw = ((d.ldx / 4 + nseg - 1) / nseg) * 4;
+  const int c0 = seg * segw, c1 = min(d.ldx, c0 + segw);
+  float* x = d.X + (size_t)b * d.ldx;
+  float4* xr = reinterpret_cast<float4*>(x + c0);
+  for (int c = threadIdx.x; c < (c1 - c0) / 4; c += blockDim.x) xr[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (seg == 0) {
+    const float4* us = reinterpret_cast<const float4*>(d.Uemb + (size_t)r * d.ldk);
+    float4* ud = reinterpret_cast<float4*>(d.Ub + (size_t)b * d.ldk);
+    for (int c = threadIdx.x; c < d.ldk / 4; c += blockDim.x) ud[c] = us[c];
+  }
   __syncthreads();
   const long long s = d.indptr[r], e = d.indptr[r + 1];
-  float* x = d.X + (size_t)b * d.ldx;
-  for (long long j = s + threadIdx.x; j < e; j += blockDim.x) x[d.indices[j]] = d.data[j];
+  for (long long j = s + threadIdx.x; j < e; j += blockDim.x) {
+    const int col = d.indices[j];
+    if (col >= c0 && col < c1) x[col] = d.data[j];
+  }
   if (threadIdx.x == 0) {
-    x[d.ncols] = 1.0f;
-    d.X[(size_t)(d.nb + b) * d.ldx + d.ncols] = 1.0f;
+    if (d.ncols >= c0 && d.ncols < c1) x[d.ncols] = 1.0f;
+    if (seg == 0) d.X[(size_t)(d.nb + b) * d.ldx + d.ncols] = 1.0f;
     if (d.uid_col >= 0) {   // DisGANMF conditions D on float(uid) (DisGANMF.py:59,110-111)
-      x[d.uid_col] = (float)(d.row_offset + r);
-      d.X[(size_t)(d.nb + b) * d.ldx + d.uid_col] = (float)(d.row_offset + r);
+      if (d.uid_col >= c0 && d.uid_col < c1) x[d.uid_col] = (float)(d.row_offset + r);
+      if (seg == 0) d.X[(size_t)(d.nb + b) * d.ldx + d.uid_col] = (float)(d.row_offset + r);
     }
   }
 }
