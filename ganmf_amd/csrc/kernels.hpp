@@ -138,7 +138,8 @@ __global__ __launch_bounds__(256) void sparse_front_kernel(const long long* __re
     const int G = 256 / width, g = tid / width, c = c0 + tid % width;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (g < G) {
-      for (long long j = s + g; j < en; j += G) {
+#pragma unroll 8
+      for (long long j = s + g; j < en; j += G) {      // (index, value and row fetches of eight entries in flight)
         const float w = data[j];
         const float4 a = *reinterpret_cast<const float4*>(We + (size_t)indices[j] * lde + 4 * c);
         acc.x += w * a.x; acc.y += w * a.y; acc.z += w * a.z; acc.w += w * a.w;
