@@ -5,6 +5,11 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
+Both forms work for N > 1: started without a launcher (`WORLD_SIZE` unset), `--gpus N` makes this process a launcher
+itself -- it starts N rank processes of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT
+in their environment) BEFORE it has touched torch, HIP or the library, relays rank 0's JSON line and exits non-zero if any
+rank does.  No process that has initialised the GPU is ever re-executed.
+
 A *step* is one minibatch parameter update — one `sess.run([dtrain|gtrain, loss])` of the
 reference (GANRec/GANMF.py:186-187,200-201) — on a batch of 128 user rows.  K timed steps are
 K/2 discriminator updates followed by K/2 generator updates over the same slices, issued exactly
@@ -48,7 +53,9 @@ C2 = dict(U=6040, N=3706, k=250, e=992, B=128, density=0.035,
 
 
 def run_steps(eng, perm, B, n_steps):
-    """n_steps = D updates then G updates, in chunks of full batches (same call fit() makes)."""
+    """EXACTLY n_steps updates: ceil(n/2) D updates and floor(n/2) G updates, in chunks of full batches -- each chunk one
+    ganmf_train_epoch call of c D updates followed by c G updates over the same slices (the call fit() makes); an odd
+    n_steps ends with one call that runs a single D update (d_steps=1, g_steps=0)."""
     per_call = (len(perm) // B)
     half = n_steps // 2
     done = 0
@@ -56,7 +63,9 @@ def run_steps(eng, perm, B, n_steps):
         c = min(per_call, half - done)
         eng.train_epoch(perm[:c * B], 1, 1)
         done += c
-    return 2 * half
+    if n_steps % 2:
+        eng.train_epoch(perm[:B], 1, 0)
+    return n_steps
 
 
 def cpu_baseline(urm, params, w, seconds):
@@ -94,13 +103,51 @@ def cpu_baseline(urm, params, w, seconds):
                       "URM[uids].toarray() densify and dense Adam, %.1f s" % (n, n, B, el)}
 
 
-def main():
-    # stdout carries exactly ONE line (the JSON).  RCCL prints a version banner through C stdio that is
-    # flushed at exit, after Python's own prints: park fd 1 on stderr for the whole run and write the JSON
-    # line to the saved descriptor at the very end.
+def launch_ranks(n, argv, script=None):
+    """`python bench.py --gpus N` without a launcher: start the N rank processes ourselves.  Runs before this process has
+    imported torch or loaded the HIP library (nothing here touches a GPU); the children are fresh interpreters."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    # rank 0's stdout (the JSON line) is drained by a thread while every child is polled: a rank that dies would leave its
+    # peers waiting in a collective for ever, so the first non-zero exit ends the others (their exact PIDs)
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = False
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs):
+            failed = True
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            for p in procs:
+                try:
+                    p.wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            break
+        time.sleep(0.2)
+    reader.join(timeout=10)
+    codes = [p.wait() for p in procs]
+    if failed or any(codes):
+        sys.stderr.write("bench.py: rank exit codes %s\n" % codes)
+        raise SystemExit(1)
+    line = b"".join(chunks)
+    sys.stdout.write(line.decode())
     sys.stdout.flush()
-    json_fd = os.dup(1)
-    os.dup2(2, 1)
+
+
+def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=192)
@@ -108,29 +155,35 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args.gpus, sys.argv[1:])
+    # stdout carries exactly ONE line (the JSON).  RCCL prints a version banner through C stdio that is
+    # flushed at exit, after Python's own prints: park fd 1 on stderr for the whole run and write the JSON
+    # line to the saved descriptor at the very end.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch N>1 with python -m torch.distributed.run (see module docstring)")
-    steps = max(2, args.steps - args.steps % 2)
-    warmup = max(0, args.warmup - args.warmup % 2)
+    steps = max(1, args.steps)
+    warmup = max(0, args.warmup)
 
+    # One GPU: no torch at all -- ganmf_train_epoch is blocking (it returns after its stream has drained), which is the
+    # synchronisation the timed region needs.  N > 1: torch.distributed (gloo) is the control plane (unique-id broadcast,
+    # barriers, the MAX over ranks) and torch.cuda.synchronize() brackets the timed region as the contract asks.
     torch = dist = None
-    try:
+    if world > 1:
         import torch
         import torch.distributed as dist
-    except Exception:
-        if world > 1:
-            raise
-    if torch is not None and torch.cuda.is_available():
-        torch.cuda.set_device(local_rank)      # torch.cuda.synchronize() below must target this rank's GPU
-    if world > 1:
         os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)   # control plane only
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local_rank)      # torch.cuda.synchronize() below must target this rank's GPU
 
     from ganmf_amd.engine import Engine, comm_unique_id
     from ganmf_amd.synthetic import glorot_params, synthetic_urm
@@ -140,12 +193,15 @@ def main():
     params = glorot_params(w["U"], w["N"], w["k"], w["e"], seed=1337)
     if rank:
         params["U"] = glorot_params(w["U"], 8, w["k"], 8, seed=1337 + rank)["U"]   # own user rows
+    force_comm = world == 1 and os.environ.get("GANMF_BENCH_FORCE_COMM") == "1"   # exercise the RCCL path on one GPU
+    if force_comm:
+        os.environ["GANMF_FORCE_COLLECTIVES"] = "1"      # (read when the handle is created) the one-rank communicator issues its
+                                                         # in-place ncclReduceScatter / ncclAllGather calls instead of skipping them
     eng = Engine(w["U"], w["N"], w["k"], w["e"], w["B"], device=local_rank, world_size=world, rank=rank,
                  row_offset=rank * w["U"], **w["hp"])
     eng.set_urm(urm)
     for name, tid in (("We", 0), ("be", 1), ("Wd", 2), ("bd", 3), ("U", 100), ("V", 101)):
         eng.set_tensor(tid, params[name])
-    force_comm = world == 1 and os.environ.get("GANMF_BENCH_FORCE_COMM") == "1"   # exercise the RCCL path on one GPU
     if world > 1 or force_comm:
         ids = [comm_unique_id() if rank == 0 else None]
         if world > 1:
@@ -159,10 +215,10 @@ def main():
         eng.train_epoch = train_dp
 
     def sync():
-        if torch is not None and torch.cuda.is_available():
-            torch.cuda.synchronize()
         if world > 1:
+            torch.cuda.synchronize()
             dist.barrier()
+            torch.cuda.synchronize()
 
     # ---- side measurement first: the generator / scoring GEMM (every rank runs it, rank 0 reports it).  ~20 ms of sustained GPU
     # work right before the warm-up: the timed region then starts at the clocks a training run holds -- a short K would
@@ -256,6 +312,12 @@ def main():
                     "unit": "TFLOP/s", "frac": round(dom_tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
                     "flops_per_launch": dom["flops"] / dom["launches"],
                     "avg_launch_us": round(dom["ms"] / dom["launches"] * 1e3, 2)}
+        # the same kernel over ALL of its classes (every launch of the family, combined launches included), time-weighted:
+        # sum of algorithmic FLOPs / sum of launch durations.  `frac` above is the family's largest class.
+        fam_tf = sum(p["flops"] for p in fam) / sum(p["ms"] for p in fam) / 1e9
+        roofline["frac_time_weighted"] = round(fam_tf / PEAK_F32_MFMA_TFLOPS, 4)
+        roofline["achieved_time_weighted"] = round(fam_tf, 2)
+        roofline["classes_time_weighted"] = [p["name"] for p in fam]
         # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in
         # separate runs, gfx950 read correction applied: tools/collect_traffic.py); null when no profile matches
         try:

@@ -5,15 +5,15 @@ import numpy as np
 
 from . import _lib as L
 from .GANMF import GANMF, _TensorRef, glorot_uniform
-from .engine import Engine
 
 
 class DisGANMF(GANMF):
     RECOMMENDER_NAME = 'DisGANMF'
 
-    def __init__(self, URM_train, mode='user', seed=1234, verbose=False, is_experiment=False, device=0):
+    def __init__(self, URM_train, mode='user', seed=1234, verbose=False, is_experiment=False, device=0, devices=None,
+                 dist_backend=None, world_size=None):
         super(DisGANMF, self).__init__(URM_train, mode=mode, verbose=verbose, seed=seed, is_experiment=is_experiment,
-                                       device=device)
+                                       device=device, devices=devices, dist_backend=dist_backend, world_size=world_size)
 
     # tensor ids follow tf.get_collection order (DisGANMF.py:121): layer_l/kernel, layer_l/bias, D_output/{kernel,bias}
     def _d_names(self):
@@ -32,8 +32,8 @@ class DisGANMF(GANMF):
         self.num_factors, self.d_layers, self.d_nodes, self.d_hidden_act = num_factors, d_layers, d_nodes, d_hidden_act
         if self.engine is not None:
             self.engine.close()
-        self.engine = Engine(self.num_users, self.num_items, num_factors, d_nodes, batch_size, model=L.MODEL_DISGANMF,
-                             d_layers=d_layers, d_act=d_hidden_act, device=self.device, mfma=self.mfma, **hp)
+        self.engine = self._make_engine(num_factors, d_nodes, batch_size, model=L.MODEL_DISGANMF, d_layers=d_layers,
+                                        d_act=d_hidden_act, mfma=self.mfma, **hp)
         self.engine.set_urm(self._URM_fit)
         self.engine.set_seen(self._URM_eval)
         self.params = {'D': [_TensorRef(i, n) for i, n in enumerate(self._d_names())],

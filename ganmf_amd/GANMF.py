@@ -62,7 +62,13 @@ class GANMF(BaseRecommender):
                   (2, 'autoencoder/decoding/kernel'), (3, 'autoencoder/decoding/bias'))
     _G_TENSORS = ((L.T_USER_EMB, 'generator/user_embeddings'), (L.T_ITEM_EMB, 'generator/item_embeddings'))
 
-    def __init__(self, URM_train, mode='user', verbose=False, seed=1234, is_experiment=False, device=0):
+    def __init__(self, URM_train, mode='user', verbose=False, seed=1234, is_experiment=False, device=0, devices=None,
+                 dist_backend=None, world_size=None):
+        """`devices` (beyond the reference's signature; also GANMF_DEVICES="0,1,2,3" in the environment, so that the
+        reference's drivers need no change): fit() shards the generator's users row-wise over these GPUs, one rank process
+        per GPU over RCCL (ganmf_amd/dist.py ShardedEngine; north star: "users shard row-wise across the 8 GPUs of one
+        node").  dist_backend="local" + world_size=N (GANMF_DIST_BACKEND / GANMF_WORLD_SIZE) puts N ranks on ONE GPU over the
+        library's loopback communicator (tests).  Default: one GPU, `device`."""
         if mode not in ['user', 'item']:
             raise ValueError('Accepted training modes are `user` and `item`. Given was {}.', mode)
         self.mode = mode
@@ -77,6 +83,11 @@ class GANMF(BaseRecommender):
         self.seed = seed
         self.verbose = verbose
         self.device = device
+        if devices is None and os.environ.get("GANMF_DEVICES"):
+            devices = [int(d) for d in os.environ["GANMF_DEVICES"].split(",") if d.strip() != ""]
+        self.devices = list(devices) if devices is not None else None
+        self.dist_backend = dist_backend or os.environ.get("GANMF_DIST_BACKEND") or "process"
+        self.world_size = world_size if world_size is not None else (int(os.environ["GANMF_WORLD_SIZE"]) if os.environ.get("GANMF_WORLD_SIZE") else None)
         self.logsdir = os.path.join('plots', self.RECOMMENDER_NAME, datetime.now().strftime("%Y%m%d-%H%M%S"))
         self.is_experiment = is_experiment
         if not self.is_experiment:
@@ -104,13 +115,28 @@ class GANMF(BaseRecommender):
         self.num_factors, self.emb_dim = num_factors, emb_dim
         if self.engine is not None:
             self.engine.close()
-        self.engine = Engine(self.num_users, self.num_items, num_factors, emb_dim, batch_size, device=self.device,
-                             mfma=self.mfma, **hp)
+        self.engine = self._make_engine(num_factors, emb_dim, batch_size, mfma=self.mfma, **hp)
         self.engine.set_urm(self._URM_fit)
         self.engine.set_seen(self._URM_eval)            # for device-side recommend()
         self.params = {'D': [_TensorRef(t, n) for t, n in self._D_TENSORS],
                        'G': [_TensorRef(t, n) for t, n in self._G_TENSORS]}
         self.sess = _SessionShim(self)
+
+    def _sharded(self):
+        if self.dist_backend == "local":
+            return (self.world_size or 1) > 1
+        return self.devices is not None and len(self.devices) > 1
+
+    def _make_engine(self, num_factors, width, batch_size, **kw):
+        """One Engine on `device`, or the row-sharded group (same methods) when several devices / ranks were asked for."""
+        if not self._sharded():
+            return Engine(self.num_users, self.num_items, num_factors, width, batch_size, device=self.device, **kw)
+        from .dist import ShardedEngine
+        if self.dist_backend == "local":
+            return ShardedEngine(self.num_users, self.num_items, num_factors, width, batch_size, world_size=self.world_size,
+                                 devices=[self.devices[0] if self.devices else self.device], backend="local", **kw)
+        return ShardedEngine(self.num_users, self.num_items, num_factors, width, batch_size, devices=self.devices,
+                             backend="process", **kw)
 
     def _init_weights(self):
         if self.initial_weights is not None:
@@ -255,9 +281,12 @@ class GANMF(BaseRecommender):
             return None
         if min(cutoffs) < 1:
             return None
-        if getattr(self, "_test_on_device", None) != (evaluator_key, id(self.engine)):
+        # `evaluator_key`: a token the evaluator draws once from a process-wide counter (never id(): ids of freed objects are
+        # reused); the engine is compared by identity through a strong reference, so a rebuilt engine uploads again
+        held = getattr(self, "_test_on_device", None)
+        if held is None or held[0] != evaluator_key or held[1] is not self.engine:
             self.engine.set_test(urm_test_sorted, gains)
-            self._test_on_device = (evaluator_key, id(self.engine))
+            self._test_on_device = (evaluator_key, self.engine)
         return self.engine.evaluate(np.asarray(user_id_array).reshape(-1), cutoffs, disc, ideal_cum,
                                     transposed=(self.mode == 'item'), remove_seen=remove_seen_flag)
 

@@ -242,6 +242,8 @@ struct ganmf_handle {
   std::shared_ptr<LocalGroup> local;   // in-process loopback communicator (ganmf_comm_init_local)
   int d_alpha = S_ALPHA_D;             // scalar slot holding lr_t of the discriminator step in flight (alternates in data-parallel runs)
   bool side_pending = false;           // data-parallel: the side lane still updates replicated tensors (dp_join before their next use)
+  bool force_coll = false;             // GANMF_FORCE_COLLECTIVES=1: a one-rank communicator still issues its (in-place) reduce-scatter /
+                                       // all-gather calls, so that the RCCL call sites execute on a one-GPU box (tests, bench)
   // tuning knobs (environment: GANMF_TILE, GANMF_RING, GANMF_NSPLIT; 0 = cost model decides)
   GemmTune tune;
   bool debug_plan = false;
@@ -420,7 +422,7 @@ int allreduce(ganmf_handle* h, float* buf, size_t count, int lane = 0) {
 // In place over a buffer of world equal slices: after the reduce-scatter rank r holds the sum of slice r (the other
 // slices of its buffer are unspecified); the all-gather fills every slice from its owner.
 int reduce_scatter(ganmf_handle* h, float* buf, size_t total, int lane) {
-  if (h->cfg.world_size == 1) return 0;     // one slice, already in place
+  if (h->cfg.world_size == 1 && !h->force_coll) return 0;     // one slice, already in place
   hipStream_t st = lane ? h->st2 : h->st;
   const size_t slice = total / (size_t)h->cfg.world_size;
   Scope s(h, T_ALLREDUCE, 0, 4.0 * total, st);
@@ -429,7 +431,7 @@ int reduce_scatter(ganmf_handle* h, float* buf, size_t total, int lane) {
   return 0;
 }
 int all_gather(ganmf_handle* h, float* buf, size_t total, int lane) {
-  if (h->cfg.world_size == 1) return 0;
+  if (h->cfg.world_size == 1 && !h->force_coll) return 0;
   hipStream_t st = lane ? h->st2 : h->st;
   const size_t slice = total / (size_t)h->cfg.world_size;
   Scope s(h, T_ALLREDUCE, 0, 4.0 * total, st);
@@ -744,7 +746,8 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
   bool dcoef_done = false;
   GemmP gde{};
   GemmPlan pde;
-  if (nb > 0 && !dist && (h->multi & 4) && (h->multi & 8)) {
+  // (data-parallel runs take the same launch: the two sums d_coef needs were all-reduced just above)
+  if (nb > 0 && (h->multi & 4) && (h->multi & 8)) {
     gde.A = h->Dl; gde.lda = h->ldN; gde.B = h->Wd.p; gde.ldb = h->ldN;
     gde.C = h->dE; gde.ldc = h->lde; gde.M = 2 * nb; gde.N = e; gde.K = N; gde.nbatch = 1;
     gde.epi.kind = EPI_ROWSCALE; gde.epi.rowscale = h->rs; gde.zero_page = h->zero_page;
@@ -793,9 +796,14 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
       return run_gemm(h, T_GEMM_GWD, T_RED_GWD, g, true, true, &regn[1], fused ? 24.0 * h->Wd.count() : 0, 0, wg_tune, nullptr,
                       nullptr, dE_red.part ? &dE_red : nullptr);
     };
-    // Data-parallel: the decoder gradient is produced first; its reduce-scatter runs on the side lane under the dE GEMM,
-    // its Adam slice + all-gather (which overwrite Wd) under the gWe_ext GEMM, once dE has read the old decoder.
-    if (dist) {
+    // Data-parallel, combined launches (default): dE's slabs exist already (de_dcoef_kernel), so the chain is the single-GPU one
+    // with stored gradients -- [gWd_ext + slab sum of dE] in one launch, then the decoder's reduce-scatter / Adam slice /
+    // all-gather on the side lane under the gWe_ext GEMM (dE has read the old decoder by then), the encoder's behind them under
+    // the next step's row expansion + generator GEMM.
+    // Data-parallel without the combined launches (GANMF_MULTI): the decoder gradient is produced first; its reduce-scatter runs
+    // on the side lane under the dE GEMM, its Adam slice + all-gather (which overwrite Wd) under the gWe_ext GEMM.
+    const bool dist_combined = dist && dcoef_done;
+    if (dist && !dist_combined) {
       TRY(gemm_gWd());
       TRY(lane_fork(h));
       TRY(reduce_scatter(h, h->Wd.g, h->Wd.cap, 1));
@@ -816,7 +824,7 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
     // Weight-gradient GEMMs.  Single GPU: the gradient tile never leaves the CU -- the epilogue
     // applies TF-Adam to theta/m/v in place (after dE, which reads the old decoder).
     // Data-parallel: the gradients are stored, reduce-scattered, and each rank updates its slice (dp_update).
-    if (dist) {
+    if (dist && !dist_combined) {
       const size_t slice = h->Wd.cap / (size_t)h->cfg.world_size, off = (size_t)h->cfg.rank * slice;
       TRY(lane_fork(h));       // the side lane waits for dE
       TRY(adam_dense(h, T_ADAM_D, h->Wd, h->Wd.g, aslot, h->cfg.d_reg, regD ? regWd : nullptr, 1, off, slice));
@@ -857,7 +865,11 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
         wpair = true;
       }
     }
-    if (!dist && !wpair) TRY(gemm_gWd());
+    if ((!dist && !wpair) || dist_combined) TRY(gemm_gWd());
+    if (dist_combined) {
+      TRY(lane_fork(h));       // the side lane waits for gWd_ext (and for dE, summed in the same launch)
+      TRY(dp_update(h, T_ADAM_D, h->Wd, aslot, h->cfg.d_reg, regD ? regWd : nullptr, 1));
+    }
     if (!wpair) {  // gWe_ext = [X;F | 1]^T . dE       -> rows 0..N-1 = gWe, row N = gbe
       GemmP g{};
       g.A = h->XF; g.lda = h->ldN; g.B = h->dE; g.ldb = h->lde;
@@ -871,6 +883,8 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
       TRY(run_gemm(h, T_GEMM_GWE, T_RED_GWE, g, true, true, &regn[0], fused ? 24.0 * h->We.count() : 0, 0, wg_tune));
     }
   } else {
+    // (ranks with rows join inside step_front; the previous step's encoder update may still be reducing We.g on the side lane)
+    TRY(dp_join(h));
     HIP_TRY(hipMemsetAsync(h->gD, 0, h->gD_elems * sizeof(float), h->st));
     if (dist) {   // same collective order as the ranks that have rows
       TRY(lane_fork(h));
@@ -932,9 +946,57 @@ int gen_update(ganmf_handle* h, int nb, int start, int b_global, int* regn_v, fl
     if (!fused) *regn_v = ADAM_GRID;
     return 0;
   };
-  if (dist) {
-    // data-parallel: gV first; its reduce-scatter runs on the side lane under gUb (which reads the OLD V), the Adam slice
-    // and the all-gather of V under the all-rows Adam pass over U
+  // gUb and gV in ONE launch (pair_kernel): both read dF.  Single GPU: gUb reads the old V while gV's Adam epilogue writes the
+  // new V into the second buffer, swapped in afterwards.  Data-parallel: gV is stored (it must be reduced before its Adam), V is
+  // not touched inside the launch.  Only when both are planned onto the 16-wave fp32 ring kernel.
+  bool paired = false;
+  if (nb > 0 && (fused || dist) && (h->multi & 2) && h->defer_gub && h->V_alt) {
+    if (dist) TRY(dp_join(h));
+    GemmP g0{}, g1{};
+    g0.A = h->dF; g0.lda = h->ldN; g0.B = h->V.p; g0.ldb = h->ldk;
+    g0.C = h->gUb; g0.ldc = h->ldk; g0.M = nb; g0.N = k; g0.K = N; g0.epi.kind = EPI_STORE; g0.nbatch = 1;
+    g0.zero_page = h->zero_page; g0.a_scale = grad_scale(h, b_global);
+    g1.A = h->dF; g1.lda = h->ldN; g1.B = h->Ub; g1.ldb = h->ldk;
+    g1.C = h->V.g; g1.ldc = h->ldk; g1.M = N; g1.N = k; g1.K = nb; g1.nbatch = 1;
+    g1.zero_page = h->zero_page; g1.a_scale = grad_scale(h, b_global);
+    g1.epi.kind = EPI_STORE;
+    if (fused) {
+      g1.epi.kind = EPI_ADAM; g1.epi.adam_theta = h->V.p; g1.epi.adam_theta_out = h->V_alt; g1.epi.adam_m = h->V.m; g1.epi.adam_v = h->V.v;
+      g1.epi.adam_alpha = h->scal + S_ALPHA_G; g1.epi.adam_reg = h->cfg.g_reg;
+      g1.epi.sq_partials = reg ? reg_v : nullptr;
+    }
+    GemmPlan p0 = gemm_plan(g0.M, g0.N, g0.K, 1, false, h->tune);
+    GemmPlan p1 = gemm_plan(g1.M, g1.N, g1.K, 1, g1.epi.sq_partials != nullptr, h->tune, true);
+    if (plan_is_f32_64_kg(p0, 4) && plan_is_f32_64_kg(p1, 4) && p1.nsplit == 1 &&
+        reduce_groups((long long)g0.M * ((g0.N + 3) >> 2), p0.nsplit) == 1) {
+      if (p0.nsplit > 1) {
+        TRY(ensure_slab(h, gemm_slab_elems(p0, g0.M, g0.ldc, 1), 1));
+        g0.C = h->slab2; g0.c_split_stride = (long long)g0.M * g0.ldc;
+        gub = SlabRef{h->slab2, p0.nsplit, (long long)g0.M * g0.ldc};
+      }
+      g0.c_batch_stride = (long long)g0.M * g0.ldc;
+      fill_plan(g0, p0);
+      fill_plan(g1, p1);
+      if (fused) *regn_v = p1.sq_count;
+      const int n0 = p0.tiles_m * p0.tiles_n * p0.nsplit, n1 = p1.tiles_m * p1.tiles_n;
+      {
+        Scope s(h, T_PAIR, gemm_flops(g0.M, g0.N, g0.K) + gemm_flops(g1.M, g1.N, g1.K),
+                gemm_bytes(g0.M, g0.N, g0.K) + gemm_bytes(g1.M, g1.N, g1.K) + (fused ? 24.0 * h->V.count() : 0));
+        if (h->pair_ring == 2) GANMF_LAUNCH((pair_kernel<4, 2>), dim3(n0 + n1), dim3(1024), 0, h->st, g0, g1);
+        else GANMF_LAUNCH((pair_kernel<4, 3>), dim3(n0 + n1), dim3(1024), 0, h->st, g0, g1);
+        HIP_TRY(hipGetLastError());
+      }
+      if (fused) std::swap(h->V.p, h->V_alt);
+      paired = true;
+    }
+  }
+  if (dist && paired) {
+    // the whole update of V on the side lane, under the all-rows Adam pass over U (which reads neither V nor its gradient)
+    TRY(lane_fork(h));
+    TRY(dp_update(h, T_ADAM_V, h->V, S_ALPHA_G, h->cfg.g_reg, reg ? reg_v : nullptr, 1));
+  } else if (dist) {
+    // data-parallel, separate launches: gV first; its reduce-scatter runs on the side lane under gUb (which reads the OLD V),
+    // the Adam slice and the all-gather of V under the all-rows Adam pass over U
     TRY(dp_join(h));
     if (nb > 0) TRY(gemm_gV());
     else HIP_TRY(hipMemsetAsync(h->V.g, 0, h->V.cap * sizeof(float), h->st));
@@ -946,45 +1008,6 @@ int gen_update(ganmf_handle* h, int nb, int start, int b_global, int* regn_v, fl
     TRY(adam_dense(h, T_ADAM_V, h->V, h->V.g, S_ALPHA_G, h->cfg.g_reg, reg ? reg_v : nullptr, 1, off, slice));
     TRY(all_gather(h, h->V.p, h->V.cap, 1));
   } else if (nb > 0) {
-    bool paired = false;
-    if (fused && (h->multi & 2) && h->defer_gub && h->V_alt) {
-      // gUb and gV in ONE launch (pair_kernel): both read dF; gUb reads the old V while gV's Adam epilogue writes the new V
-      // into the second buffer, swapped in afterwards.  Only when both are planned onto the 16-wave fp32 ring kernel.
-      GemmP g0{}, g1{};
-      g0.A = h->dF; g0.lda = h->ldN; g0.B = h->V.p; g0.ldb = h->ldk;
-      g0.C = h->gUb; g0.ldc = h->ldk; g0.M = nb; g0.N = k; g0.K = N; g0.epi.kind = EPI_STORE; g0.nbatch = 1;
-      g0.zero_page = h->zero_page; g0.a_scale = grad_scale(h, b_global);
-      g1.A = h->dF; g1.lda = h->ldN; g1.B = h->Ub; g1.ldb = h->ldk;
-      g1.C = h->V.g; g1.ldc = h->ldk; g1.M = N; g1.N = k; g1.K = nb; g1.nbatch = 1;
-      g1.zero_page = h->zero_page; g1.a_scale = grad_scale(h, b_global);
-      g1.epi.kind = EPI_ADAM; g1.epi.adam_theta = h->V.p; g1.epi.adam_theta_out = h->V_alt; g1.epi.adam_m = h->V.m; g1.epi.adam_v = h->V.v;
-      g1.epi.adam_alpha = h->scal + S_ALPHA_G; g1.epi.adam_reg = h->cfg.g_reg;
-      g1.epi.sq_partials = reg ? reg_v : nullptr;
-      GemmPlan p0 = gemm_plan(g0.M, g0.N, g0.K, 1, false, h->tune);
-      GemmPlan p1 = gemm_plan(g1.M, g1.N, g1.K, 1, g1.epi.sq_partials != nullptr, h->tune, true);
-      if (plan_is_f32_64_kg(p0, 4) && plan_is_f32_64_kg(p1, 4) && p1.nsplit == 1 &&
-          reduce_groups((long long)g0.M * ((g0.N + 3) >> 2), p0.nsplit) == 1) {
-        if (p0.nsplit > 1) {
-          TRY(ensure_slab(h, gemm_slab_elems(p0, g0.M, g0.ldc, 1), 1));
-          g0.C = h->slab2; g0.c_split_stride = (long long)g0.M * g0.ldc;
-          gub = SlabRef{h->slab2, p0.nsplit, (long long)g0.M * g0.ldc};
-        }
-        g0.c_batch_stride = (long long)g0.M * g0.ldc;
-        fill_plan(g0, p0);
-        fill_plan(g1, p1);
-        *regn_v = p1.sq_count;
-        const int n0 = p0.tiles_m * p0.tiles_n * p0.nsplit, n1 = p1.tiles_m * p1.tiles_n;
-        {
-          Scope s(h, T_PAIR, gemm_flops(g0.M, g0.N, g0.K) + gemm_flops(g1.M, g1.N, g1.K),
-                  gemm_bytes(g0.M, g0.N, g0.K) + gemm_bytes(g1.M, g1.N, g1.K) + 24.0 * h->V.count());
-          if (h->pair_ring == 2) GANMF_LAUNCH((pair_kernel<4, 2>), dim3(n0 + n1), dim3(1024), 0, h->st, g0, g1);
-          else GANMF_LAUNCH((pair_kernel<4, 3>), dim3(n0 + n1), dim3(1024), 0, h->st, g0, g1);
-          HIP_TRY(hipGetLastError());
-        }
-        std::swap(h->V.p, h->V_alt);
-        paired = true;
-      }
-    }
     if (!paired) {
       TRY(gemm_gUb());
       TRY(gemm_gV());      // fused: Adam(V) in the epilogue, after gUb has read the old V
@@ -1456,6 +1479,7 @@ static int create_impl(const ganmf_cfg* cfg, ganmf_handle* h) {
   h->pair_ring = env_int("GANMF_PAIR_RING", 2) == 3 ? 3 : 2;
   h->inkernel_reduce = env_int("GANMF_INKERNEL_REDUCE", 0) != 0;   // measured slower than the chip-wide reduce kernel
   h->inlaunch_max = env_int("GANMF_INLAUNCH_MAX", 4);
+  h->force_coll = env_int("GANMF_FORCE_COLLECTIVES", 0) != 0;
   TRY(dalloc((float**)&h->counters, COUNTER_CAP));
   TRY(dalloc((float**)&h->counters2, COUNTER_CAP));
   const int U = h->U, N = h->N, k = h->k, e = h->e, B = h->B;
@@ -1647,6 +1671,11 @@ static int copy_view(ganmf_handle* h, int tensor_id, int slot, float* host, int6
   View v;
   if (!h || !host || !find_view(h, tensor_id, &v)) return fail(-1, "%s: unknown tensor id %d", who, tensor_id);
   if (n != (int64_t)v.rows * v.cols) return fail(-1, "%s: tensor %d has %lld elements, got %lld", who, tensor_id, (long long)v.rows * v.cols, (long long)n);
+  // data-parallel runs keep the Adam moments of a REPLICATED tensor sharded: rank r updates slice r only (dp_update), the other
+  // slices of its m / v buffers are stale.  Reading or writing them through one rank would silently give a different optimizer.
+  if ((slot == GANMF_SLOT_ADAM_M || slot == GANMF_SLOT_ADAM_V) && h->has_comm && h->cfg.world_size > 1 && tensor_id != GANMF_T_USER_EMB)
+    return fail(-1, "%s: the Adam moments of replicated tensor %d are sharded over the %d ranks of a data-parallel run "
+                    "(each rank holds its slice only); only user_embeddings' moments are whole on their rank", who, tensor_id, h->cfg.world_size);
   HIP_TRY(hipSetDevice(h->dev));
   HIP_TRY(hipStreamSynchronize(h->st));
   for (int i = 0; i < v.nseg; ++i) {
@@ -1690,6 +1719,12 @@ int ganmf_set_adam_powers(ganmf_handle* h, const float in4[4]) {
 int ganmf_train_epoch(ganmf_handle* h, const int32_t* perm, int64_t n, int32_t d_steps, int32_t g_steps,
                       int64_t n_steps_per_pass, const int32_t* global_batch_rows, float* d_losses,
                       float* g_losses) {
+  return ganmf_train_epoch_ragged(h, perm, n, d_steps, g_steps, n_steps_per_pass, global_batch_rows, nullptr, d_losses, g_losses);
+}
+
+int ganmf_train_epoch_ragged(ganmf_handle* h, const int32_t* perm, int64_t n, int32_t d_steps, int32_t g_steps,
+                             int64_t n_steps_per_pass, const int32_t* global_batch_rows,
+                             const int32_t* local_batch_rows, float* d_losses, float* g_losses) {
   if (!h || (!perm && n > 0)) return fail(-1, "ganmf_train_epoch: null argument");
   if (!h->has_urm) return fail(-1, "ganmf_train_epoch: ganmf_set_urm_csr has not been called");
   if (n < 0 || n > h->U) return fail(-1, "ganmf_train_epoch: n=%lld out of range", (long long)n);
@@ -1702,9 +1737,28 @@ int ganmf_train_epoch(ganmf_handle* h, const int32_t* perm, int64_t n, int32_t d
   auto since = [&]() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tp0).count(); };
   double t_prep = 0, t_first = 0, t_enq = 0, t_sync = 0;
   const int B = h->B;
-  const int64_t local_steps = (n + B - 1) / B;
+  const int64_t local_steps = local_batch_rows ? n_steps_per_pass : (n + B - 1) / B;
   const int64_t per_pass = std::max(local_steps, n_steps_per_pass);
   if (per_pass == 0) return 0;
+  // slice i = rows [slice_at[i], slice_at[i] + slice_nb[i]) of the permutation
+  std::vector<int64_t> slice_at(per_pass);
+  std::vector<int> slice_nb(per_pass);
+  {
+    int64_t at = 0;
+    for (int64_t i = 0; i < per_pass; ++i) {
+      int nb;
+      if (local_batch_rows) {
+        nb = local_batch_rows[i];
+        if (nb < 0 || nb > B || at + nb > n) return fail(-1, "ganmf_train_epoch_ragged: local_batch_rows[%lld]=%d (batch_size %d, %lld of %lld rows used)", (long long)i, nb, B, (long long)at, (long long)n);
+      } else {
+        nb = (int)std::max<int64_t>(0, std::min<int64_t>(B, n - i * B));
+        at = std::min<int64_t>(i * B, n);
+      }
+      slice_at[i] = at; slice_nb[i] = nb;
+      at += nb;
+    }
+    if (local_batch_rows && at != n) return fail(-1, "ganmf_train_epoch_ragged: local_batch_rows sum to %lld, n = %lld", (long long)at, (long long)n);
+  }
   // the permutation and its inverse go up from ONE pinned staging buffer in one asynchronous copy, the loss parts come back
   // into pinned memory: pageable copies are staged synchronously by the runtime, ~0.1 ms per epoch call that a 10-slice call
   // (2.6 ms of GPU work) notices
@@ -1721,8 +1775,7 @@ int ganmf_train_epoch(ganmf_handle* h, const int32_t* perm, int64_t n, int32_t d
   }
   std::vector<int> bglob(per_pass);
   for (int64_t i = 0; i < per_pass; ++i) {
-    const int64_t a = i * B;
-    const int nb = (int)std::max<int64_t>(0, std::min<int64_t>(B, n - a));
+    const int nb = slice_nb[i];
     bglob[i] = global_batch_rows ? global_batch_rows[i] : nb;
     if (bglob[i] < nb || bglob[i] < 1) return fail(-1, "ganmf_train_epoch: global_batch_rows[%lld]=%d < local %d", (long long)i, bglob[i], nb);
   }
@@ -1734,15 +1787,15 @@ int ganmf_train_epoch(ganmf_handle* h, const int32_t* perm, int64_t n, int32_t d
   int64_t idx = 0;
   for (int p = 0; p < d_steps; ++p)
     for (int64_t i = 0; i < per_pass; ++i, ++idx) {
-      const int64_t a = i * B;
-      const int nb = (int)std::max<int64_t>(0, std::min<int64_t>(B, n - a));
+      const int64_t a = slice_at[i];
+      const int nb = slice_nb[i];
       TRY(any_d_step(h, h->perm + std::min<int64_t>(a, std::max<int64_t>(n - 1, 0)), nb, bglob[i], idx));
     }
   idx = 0;
   for (int p = 0; p < g_steps; ++p)
     for (int64_t i = 0; i < per_pass; ++i, ++idx) {
-      const int64_t a = i * B;
-      const int nb = (int)std::max<int64_t>(0, std::min<int64_t>(B, n - a));
+      const int64_t a = slice_at[i];
+      const int nb = slice_nb[i];
       TRY(any_g_step(h, h->perm + std::min<int64_t>(a, std::max<int64_t>(n - 1, 0)), nb, (int)a, bglob[i], idx));
     }
   TRY(dp_join(h));      // the last step's side-lane updates (and their sum(theta^2) partials) are complete

@@ -28,9 +28,21 @@ namespace ganmf {
 struct PersistP {
   int xb_m, xb_n;        // XCD blocking of the tile grid: xb_m * xb_n == 8
   int wgs_per_xcd;       // gridDim.x / 8
-  int diag;              // timing-only experiments (GANMF_PERSIST_DIAG; wrong results): 1 no C stores, 2 no staging dump,
-                         // 4 no K-tile refills after the prologue
+  int diag;              // timing-only experiments (wrong results): 1 no C stores, 2 no staging dump, 4 no K-tile refills after
+                         // the prologue, 256 in-kernel stamps.  Only in a library built with -DGANMF_PERSIST_DIAG_BUILD
+                         // (make DIAG=1): the shipped library ignores the GANMF_PERSIST_DIAG environment variable.
 };
+
+#ifdef GANMF_PERSIST_DIAG_BUILD
+#define PERSIST_DIAG_BIT(q, bit) (((q).diag & (bit)) != 0)
+inline int persist_diag_bits() {
+  const char* dg = getenv("GANMF_PERSIST_DIAG");
+  return dg ? atoi(dg) : 0;
+}
+#else
+#define PERSIST_DIAG_BIT(q, bit) (false)
+inline int persist_diag_bits() { return 0; }
+#endif
 
 // A float4 from LDS through a __restrict__ parameter.  hipcc's waitcnt pass puts `s_waitcnt vmcnt(0)` in front of every
 // LDS read that MAY alias an LDS-DMA in flight; a read whose pointer carries alias-scope metadata (what inlining a
@@ -140,7 +152,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_f32_persist(const GemmP p
   int sto[2];
   bool sth[2] = {false, false};
   auto piece_read = [&](int k) {          // stage register k <- next piece (nothing if none is pending)
-    if (q.diag & 1) { st_next = NPIECE; return; }     // timing only
+    if PERSIST_DIAG_BIT(q, 1) { st_next = NPIECE; return; }     // timing only
     if (st_next < NPIECE) {
       const int row_l = tr + st_next * RPP;
       const int row = st_m0 + row_l, col = st_n0 + tc * 4;
@@ -184,7 +196,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_f32_persist(const GemmP p
   int cur_l = j, kstep = 0;        // compute side: local tile index and K-step inside it
   auto refill_chunk = [&](auto cc) {
     constexpr int c = decltype(cc)::value;
-    if (pend_kleft > 0 && !(q.diag & 4)) {
+    if (pend_kleft > 0 && !PERSIST_DIAG_BIT(q, 4)) {
       float* base = smem + pend_slot * BUF;
       constexpr int q0 = c * PPC < LOADS ? c * PPC : LOADS, q1 = (c + 1) * PPC < LOADS ? (c + 1) * PPC : LOADS;
       constexpr int a0 = q0 < SA::NP ? q0 : SA::NP, a1 = q1 < SA::NP ? q1 : SA::NP;
@@ -196,7 +208,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_f32_persist(const GemmP p
   int stamp_i = 0;
   auto step = [&](auto tail_tag) {
     constexpr bool TAIL = decltype(tail_tag)::value;
-    if ((q.diag & 256) && p.counters && (blockIdx.x == 0 || blockIdx.x == 101) && tid == 0 && stamp_i < 60)
+    if (PERSIST_DIAG_BIT(q, 256) && p.counters && (blockIdx.x == 0 || blockIdx.x == 101) && tid == 0 && stamp_i < 60)
       reinterpret_cast<unsigned long long*>(p.counters)[(blockIdx.x ? 64 : 0) + stamp_i++] = __builtin_amdgcn_s_memtime();
     const float* __restrict__ cur = smem + slot * BUF;
     const int nslot = (slot + 1 == NS) ? 0 : slot + 1;
@@ -236,7 +248,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_f32_persist(const GemmP p
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
       }
-      if (!(q.diag & 2))
+      if (!PERSIST_DIAG_BIT(q, 2))
 #pragma unroll
       for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -294,7 +306,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_persist2(const GemmP p, const
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
   const int li = lane & 31, lh = lane >> 5;
-  const bool stamping = (q.diag & 256) && p.counters && (blockIdx.x == 0 || blockIdx.x == 101) && tid == 0;
+  const bool stamping = PERSIST_DIAG_BIT(q, 256) && p.counters && (blockIdx.x == 0 || blockIdx.x == 101) && tid == 0;
   unsigned long long* stamps = reinterpret_cast<unsigned long long*>(p.counters) + (blockIdx.x ? 64 : 0);
   if (stamping) stamps[60] = __builtin_amdgcn_s_memtime();
 
@@ -388,7 +400,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_persist2(const GemmP p, const
   int sto[2];
   bool sth[2] = {false, false};
   auto piece_read = [&](int k) {   // float4 number tid + 256 k of the staged unit: patch (wave that dumped it), row, 16-byte column
-    if (rd_valid && !(q.diag & 1)) {
+    if (rd_valid && !PERSIST_DIAG_BIT(q, 1)) {
       const int idx = tid + 256 * k;
       const int patch = idx >> 7, prow = (idx >> 3) & 15, c4 = idx & 7;
       const int a = rd_unit >> 2, b = (rd_unit >> 1) & 1, h = rd_unit & 1;
@@ -454,11 +466,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_persist2(const GemmP p, const
   };
   int stamp_i = 0;
   for (int s = 0; s < total; ++s) {
-    if ((q.diag & 256) && p.counters && (blockIdx.x == 0 || blockIdx.x == 101) && tid == 0 && stamp_i < 60)
+    if (PERSIST_DIAG_BIT(q, 256) && p.counters && (blockIdx.x == 0 || blockIdx.x == 101) && tid == 0 && stamp_i < 60)
       reinterpret_cast<unsigned long long*>(p.counters)[(blockIdx.x ? 64 : 0) + stamp_i++] = __builtin_amdgcn_s_memtime();
     const float* __restrict__ cur = smem + slot * BUF;
     const int nslot = slot ^ 1;
-    const bool dumping = ds_unit < UNITS && !(q.diag & 2);
+    const bool dumping = ds_unit < UNITS && !PERSIST_DIAG_BIT(q, 2);
     // chunk 0: read the first float4 of the unit dumped in the previous step
     load_frags(1, cur, 1);
     piece_read(0);
@@ -573,10 +585,9 @@ inline PersistPlan persist_plan(int M, int N, int K, int tile, int cus) {
 
 template <int BM, int BN, int BK, int NS, int WGM, int WGN>
 inline hipError_t gemm_persist_launch(hipStream_t st, const GemmP& p, bool akm, bool bkm, const PersistPlan& pp) {
-  const char* dg = getenv("GANMF_PERSIST_DIAG");
-  PersistP q{pp.xb_m, pp.xb_n, pp.grid / 8, dg ? atoi(dg) : 0};
+  PersistP q{pp.xb_m, pp.xb_n, pp.grid / 8, persist_diag_bits()};
   if (akm || bkm) return hipErrorInvalidValue;     // only the NT product (scores) takes this route
-  if (q.diag & 256) {      // diagnostic build path: per-K-step s_memtime stamps of two workgroups, printed after the launch
+  if PERSIST_DIAG_BIT(q, 256) {      // diagnostic build path: per-K-step s_memtime stamps of two workgroups, printed after the launch
     static unsigned long long* dbg = nullptr;
     if (!dbg) { if (hipMalloc((void**)&dbg, 128 * 8) != hipSuccess) return hipErrorOutOfMemory; }
     (void)hipMemset(dbg, 0, 128 * 8);
@@ -619,9 +630,8 @@ inline hipError_t gemm_dispatch_persist(hipStream_t st, const GemmP& p, bool akm
   // default: two persistent 4-wave workgroups per CU
   if (akm || bkm) return hipErrorInvalidValue;
   const PersistPlan p2 = persist_plan(p.M, p.N, p.K, 128, 2 * GEMM_CUS);
-  const char* dg = getenv("GANMF_PERSIST_DIAG");
-  PersistP q{p2.xb_m, p2.xb_n, p2.grid / 8, dg ? atoi(dg) : 0};
-  if (q.diag & 256) {      // diagnostic: per-K-step s_memtime stamps of two workgroups, printed after the launch
+  PersistP q{p2.xb_m, p2.xb_n, p2.grid / 8, persist_diag_bits()};
+  if PERSIST_DIAG_BIT(q, 256) {      // diagnostic: per-K-step s_memtime stamps of two workgroups, printed after the launch
     static unsigned long long* dbg = nullptr;
     if (!dbg) { if (hipMalloc((void**)&dbg, 128 * 8) != hipSuccess) return hipErrorOutOfMemory; }
     (void)hipMemset(dbg, 0, 128 * 8);

@@ -96,6 +96,20 @@ class Engine:
                 "ganmf_train_epoch")
         return dl[:d_steps * per_pass], gl[:g_steps * per_pass]
 
+    def train_epoch_ragged(self, perm, local_batch_rows, global_batch_rows, d_steps=1, g_steps=1):
+        """Slices of given sizes (ganmf_train_epoch_ragged): slice i = the next local_batch_rows[i] rows of `perm`, part of a
+        global minibatch of global_batch_rows[i] rows (row-sharded fit(), ganmf_amd/dist.py)."""
+        perm = np.ascontiguousarray(perm, dtype=np.int32)
+        lb = np.ascontiguousarray(local_batch_rows, dtype=np.int32)
+        gb = np.ascontiguousarray(global_batch_rows, dtype=np.int32)
+        assert lb.size == gb.size and int(lb.sum()) == perm.size
+        per_pass = lb.size
+        dl = np.zeros(max(d_steps * per_pass, 1), dtype=np.float32)
+        gl = np.zeros(max(g_steps * per_pass, 1), dtype=np.float32)
+        L.check(self.lib.ganmf_train_epoch_ragged(self.h, _i32p(perm), perm.size, d_steps, g_steps, per_pass, _i32p(gb),
+                                                  _i32p(lb), _f32p(dl), _f32p(gl)), "ganmf_train_epoch_ragged")
+        return dl[:d_steps * per_pass], gl[:g_steps * per_pass]
+
     def train_step(self, kind, uids):
         u = np.ascontiguousarray(uids, dtype=np.int32)
         loss = C.c_float()
@@ -184,6 +198,10 @@ class Engine:
     def comm_init_local(self, group_id):
         """join the in-process loopback communicator `group_id` (all world_size engines of this process must)"""
         L.check(self.lib.ganmf_comm_init_local(self.h, int(group_id)), "ganmf_comm_init_local")
+
+    def comm_unique_id(self):
+        """128 bytes rank 0 hands to every rank's comm_init (ganmf_comm_unique_id)"""
+        return comm_unique_id()
 
     def comm_init(self, id_bytes):
         arr = (C.c_uint8 * 128).from_buffer_copy(bytes(id_bytes))

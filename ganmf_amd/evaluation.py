@@ -14,6 +14,8 @@ Every user contributes the same weight; values are means over the evaluated user
 `RankedListMetrics` computes all of them for one list in one pass over the hit positions.  Where the reference's
 evaluator works in float32 (hit counts divided in float32, the DCG sums, and therefore its running sums) this one
 does too, so that the two agree to the last digits on the reference's golden outputs (tests/test_evaluator.py)."""
+import itertools
+
 import numpy as np
 import scipy.sparse as sps
 
@@ -158,6 +160,9 @@ class EvaluatorHoldout(object):
         return results, get_result_string(results)
 
 
+_DEVICE_TOKENS = itertools.count(1)
+
+
 class EvaluatorHoldoutFast(EvaluatorHoldout):
     """Same protocol and result dictionaries as EvaluatorHoldout (Evaluator.py:214-414), but consumes only the
     top-`max_cutoff` ids of each user — `recommender.recommend_topk(...)` when the recommender has it (device
@@ -190,6 +195,9 @@ class EvaluatorHoldoutFast(EvaluatorHoldout):
         self._test_sorted.sort_indices()
         self._test_gain = np.power(2.0, self._test_sorted.data.astype(np.float32)).astype(np.float64) - 1.0
         self.use_device_metrics = True
+        # identifies THIS evaluator's test matrix on the device (never reused, unlike id(): CPython hands the id of a freed
+        # evaluator to the next one, and a recommender keyed on it would score the new evaluator against the old test matrix)
+        self._device_token = next(_DEVICE_TOKENS)
 
     def _topk(self, rec, batch):
         K = self.max_cutoff
@@ -211,8 +219,21 @@ class EvaluatorHoldoutFast(EvaluatorHoldout):
         inv_rank = 1.0 / np.arange(1, K + 1, dtype=np.float64)
         if self.use_device_metrics and n_eval > 0 and hasattr(recommender_object, "evaluate_on_device"):
             # everything on the device: scores, seen mask, top-k AND the metric sums (only len(cutoffs) x 9 doubles come back)
-            dev = recommender_object.evaluate_on_device(id(self), self._test_sorted, self._test_gain, self._users, self.cutoff_list,
-                                                        self._disc, self._ideal_cum, remove_seen_flag=self.exclude_seen)
+            # in user blocks: the device forms a [block, n_items] score matrix (+ block x K doubles) per call, the same cap as
+            # the host routes; the [cutoffs, 9] partial sums are added here in block order.  Out of device memory -> host route.
+            dev = None
+            try:
+                for start in range(0, n_eval, max(1, int(1e8 / self.n_items))):
+                    sl = slice(start, min(start + max(1, int(1e8 / self.n_items)), n_eval))
+                    part = recommender_object.evaluate_on_device(self._device_token, self._test_sorted, self._test_gain,
+                                                                 self._users[sl], self.cutoff_list, self._disc,
+                                                                 self._ideal_cum[sl], remove_seen_flag=self.exclude_seen)
+                    if part is None:
+                        dev = None
+                        break
+                    dev = part if dev is None else dev + part
+            except MemoryError:
+                dev = None
             if dev is not None:
                 from ._lib import EVAL_METRICS
                 for ci, c in enumerate(self.cutoff_list):

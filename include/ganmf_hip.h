@@ -107,7 +107,11 @@ int ganmf_set_urm_csr(ganmf_handle* h, const int64_t* indptr, const int32_t* ind
                       const float* data, int64_t n_rows, int64_t n_cols);
 
 /* Replaces sess.run(var) / sess.run(var.assign(x)) on one variable (GANMF.py:294-302,
- * Utils_.py:292-294,305-310).  `n` must equal the tensor's element count (row-major, unpadded). */
+ * Utils_.py:292-294,305-310).  `n` must equal the tensor's element count (row-major, unpadded).
+ * Data-parallel handles (communicator attached, world_size > 1): the Adam moments (GANMF_SLOT_ADAM_M / _V) of the
+ * REPLICATED tensors (item_embeddings and every discriminator tensor) live sharded over the ranks -- rank r updates
+ * slice r only -- so these two slots are rejected (-1) for them; parameters and the best snapshot are whole and identical
+ * on every rank, and user_embeddings (rank-owned rows) is whole in every slot. */
 int ganmf_set_tensor(ganmf_handle* h, int tensor_id, int slot, const float* host, int64_t n);
 int ganmf_get_tensor(ganmf_handle* h, int tensor_id, int slot, float* host, int64_t n);
 int ganmf_tensor_shape(ganmf_handle* h, int tensor_id, int64_t* rows, int64_t* cols);
@@ -129,6 +133,18 @@ int ganmf_set_adam_powers(ganmf_handle* h, const float in4[4]);
 int ganmf_train_epoch(ganmf_handle* h, const int32_t* perm, int64_t n, int32_t d_steps,
                       int32_t g_steps, int64_t n_steps_per_pass, const int32_t* global_batch_rows,
                       float* d_losses, float* g_losses);
+
+/* The same pass with slices of GIVEN sizes: slice i takes the next local_batch_rows[i] rows of `perm`
+ * (0 <= local_batch_rows[i] <= batch_size, their sum == n, n_steps_per_pass entries), global_batch_rows[i]
+ * (>= local_batch_rows[i], >= 1) as above.  This is how a row-sharded fit() replays the REFERENCE's minibatch
+ * schedule (GANMF.py:175-203) on several GPUs: every global minibatch of the single shuffled permutation is
+ * split by row owner, so rank r's i-th slice is "the rows of global minibatch i that rank r owns" -- a variable
+ * count -- and the union over ranks is exactly the minibatch the reference would have drawn
+ * (ganmf_amd/dist.py split_by_owner).  Loss arrays hold d_steps * n_steps_per_pass resp. g_steps * n_steps_per_pass
+ * floats.  Blocking. */
+int ganmf_train_epoch_ragged(ganmf_handle* h, const int32_t* perm, int64_t n, int32_t d_steps, int32_t g_steps,
+                             int64_t n_steps_per_pass, const int32_t* global_batch_rows,
+                             const int32_t* local_batch_rows, float* d_losses, float* g_losses);
 
 /* Single updates on an explicit id list (same arithmetic as inside ganmf_train_epoch); used by
  * tests and by callers that schedule batches themselves.  kind: 0 = D-step, 1 = G-step. */

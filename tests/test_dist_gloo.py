@@ -1,8 +1,9 @@
 """The data-parallel decomposition (ganmf_amd/dist.py + the per-rank arithmetic of the C++
 d_step/g_step) checked on CPU with torch.distributed gloo, world_size 2: each rank computes the
 oracle's gradients on its own rows with the GLOBAL batch size in the loss scales, gradients of
-replicated tensors are all-reduced, and the result must equal the single-process oracle on the
-union batch."""
+replicated tensors are all-reduced (or reduce-scattered, updated slice-wise and all-gathered), and the
+result of a discriminator pass AND a generator pass -- item_embeddings' slice update, the rank-owned rows of
+user_embeddings -- must equal the single-process oracle on the union batches."""
 import os
 import sys
 
@@ -33,7 +34,7 @@ def _worker(rank, world, port, out, sliced=False):
     rng = np.random.RandomState(0)
     U, N, k, e, B = 23, 31, 4, 6, 8
     X = (rng.rand(U, N) < 0.2).astype(np.float64)
-    hp = dict(d_lr=1e-3, g_lr=1e-3, d_reg=1e-3, g_reg=0.0, m=10.0, recon_coefficient=0.1)
+    hp = dict(d_lr=1e-3, g_lr=1e-3, d_reg=1e-3, g_reg=1e-3, m=10.0, recon_coefficient=0.1)
     full = GANMFOracle(U, N, k, e, dtype=np.float64, seed=4, **hp)
     bounds = shard_bounds(U, world)
     lo, hi = bounds[rank]
@@ -91,13 +92,55 @@ def _worker(rank, world, port, out, sliced=False):
         full.d_step(union, X[union])
     for n in loc.D_NAMES:
         np.testing.assert_allclose(loc.p[n], full.p[n], rtol=1e-9, atol=1e-12)
+    # ---- the generator pass over the SAME slices (GANMF.py:191-203; ganmf_hip.hip g_step / gen_update): every rank forms
+    # dF for its own rows with the GLOBAL batch size in both scales; gV is summed over ranks (all-reduce, or reduce-scatter
+    # -> Adam on the rank's slice of V -> all-gather); the rows of U belong to their rank and are never communicated -- the
+    # all-rows TF update (App. B.5: non-batch rows decay their moments and still move) runs on the local rows only.
+    alpha, g_reg = hp["recon_coefficient"], hp["g_reg"]
+    for i in range(steps):
+        rows = np.arange(i * B, min((i + 1) * B, hi - lo))
+        Bg, nb = int(grows[i]), len(rows)
+        gV = np.zeros_like(loc.p["V"])
+        gU = g_reg * loc.p["U"]
+        if nb:
+            Xb = X[lo:hi][rows]
+            Ub = loc.p["U"][rows]
+            F = Ub @ loc.p["V"].T
+            Er = Xb @ loc.p["We"] + loc.p["be"]
+            Ef, df, _ = loc.autoencoder(F)
+            dR = ((1 - alpha) * 2.0 / (Bg * N)) * df
+            dE = dR @ loc.p["Wd"].T + (alpha * 2.0 / (Bg * e)) * (Ef - Er)
+            dF = dE @ loc.p["We"].T - dR
+            gV = dF.T @ Ub
+            gU[rows] += dF @ loc.p["V"]           # reads the OLD V
+        if not sliced:
+            t = torch.from_numpy(gV); dist.all_reduce(t)
+            loc.opt_g.apply_dense("V", loc.p["V"], t.numpy() + g_reg * loc.p["V"])
+        else:
+            flat = loc.p["V"].reshape(-1)
+            slice_n = -(-flat.size // world)
+            gpad = np.zeros(slice_n * world); gpad[:flat.size] = gV.reshape(-1)
+            ppad = np.zeros(slice_n * world); ppad[:flat.size] = flat
+            t = torch.from_numpy(gpad); dist.all_reduce(t)
+            sl = slice(rank * slice_n, (rank + 1) * slice_n)
+            mine = ppad[sl].copy()
+            loc.opt_g.apply_dense("V", mine, t.numpy()[sl] + g_reg * mine)
+            parts = [torch.zeros(slice_n, dtype=torch.float64) for _ in range(world)]
+            dist.all_gather(parts, torch.from_numpy(mine))
+            loc.p["V"][...] = torch.cat(parts).numpy()[:flat.size].reshape(loc.p["V"].shape)
+        loc.opt_g.apply_sparse_all_rows("U", loc.p["U"], gU)
+        loc.opt_g.finish()
+        union = np.concatenate([np.arange(a + i * B, min(a + (i + 1) * B, b)) for a, b in bounds])
+        full.g_step(union, X[union])
+    np.testing.assert_allclose(loc.p["V"], full.p["V"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(loc.p["U"], full.p["U"][lo:hi], rtol=1e-9, atol=1e-12)      # rank-owned rows
     dist.barrier()
     dist.destroy_process_group()
     out.put((rank, "ok"))
 
 
 @pytest.mark.parametrize("sliced", [False, True])
-def test_sharded_d_steps_equal_union_batch_gloo(sliced):
+def test_sharded_d_and_g_steps_equal_union_batch_gloo(sliced):
     """sliced = False: all-reduce + replicated Adam; True: reduce-scatter / Adam on the rank's slice / all-gather (what the
     library runs since round 2).  Both must equal the single-process oracle on the union batches."""
     import torch.multiprocessing as mp

@@ -220,12 +220,22 @@ def test_snapshot_restore_and_errors():
     eng.close()
 
 
-def test_rccl_path_single_rank_matches_plain():
-    """The data-parallel code path (RCCL all-reduce of the hinge sums, of the D gradients and of gV,
-    presummed d_coef, per-epoch loss all-reduce) with a 1-rank communicator must reproduce the plain
-    single-GPU path bit for bit."""
+@pytest.mark.parametrize("shape", ["small", "c2"])
+@pytest.mark.parametrize("force_collectives", [False, True])
+def test_rccl_path_single_rank_matches_plain(monkeypatch, force_collectives, shape):
+    """The data-parallel code path (RCCL all-reduce of the hinge sums, reduce-scatter of the D gradients and of gV, Adam on
+    the rank's slice, all-gather of the parameters, presummed d_coef, per-epoch loss all-reduce) with a 1-rank communicator
+    must reproduce the plain single-GPU path bit for bit.  force_collectives: GANMF_FORCE_COLLECTIVES=1 makes the one-rank
+    communicator ISSUE its in-place ncclReduceScatter / ncclAllGather calls (they are skipped at world_size 1 otherwise),
+    so the RCCL call sites of ganmf_hip.hip reduce_scatter() / all_gather() execute on this one-GPU box.  shape "c2": the
+    BASELINE configs[1] shape, where the data-parallel step takes the combined launches (de_dcoef_kernel, gWd + slab sum of
+    dE, gUb + gV)."""
     from ganmf_amd.engine import Engine, comm_unique_id
-    U, N, k, e, B = 150, 210, 9, 17, 32
+    if force_collectives:
+        monkeypatch.setenv("GANMF_FORCE_COLLECTIVES", "1")
+    else:
+        monkeypatch.delenv("GANMF_FORCE_COLLECTIVES", raising=False)
+    U, N, k, e, B = (150, 210, 9, 17, 32) if shape == "small" else (700, 3706, 250, 992, 128)
     rng = np.random.RandomState(5)
     urm = _rand_urm(rng, U, N, 0.08)
     o = GANMFOracle(U, N, k, e, seed=4, **HP)

@@ -105,19 +105,20 @@ def test_disganmf_ml1m_full_training(golden_dir, mode):
     assert -0.025 <= vals.mean() - pub <= 0.01, (vals.mean(), pub)
 
 
-@pytest.mark.parametrize("case", ["ganmf_ml1m_user", "disganmf_ml1m_user", "ganmf_hetrec_item", "ganmf_lastfm_user"])
+@pytest.mark.parametrize("case", ["ganmf_ml1m_user", "ganmf_hetrec_item", "ganmf_lastfm_user"])
 def test_hip_matches_oracle_end_to_end(golden_dir, case):
     """The HIP path against the numpy oracle's OWN full training run (oracle/run_end_to_end.py, committed as
     tests/golden/oracle_end_to_end.json): same hyper-parameters, same initial weights (RandomState(1337) draws in the
     same tensor order), same minibatch schedule.  Per-step agreement is tested elsewhere at 1e-4; over 10^4 chaotic
     updates the two fp32 trajectories separate, so the end-to-end comparison is on the metrics and the factor norms:
-    GANMF within 0.004 on every metric @5 and on MAP@10/20/50 (the published row sits inside the same band).  DisGANMF's
-    trajectory is chaotic enough that two fp32 implementations with different summation orders are two DRAWS of one
-    distribution -- the eight-initialisation test above measures its spread, MAP@5 0.115 .. 0.150 -- so the band there is
-    that spread, 0.035 (after the late round-2 kernel changes the HIP run of seed 1337 moved from 0.129 to 0.150, the
-    published row is 0.148, the numpy oracle's run 0.135; the per-step agreement that pins the arithmetic is
-    tests/test_gpu_disganmf.py, the reference-held pin tests/test_gpu_trial_logs.py; tools/chaos_check.py shows two builds that
-    agree bit for bit after one D and one G step 26 % apart element-wise in U after 20 epochs, with equal norms and losses)."""
+    GANMF within 0.004 on every metric @5 and on MAP@10/20/50 (the published row sits inside the same band) and 1 % on the
+    factor norms.  DisGANMF is NOT held to its oracle run end to end: over 10^4 updates its trajectory is chaotic enough that
+    two fp32 implementations with different summation orders are two draws of one distribution (tools/chaos_check.py), and
+    a band as wide as that distribution cannot fail.  Its arithmetic is pinned per step (tests/test_gpu_disganmf.py), over
+    200 updates at the configs[4] shape with a stated tolerance per horizon (tests/test_gpu_trajectory.py), by the
+    reference's 100 logged trials (tests/test_gpu_trial_logs.py) and as a distribution over initialisations
+    (test_disganmf_ml1m_full_training above); the oracle's own DisGANMF run is held to the published row and the measured
+    spread in tests/test_oracle_pin.py."""
     fx = json.load(open(os.path.join(golden_dir, "oracle_end_to_end.json")))
     if case not in fx:
         pytest.skip("oracle run %s not committed" % case)
@@ -132,7 +133,8 @@ def test_hip_matches_oracle_end_to_end(golden_dir, case):
     model = cls(train, mode=o["mode"], seed=o["seed"], is_experiment=True)
     model.fit(validation_set=None, sample_every=None, validation_evaluator=None, **o["best_params"])
     res, _ = EvaluatorHoldoutFast(test, [5, 10, 20, 50]).evaluateRecommender(model)
-    tol = 0.004 if o["model"] == "GANMF" else 0.035
+    assert o["model"] == "GANMF"
+    tol = 0.004
     ref = o["oracle_metrics"]
     print("%s: HIP MAP@5 %.4f NDCG@5 %.4f | oracle %.4f %.4f | published %.4f %.4f" % (
         case, res[5]["MAP"], res[5]["NDCG"], ref["5"]["MAP"], ref["5"]["NDCG"], o["published_at5"]["MAP"], o["published_at5"]["NDCG"]))
@@ -140,8 +142,7 @@ def test_hip_matches_oracle_end_to_end(golden_dir, case):
         assert abs(res[5][metric] - ref["5"][metric]) <= tol, (metric, res[5][metric], ref["5"][metric])
     for c in (10, 20, 50):
         assert abs(res[c]["MAP"] - ref[str(c)]["MAP"]) <= tol, (c, res[c]["MAP"], ref[str(c)]["MAP"])
-    # DisGANMF: |U| of the eight initialisations spreads 21.1 .. 25.4 around the oracle run's 23.05 (tools/chaos_check.py norms)
-    norm_tol = 0.01 if o["model"] == "GANMF" else 0.12
+    norm_tol = 0.01
     for name, got in (("U", model.user_factors()), ("V", model.item_factors())):
         want = o["factor_norms"][name]
         assert abs(np.linalg.norm(got.astype(np.float64)) - want) <= norm_tol * want, (name, np.linalg.norm(got), want)
@@ -150,28 +151,37 @@ def test_hip_matches_oracle_end_to_end(golden_dir, case):
 
 def test_ml1m_user_feature_matching_ablation(golden_dir):
     """The paper's feature-matching ablation on ML-1M user mode, every point trained with the parameters the reference
-    tuned for it: alpha in {0, .2, .4, .6, .8, 1} (feature_matching/GANMF_user_1M_*).  +-0.01 on MAP@5 per point and the
-    published shape of the curve: alpha = 0 (no feature matching) collapses to less than 60 % of any other point.
-    The alpha = 0.2 point (20 epochs at d_lr 2.4e-3, g_lr 1.5e-3) is bimodal across initialisations — 0.287, 0.349,
-    0.215, 0.352 over seeds 1337, 1, 2, 3 — and the published 0.3474 is its upper mode: that point takes the better of
-    two seeds."""
+    tuned for it: alpha in {0, .2, .4, .6, .8, 1} (feature_matching/GANMF_user_1M_*).  +-0.01 on MAP@5 per point at seed 1337
+    and the published shape of the curve: alpha = 0 (no feature matching) collapses to less than 60 % of any other point.
+    The alpha = 0.2 point (20 epochs at d_lr 2.4e-3, g_lr 1.5e-3: the largest learning rates of the six) is bimodal across
+    initialisations, so it is tested as a DISTRIBUTION over eight seeds, like DisGANMF above: the published 0.3474 (one run
+    of the configuration that won the search: expected in the upper mode) must lie inside [min - 0.01, max + 0.01] of the
+    eight runs, and at least two of the eight must land within 0.01 of it (an upper mode exists; it is not one lucky seed)."""
     from ganmf_amd.GANMF import GANMF
     from ganmf_amd.evaluation import EvaluatorHoldoutFast
     abl = json.load(open(os.path.join(golden_dir, "statistical_kat_ml1m_user_ablations.json")))
     train = sps.load_npz(os.path.join(golden_dir, "Movielens1M_URM_train.npz")).tocsr()
     test = sps.load_npz(os.path.join(golden_dir, "Movielens1M_URM_test.npz")).tocsr()
     ev = EvaluatorHoldoutFast(test, [5])
+
+    def run(point, seed):
+        np.random.seed(seed)
+        model = GANMF(train, mode="user", seed=seed, is_experiment=True)
+        model.fit(validation_set=None, sample_every=None, validation_evaluator=None, **point["best_params"])
+        v = ev.evaluateRecommender(model)[0][5]["MAP"]
+        model.engine.close()
+        return v
     got = {}
     for name, point in abl.items():
-        vals = []
-        for seed in ((1337, 1) if name == "feature_matching_02" else (1337,)):
-            np.random.seed(seed)
-            model = GANMF(train, mode="user", seed=seed, is_experiment=True)
-            model.fit(validation_set=None, sample_every=None, validation_evaluator=None, **point["best_params"])
-            vals.append(ev.evaluateRecommender(model)[0][5]["MAP"])
-            model.engine.close()
-        got[name] = max(vals)
+        if name == "feature_matching_02":
+            continue
+        got[name] = run(point, 1337)
         print("%-24s MAP@5 %.4f (published %.4f)" % (name, got[name], point["published_map5"]))
-    for name, point in abl.items():
         assert abs(got[name] - point["published_map5"]) <= 0.01, (name, got[name], point["published_map5"])
-    assert got["feature_matching_00"] < 0.6 * min(v for k, v in got.items() if not k.endswith("_00"))
+    p02 = abl["feature_matching_02"]
+    vals = np.array([run(p02, seed) for seed in (1337, 1, 2, 3, 4, 5, 6, 7)])
+    pub = p02["published_map5"]
+    print("feature_matching_02 over 8 seeds: %s  (published %.4f)" % (np.round(vals, 4), pub))
+    assert vals.min() - 0.01 <= pub <= vals.max() + 0.01, (vals, pub)
+    assert np.sum(np.abs(vals - pub) <= 0.01) >= 2, (vals, pub)
+    assert got["feature_matching_00"] < 0.6 * min(min(v for k, v in got.items() if not k.endswith("_00")), vals.max())

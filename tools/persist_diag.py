@@ -1,4 +1,6 @@
-"""Timing-only decomposition of the persistent scoring GEMM (GANMF_PERSIST_DIAG bits; results are wrong by design)."""
+"""Timing-only decomposition of the persistent scoring GEMM (GANMF_PERSIST_DIAG bits; results are wrong by design).
+Needs a diagnostic build of the library: `make -C ganmf_amd/csrc clean && make -C ganmf_amd/csrc DIAG=1`; the shipped
+library ignores the variable."""
 import os
 import sys
 
