@@ -159,6 +159,7 @@ struct ganmf_handle {
   hipStream_t st = nullptr;
   hipStream_t st2 = nullptr;             // side lane: independent kernels overlap the main lane
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_mid = nullptr;
+  hipEvent_t ev_we = nullptr, ev_wd = nullptr;   // data-parallel: "the side lane has finished updating We / Wd" (dp_mark / dp_join)
   int U = 0, N = 0, k = 0, e = 0, B = 0;
   int ldN = 0, ldk = 0, lde = 0;
   // DisGANMF (model 1): hidden layers W_l_ext and the output unit; see the DisGANMF section below
@@ -177,6 +178,12 @@ struct ganmf_handle {
   long long nnz = 0;
   bool has_urm = false;
   bool sparse_g = false;   // generator steps take the real rows' encodings from a CSR row-sum (no densify of X)
+  bool sparse_d = false;   //               discriminator steps too: Er from the CSR rows, X subtracted from the reconstruction through a CSR
+                           //               lookup in the decode epilogue, X^T.dE_r added to the encoder gradient from the CSC matrix
+  long long* csc_colptr = nullptr;   // CSC form of the same matrix (sparse_d): column j = the rows that store item j, ascending
+  int* csc_rowidx = nullptr;
+  float* csc_val = nullptr;
+  float* sp_rows = nullptr;          // [N + CSC_BIAS_PARTS, lde]: X^T . dE_r of the step in flight (csc_rows_kernel)
   // epoch schedule
   int* perm = nullptr;      // [2U] device: the epoch's permutation, then (pos = perm + U) its inverse
   int* pos = nullptr;
@@ -241,7 +248,9 @@ struct ganmf_handle {
   bool has_comm = false;
   std::shared_ptr<LocalGroup> local;   // in-process loopback communicator (ganmf_comm_init_local)
   int d_alpha = S_ALPHA_D;             // scalar slot holding lr_t of the discriminator step in flight (alternates in data-parallel runs)
-  bool side_pending = false;           // data-parallel: the side lane still updates replicated tensors (dp_join before their next use)
+  int side_pending = 0;                // data-parallel: PEND_* bits of the replicated tensors the side lane still updates (dp_join
+                                       // before their next use on the main lane)
+  bool fork_attach = true;             // GANMF_FORK_ATTACH: forks ride on the producing kernel's completion event (fork_arm / fork_wait)
   bool force_coll = false;             // GANMF_FORCE_COLLECTIVES=1: a one-rank communicator still issues its (in-place) reduce-scatter /
                                        // all-gather calls, so that the RCCL call sites execute on a one-GPU box (tests, bench)
   // tuning knobs (environment: GANMF_TILE, GANMF_RING, GANMF_NSPLIT; 0 = cost model decides)
@@ -577,6 +586,23 @@ int lane_fork(ganmf_handle* h) {
   HIP_TRY(hipStreamWaitEvent(h->st2, h->ev_fork, 0));
   return 0;
 }
+// The same fork in two halves around the LAST main-lane launch the side lane has to wait for: fork_arm() before it (that launch
+// then carries ev_fork as its completion event: no marker packet on the main lane), fork_wait() after it.  While the library's
+// profiler is on (its scopes hand their own events to the launches) and with GANMF_FORK_ATTACH=0 the plain fork is used.
+bool fork_arm(ganmf_handle* h) {
+  if (!h->fork_attach || h->prof) return false;
+  launch_stop_event() = h->ev_fork;
+  return true;
+}
+int fork_wait(ganmf_handle* h, bool armed) {
+  if (!armed) return lane_fork(h);
+  if (launch_stop_event() != nullptr) {      // nothing was launched in between (a plan without a kernel): plain fork
+    launch_stop_event() = nullptr;
+    return lane_fork(h);
+  }
+  HIP_TRY(hipStreamWaitEvent(h->st2, h->ev_fork, 0));
+  return 0;
+}
 // join: the main lane continues after everything enqueued so far on the side lane
 int lane_join(ganmf_handle* h) {
   HIP_TRY(hipEventRecord(h->ev_join, h->st2));
@@ -584,11 +610,24 @@ int lane_join(ganmf_handle* h) {
   return 0;
 }
 
-// the main lane may not touch We / Wd / V again before the side lane's reduce-scatter / Adam / all-gather are done
-int dp_join(ganmf_handle* h) {
-  if (!h->side_pending) return 0;
-  h->side_pending = false;
-  return lane_join(h);
+// The main lane may not touch We / Wd again before the side lane's reduce-scatter / Adam / all-gather on them are done.
+// dp_mark: everything enqueued on the side lane so far completes the update of the tensors in `mask`; dp_join: the main lane
+// waits for the tensors in `mask` that are still pending -- the encoder before the next encode GEMM, the decoder only before the
+// next decode GEMM, one encode GEMM later (the side lane is in order: the decoder's event implies the encoder's).
+enum : int { PEND_WE = 1, PEND_WD = 2, PEND_ALL = 3 };
+int dp_mark(ganmf_handle* h, int mask) {
+  if (mask & PEND_WE) HIP_TRY(hipEventRecord(h->ev_we, h->st2));
+  if (mask & PEND_WD) HIP_TRY(hipEventRecord(h->ev_wd, h->st2));
+  h->side_pending |= mask;
+  return 0;
+}
+int dp_join(ganmf_handle* h, int mask = PEND_ALL) {
+  const int m = h->side_pending & mask;
+  if (!m) return 0;
+  if (m & PEND_WE) HIP_TRY(hipStreamWaitEvent(h->st, h->ev_we, 0));
+  if (m & PEND_WD) HIP_TRY(hipStreamWaitEvent(h->st, h->ev_wd, 0));
+  h->side_pending &= ~m;
+  return 0;
 }
 
 int adam_dense(ganmf_handle* h, int tag, Tensor& t, const float* g, int alpha_idx, float reg, float* sq, int lane = 0,
@@ -662,14 +701,13 @@ int rows_and_generator(ganmf_handle* h, const int* rows_dev, int nb, int which, 
 int step_front(ganmf_handle* h, const int* rows_dev, int nb, int which) {
   const int N = h->N, k = h->k, e = h->e;
   const int aslot = which ? S_ALPHA_G : h->d_alpha;
-  if (which == 1 && h->sparse_g) {
-    // sparse regime, generator step: Er from the CSR rows, X never materialised, the encode GEMM runs on the generated
-    // half only
-    TRY(dp_join(h));
+  if ((which == 1 && h->sparse_g) || (which == 0 && h->sparse_d)) {
+    // sparse regime: Er from the CSR rows, X never materialised, the encode GEMM runs on the generated half only
+    TRY(dp_join(h, PEND_WE));
     {
       Scope s(h, T_DENSIFY, 0, 4.0 * nb * (2 * k + e) + 4.0 * (double)h->nnz / std::max(h->U, 1) * nb * e);
       GANMF_LAUNCH(sparse_front_kernel, dim3(nb), dim3(256), 0, h->st, h->indptr, h->indices, h->data, rows_dev, nb, N,
-                         h->XF, h->ldN, h->Ue.p, h->ldk, h->Ub, h->scal, which, aslot, h->cfg.g_lr, h->We.p, h->lde, e, h->E);
+                         h->XF, h->ldN, h->Ue.p, h->ldk, h->Ub, h->scal, which, aslot, which ? h->cfg.g_lr : h->cfg.d_lr, h->We.p, h->lde, e, h->E);
       HIP_TRY(hipGetLastError());
     }
     {
@@ -680,7 +718,7 @@ int step_front(ganmf_handle* h, const int* rows_dev, int nb, int which) {
       TRY(run_gemm(h, T_GEMM_GEN, T_RED_GEN, g, false, false));
     }
     {
-      TRY(dp_join(h));
+      TRY(dp_join(h, PEND_WE));
       GemmP g{};
       g.A = h->XF + (size_t)nb * h->ldN; g.lda = h->ldN; g.B = h->We.p; g.ldb = h->lde;
       g.C = h->E + (size_t)nb * h->lde; g.ldc = h->lde; g.M = nb; g.N = e; g.K = N + 1; g.epi.kind = EPI_STORE;
@@ -690,7 +728,7 @@ int step_front(ganmf_handle* h, const int* rows_dev, int nb, int which) {
   }
   TRY(rows_and_generator(h, rows_dev, nb, which, aslot, -1, 0));   // X rows, Ub, F = Ub . V^T -> rows [nb, 2nb) of XF  (GANMF.py:82-83)
   {  // E = [X;F | 1] . We_ext  (bias = row N); the ones column E[:, e] is never overwritten  (GANMF.py:64-65)
-    TRY(dp_join(h));     // (data-parallel: the previous step's encoder update ran on the side lane under densify + generator GEMM)
+    TRY(dp_join(h, PEND_WE));     // (data-parallel: the previous step's encoder update ran on the side lane under densify + generator GEMM)
     GemmP g{};
     g.A = h->XF; g.lda = h->ldN; g.B = h->We.p; g.ldb = h->lde;
     g.C = h->E; g.ldc = h->lde; g.M = 2 * nb; g.N = e; g.K = N + 1; g.epi.kind = EPI_STORE;
@@ -713,6 +751,7 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
   int regn[2] = {ADAM_GRID, ADAM_GRID};
   if (nb > 0) {
     TRY(step_front(h, rows_dev, nb, 0));
+    TRY(dp_join(h, PEND_WD));      // (data-parallel: the previous step's decoder update ran under this step's front and encode GEMM)
     {  // Delta = [E|1].Wd_ext - inp, per-path sum of squares  (GANMF.py:66-68), batch z = path
       GemmP g{};
       g.A = h->E; g.lda = h->lde; g.B = h->Wd.p; g.ldb = h->ldN;
@@ -720,6 +759,9 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
       g.nbatch = 2; g.a_batch_stride = (long long)nb * h->lde; g.c_batch_stride = (long long)nb * h->ldN;
       g.epi.kind = EPI_SUB_AUX_SQ; g.epi.aux = h->XF; g.epi.ldaux = h->ldN;
       g.epi.aux_batch_stride = (long long)nb * h->ldN; g.epi.sq_partials = h->sqp;
+      if (h->sparse_d) {      // the real rows were never expanded: X[m, n] is looked up in the CSR rows of the batch
+        g.epi.csr_indptr = h->indptr; g.epi.csr_indices = h->indices; g.epi.csr_data = h->data; g.epi.csr_rows = rows_dev;
+      }
       TRY(run_gemm(h, T_GEMM_DEC, T_RED_DEC, g, false, true, &sqn, 4.0 * 2 * nb * N));
     }
   } else {
@@ -782,6 +824,22 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
     // the data-parallel path runs the same two GEMMs with a plain store epilogue: same tile, split and arithmetic,
     // so that it stays bitwise equal to the fused single-GPU path (tests/test_gpu_parity.py, one-rank RCCL)
     const GemmTune* wg_tune = &ft;
+    // sparse regime: the encoder-gradient GEMM runs over the generated rows only (A = F, B = dE_f, K = nb); the real rows' share
+    // X^T . dE_r (and the bias row's column sums of dE_r) is added in its epilogue from the CSC matrix, before Adam / the store
+    const int start = (int)(rows_dev - h->perm);      // position of this batch in the epoch permutation (pos[] is its inverse)
+    auto sparse_gWe = [&](GemmP& g) {
+      if (!h->sparse_d) return;
+      g.A = h->XF + (size_t)nb * h->ldN; g.B = h->dE + (size_t)nb * h->lde; g.K = nb;
+      g.epi.sp_rows = h->sp_rows; g.epi.sp_ld = h->lde; g.epi.sp_bias_row = N; g.epi.sp_bias_parts = CSC_BIAS_PARTS;
+    };
+    auto sparse_rows = [&]() -> int {      // S = X^T . dE_r (+ the bias parts): dE must be final
+      if (!h->sparse_d) return 0;
+      Scope s(h, T_DENSIFY, 0, 4.0 * ((double)h->nnz / std::max(h->U, 1) * nb * e + 2.0 * (N + CSC_BIAS_PARTS) * e));
+      GANMF_LAUNCH(csc_rows_kernel, dim3(N + CSC_BIAS_PARTS), dim3(256), 0, h->st, h->csc_colptr, h->csc_rowidx, h->csc_val,
+                   h->pos, start, nb, N, h->dE, h->lde, e, h->sp_rows);
+      HIP_TRY(hipGetLastError());
+      return 0;
+    };
     RedP dE_red{};                  // single GPU: the slab sum of dE rides in the gWd launch (gWd does not read dE, gWe does)
     auto gemm_gWd = [&]() -> int {  // gWd_ext = (rs*[E|1])^T . Delta   -> rows 0..e-1 = gWd, row e = gbd
       GemmP g{};
@@ -796,18 +854,12 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
       return run_gemm(h, T_GEMM_GWD, T_RED_GWD, g, true, true, &regn[1], fused ? 24.0 * h->Wd.count() : 0, 0, wg_tune, nullptr,
                       nullptr, dE_red.part ? &dE_red : nullptr);
     };
-    // Data-parallel, combined launches (default): dE's slabs exist already (de_dcoef_kernel), so the chain is the single-GPU one
-    // with stored gradients -- [gWd_ext + slab sum of dE] in one launch, then the decoder's reduce-scatter / Adam slice /
-    // all-gather on the side lane under the gWe_ext GEMM (dE has read the old decoder by then), the encoder's behind them under
-    // the next step's row expansion + generator GEMM.
-    // Data-parallel without the combined launches (GANMF_MULTI): the decoder gradient is produced first; its reduce-scatter runs
-    // on the side lane under the dE GEMM, its Adam slice + all-gather (which overwrite Wd) under the gWe_ext GEMM.
-    const bool dist_combined = dist && dcoef_done;
-    if (dist && !dist_combined) {
-      TRY(gemm_gWd());
-      TRY(lane_fork(h));
-      TRY(reduce_scatter(h, h->Wd.g, h->Wd.cap, 1));
-    }
+    // Data-parallel: ONE order of collectives whatever this rank's row count or GEMM plans (ranks of a ragged step plan
+    // differently; a rank without rows issues the same sequence on zero gradients): encoder first -- the next step needs We one
+    // GEMM earlier than Wd.  dE (its slabs may exist already, de_dcoef_kernel) -> gWe_ext -> We's reduce-scatter / Adam slice /
+    // all-gather on the side lane under the gWd_ext GEMM and the next step's row expansion + generator GEMM (joined before its
+    // encode GEMM) -> gWd_ext -> Wd's behind them under that encode GEMM (joined before the decode GEMM; dE has read the old
+    // decoder long before).
     if (dcoef_done) {   // the slabs are there already: hand their sum (+ row scale) to the gWd launch
       dE_red = RedP{};
       dE_red.part = h->slab; dE_red.nsplit = pde.nsplit; dE_red.out = gde.C; dE_red.ld = gde.ldc; dE_red.M = gde.M; dE_red.N = gde.N;
@@ -824,12 +876,6 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
     // Weight-gradient GEMMs.  Single GPU: the gradient tile never leaves the CU -- the epilogue
     // applies TF-Adam to theta/m/v in place (after dE, which reads the old decoder).
     // Data-parallel: the gradients are stored, reduce-scattered, and each rank updates its slice (dp_update).
-    if (dist && !dist_combined) {
-      const size_t slice = h->Wd.cap / (size_t)h->cfg.world_size, off = (size_t)h->cfg.rank * slice;
-      TRY(lane_fork(h));       // the side lane waits for dE
-      TRY(adam_dense(h, T_ADAM_D, h->Wd, h->Wd.g, aslot, h->cfg.d_reg, regD ? regWd : nullptr, 1, off, slice));
-      TRY(all_gather(h, h->Wd.p, h->Wd.cap, 1));
-    }
     bool wpair = false;
     if (!dist && fused && (h->multi & 16) && dE_red.part) {
       // both weight-gradient products in ONE launch (wgrad_pair_kernel); the slab sum of dE, which gWe reads, gets its own
@@ -845,6 +891,7 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
       g1.b_scale = grad_scale(h, b_global);
       g1.epi.kind = EPI_ADAM; g1.epi.adam_theta = h->We.p; g1.epi.adam_m = h->We.m; g1.epi.adam_v = h->We.v;
       g1.epi.adam_alpha = h->scal + aslot; g1.epi.adam_reg = h->cfg.d_reg; g1.epi.sq_partials = regD ? regWe : nullptr;
+      sparse_gWe(g1);
       GemmPlan p0 = gemm_plan(g0.M, g0.N, g0.K, 1, regD, ft, true), p1 = gemm_plan(g1.M, g1.N, g1.K, 1, regD, ft, true);
       auto staged = [](const GemmPlan& pl) { return pl.mode == MFMA_BF16X3 && pl.tile == 64 && pl.bk == 32 && pl.nsplit == 1; };
       if (staged(p0) && staged(p1)) {
@@ -853,6 +900,7 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
           GANMF_LAUNCH(splitk_reduce_kernel, dim3(GEMM_RED_GRID, 1), dim3(256), 0, h->st, dE_red);
           HIP_TRY(hipGetLastError());
         }
+        TRY(sparse_rows());
         fill_plan(g0, p0);
         fill_plan(g1, p1);
         regn[1] = p0.sq_count; regn[0] = p1.sq_count;
@@ -865,12 +913,15 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
         wpair = true;
       }
     }
-    if ((!dist && !wpair) || dist_combined) TRY(gemm_gWd());
-    if (dist_combined) {
-      TRY(lane_fork(h));       // the side lane waits for gWd_ext (and for dE, summed in the same launch)
-      TRY(dp_update(h, T_ADAM_D, h->Wd, aslot, h->cfg.d_reg, regD ? regWd : nullptr, 1));
+    if (dist && dE_red.part) {     // (dcoef_done: the slabs of dE are waiting for their sum)
+      Scope s(h, T_RED_DE, 0, 4.0 * (dE_red.nsplit + 1) * dE_red.M * dE_red.N);
+      GANMF_LAUNCH(splitk_reduce_kernel, dim3(GEMM_RED_GRID, 1), dim3(256), 0, h->st, dE_red);
+      HIP_TRY(hipGetLastError());
+      dE_red.part = nullptr;      // (summed: nothing to attach to the gWd launch)
     }
+    if (!dist && !wpair) TRY(gemm_gWd());
     if (!wpair) {  // gWe_ext = [X;F | 1]^T . dE       -> rows 0..N-1 = gWe, row N = gbe
+      TRY(sparse_rows());
       GemmP g{};
       g.A = h->XF; g.lda = h->ldN; g.B = h->dE; g.ldb = h->lde;
       g.C = h->We.g; g.ldc = h->lde; g.M = N + 1; g.N = e; g.K = 2 * nb; g.epi.kind = EPI_STORE;
@@ -880,25 +931,37 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
         g.epi.adam_alpha = h->scal + aslot; g.epi.adam_reg = h->cfg.d_reg;
         g.epi.sq_partials = regD ? regWe : nullptr;
       }
+      sparse_gWe(g);
+      const bool armed = dist && fork_arm(h);
       TRY(run_gemm(h, T_GEMM_GWE, T_RED_GWE, g, true, true, &regn[0], fused ? 24.0 * h->We.count() : 0, 0, wg_tune));
+      if (dist) TRY(fork_wait(h, armed));       // the side lane waits for gWe_ext
+    }
+    if (dist) {
+      TRY(dp_update(h, T_ADAM_D, h->We, aslot, h->cfg.d_reg, regD ? regWe : nullptr, 1));
+      TRY(dp_mark(h, PEND_WE));
+      const bool armed = fork_arm(h);
+      TRY(gemm_gWd());
+      TRY(fork_wait(h, armed));       // ... and for gWd_ext
+      TRY(dp_update(h, T_ADAM_D, h->Wd, aslot, h->cfg.d_reg, regD ? regWd : nullptr, 1));
+      TRY(dp_mark(h, PEND_WD));
+      (void)regn; (void)parts;
+      return 0;
     }
   } else {
     // (ranks with rows join inside step_front; the previous step's encoder update may still be reducing We.g on the side lane)
     TRY(dp_join(h));
     HIP_TRY(hipMemsetAsync(h->gD, 0, h->gD_elems * sizeof(float), h->st));
-    if (dist) {   // same collective order as the ranks that have rows
+    if (dist) {   // same collective order as the ranks that have rows: encoder, then decoder
+      const bool regD = h->cfg.d_reg != 0.f;
       TRY(lane_fork(h));
-      TRY(dp_update(h, T_ADAM_D, h->Wd, aslot, h->cfg.d_reg, h->cfg.d_reg != 0.f ? regWd : nullptr, 1));
+      TRY(dp_update(h, T_ADAM_D, h->We, aslot, h->cfg.d_reg, regD ? regWe : nullptr, 1));
+      TRY(dp_mark(h, PEND_WE));
+      TRY(dp_update(h, T_ADAM_D, h->Wd, aslot, h->cfg.d_reg, regD ? regWd : nullptr, 1));
+      TRY(dp_mark(h, PEND_WD));
     }
   }
   const bool reg = h->cfg.d_reg != 0.f;
-  if (dist) {
-    // encoder: behind the decoder's collectives on the side lane; the main lane goes on with the next step's densify
-    // and generator GEMM (they read neither We nor Wd) and joins before its encode GEMM (dp_join)
-    TRY(lane_fork(h));
-    TRY(dp_update(h, T_ADAM_D, h->We, aslot, h->cfg.d_reg, reg ? regWe : nullptr, 1));
-    h->side_pending = true;
-  } else if (!fused) {
+  if (!dist && !fused) {
     TRY(adam_dense(h, T_ADAM_D, h->We, h->We.g, aslot, h->cfg.d_reg, reg ? regWe : nullptr));
     TRY(adam_dense(h, T_ADAM_D, h->Wd, h->Wd.g, aslot, h->cfg.d_reg, reg ? regWd : nullptr));
   }
@@ -949,7 +1012,7 @@ int gen_update(ganmf_handle* h, int nb, int start, int b_global, int* regn_v, fl
   // gUb and gV in ONE launch (pair_kernel): both read dF.  Single GPU: gUb reads the old V while gV's Adam epilogue writes the
   // new V into the second buffer, swapped in afterwards.  Data-parallel: gV is stored (it must be reduced before its Adam), V is
   // not touched inside the launch.  Only when both are planned onto the 16-wave fp32 ring kernel.
-  bool paired = false;
+  bool paired = false, pair_armed = false;
   if (nb > 0 && (fused || dist) && (h->multi & 2) && h->defer_gub && h->V_alt) {
     if (dist) TRY(dp_join(h));
     GemmP g0{}, g1{};
@@ -982,6 +1045,7 @@ int gen_update(ganmf_handle* h, int nb, int start, int b_global, int* regn_v, fl
       {
         Scope s(h, T_PAIR, gemm_flops(g0.M, g0.N, g0.K) + gemm_flops(g1.M, g1.N, g1.K),
                 gemm_bytes(g0.M, g0.N, g0.K) + gemm_bytes(g1.M, g1.N, g1.K) + (fused ? 24.0 * h->V.count() : 0));
+        pair_armed = dist && fork_arm(h);
         if (h->pair_ring == 2) GANMF_LAUNCH((pair_kernel<4, 2>), dim3(n0 + n1), dim3(1024), 0, h->st, g0, g1);
         else GANMF_LAUNCH((pair_kernel<4, 3>), dim3(n0 + n1), dim3(1024), 0, h->st, g0, g1);
         HIP_TRY(hipGetLastError());
@@ -992,7 +1056,7 @@ int gen_update(ganmf_handle* h, int nb, int start, int b_global, int* regn_v, fl
   }
   if (dist && paired) {
     // the whole update of V on the side lane, under the all-rows Adam pass over U (which reads neither V nor its gradient)
-    TRY(lane_fork(h));
+    TRY(fork_wait(h, pair_armed));
     TRY(dp_update(h, T_ADAM_V, h->V, S_ALPHA_G, h->cfg.g_reg, reg ? reg_v : nullptr, 1));
   } else if (dist) {
     // data-parallel, separate launches: gV first; its reduce-scatter runs on the side lane under gUb (which reads the OLD V),
@@ -1038,6 +1102,7 @@ int g_step(ganmf_handle* h, const int* rows_dev, int nb, int start, int b_global
   int sqn = 0, fmn = 0;
   if (nb > 0) {
     TRY(step_front(h, rows_dev, nb, 1));
+    TRY(dp_join(h, PEND_WD));
     {  // Delta_f = [Ef|1].Wd_ext - F, sum of squares
       GemmP g{};
       g.A = h->E + (size_t)nb * h->lde; g.lda = h->lde; g.B = h->Wd.p; g.ldb = h->ldN;
@@ -1468,9 +1533,15 @@ static int create_impl(const ganmf_cfg* cfg, ganmf_handle* h) {
                                                  // theta / m / v round trip of each other (33.6 / 28.8 us against 37.2 / 32.0 at 64)
   HIP_TRY(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
   HIP_TRY(hipStreamCreateWithFlags(&h->st2, hipStreamNonBlocking));
-  HIP_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-  HIP_TRY(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
-  HIP_TRY(hipEventCreateWithFlags(&h->ev_mid, hipEventDisableTiming));
+  // lane events order two streams of THIS device only: no system-scope fence when they are recorded (the cache write-back /
+  // invalidate a host-visible event performs showed as ~7 us of idle main lane per fork or join in the data-parallel step's
+  // rocprofv3 timeline, profiles/r03_dp_timeline.md; kernel boundaries keep their device-scope release / acquire)
+  const unsigned lane_flags = env_int("GANMF_LANE_EVENT_FENCE", 0) ? hipEventDisableTiming : (hipEventDisableTiming | hipEventDisableSystemFence);
+  HIP_TRY(hipEventCreateWithFlags(&h->ev_fork, lane_flags));
+  HIP_TRY(hipEventCreateWithFlags(&h->ev_join, lane_flags));
+  HIP_TRY(hipEventCreateWithFlags(&h->ev_mid, lane_flags));
+  HIP_TRY(hipEventCreateWithFlags(&h->ev_we, lane_flags));
+  HIP_TRY(hipEventCreateWithFlags(&h->ev_wd, lane_flags));
   h->fuse_adam = env_int("GANMF_FUSE_ADAM", 1) != 0;
   h->defer_gub = env_int("GANMF_DEFER_GUB", 1) != 0;
   h->multi = env_int("GANMF_MULTI", 31);
@@ -1480,6 +1551,7 @@ static int create_impl(const ganmf_cfg* cfg, ganmf_handle* h) {
   h->inkernel_reduce = env_int("GANMF_INKERNEL_REDUCE", 0) != 0;   // measured slower than the chip-wide reduce kernel
   h->inlaunch_max = env_int("GANMF_INLAUNCH_MAX", 4);
   h->force_coll = env_int("GANMF_FORCE_COLLECTIVES", 0) != 0;
+  h->fork_attach = env_int("GANMF_FORK_ATTACH", 1) != 0;
   TRY(dalloc((float**)&h->counters, COUNTER_CAP));
   TRY(dalloc((float**)&h->counters2, COUNTER_CAP));
   const int U = h->U, N = h->N, k = h->k, e = h->e, B = h->B;
@@ -1572,6 +1644,7 @@ int ganmf_destroy(ganmf_handle* h) {
   hipFree(h->dz0); hipFree(h->dz1); hipFree(h->dlogit);
   free_tensor(h->Ue, false); free_tensor(h->V, true); hipFree(h->V_alt);
   hipFree(h->gD); hipFree(h->indptr); hipFree(h->indices); hipFree(h->data); hipFree(h->perm);
+  hipFree(h->csc_colptr); hipFree(h->csc_rowidx); hipFree(h->csc_val); hipFree(h->sp_rows);
   if (h->stage_i) hipHostFree(h->stage_i);
   if (h->stage_f) hipHostFree(h->stage_f);
   hipFree(h->test_indptr); hipFree(h->test_indices); hipFree(h->test_gain); hipFree(h->eval_buf);
@@ -1584,6 +1657,8 @@ int ganmf_destroy(ganmf_handle* h) {
   if (h->ev_fork) hipEventDestroy(h->ev_fork);
   if (h->ev_join) hipEventDestroy(h->ev_join);
   if (h->ev_mid) hipEventDestroy(h->ev_mid);
+  if (h->ev_we) hipEventDestroy(h->ev_we);
+  if (h->ev_wd) hipEventDestroy(h->ev_wd);
   if (h->st2) hipStreamDestroy(h->st2);
   if (h->st) hipStreamDestroy(h->st);
   hipFree(h->slab2); hipFree(h->counters); hipFree(h->counters2);
@@ -1656,6 +1731,37 @@ int ganmf_set_urm_csr(ganmf_handle* h, const int64_t* indptr, const int32_t* ind
   const double density = (double)nnz / ((double)n_rows * (double)n_cols);
   const int force = env_int("GANMF_SPARSE", -1);
   h->sparse_g = h->cfg.model == GANMF_MODEL_GANMF && (force >= 0 ? force != 0 : density < 0.005);
+  // The discriminator step's sparse path trades 4.B.N.e dense FLOPs (real half of the encode GEMM and of the encoder-gradient
+  // GEMM) and the [B, N] row expansion for a CSR row-sum, a CSR lookup per residual element and a CSC walk per gradient element:
+  // it pays once those FLOPs are worth more than the few microseconds the lookups add to two epilogues (LastFM at the reference's
+  // defaults, B = 32, e = 32: 0.07 GFLOP -- dense; at its tuned B = 1024, e = 398: 28.7 GFLOP of a 146 GFLOP step -- sparse).
+  // GANMF_SPARSE_D = 0 / 1 overrides (GANMF_SPARSE = 0 switches both paths off).
+  const int force_d = env_int("GANMF_SPARSE_D", -1);
+  const double flops_saved = 4.0 * (double)h->B * (double)h->N * (double)h->e;
+  h->sparse_d = h->cfg.model == GANMF_MODEL_GANMF && force != 0 &&
+                (force_d >= 0 ? force_d != 0 : (density < 0.005 && flops_saved >= 2.0e9));
+  hipFree(h->csc_colptr); hipFree(h->csc_rowidx); hipFree(h->csc_val);
+  h->csc_colptr = nullptr; h->csc_rowidx = nullptr; h->csc_val = nullptr;
+  if (h->sparse_d) {      // counting sort by column; rows ascend inside a column because the CSR rows are walked in order
+    std::vector<long long> colptr((size_t)n_cols + 1, 0);
+    for (int64_t j = 0; j < nnz; ++j) ++colptr[(size_t)indices[j] + 1];
+    for (int64_t c = 0; c < n_cols; ++c) colptr[c + 1] += colptr[c];
+    std::vector<long long> fill(colptr.begin(), colptr.end() - 1);
+    std::vector<int> rowidx((size_t)std::max<int64_t>(nnz, 1));
+    std::vector<float> val((size_t)std::max<int64_t>(nnz, 1));
+    for (int64_t r = 0; r < n_rows; ++r)
+      for (int64_t j = indptr[r]; j < indptr[r + 1]; ++j) {
+        const long long at = fill[indices[j]]++;
+        rowidx[at] = (int)r; val[at] = data[j];
+      }
+    HIP_TRY(hipMalloc((void**)&h->csc_colptr, (size_t)(n_cols + 1) * sizeof(long long)));
+    HIP_TRY(hipMalloc((void**)&h->csc_rowidx, rowidx.size() * sizeof(int)));
+    HIP_TRY(hipMalloc((void**)&h->csc_val, val.size() * sizeof(float)));
+    HIP_TRY(hipMemcpy(h->csc_colptr, colptr.data(), (size_t)(n_cols + 1) * sizeof(long long), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->csc_rowidx, rowidx.data(), rowidx.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->csc_val, val.data(), val.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (!h->sp_rows) TRY(dalloc(&h->sp_rows, (size_t)(h->N + CSC_BIAS_PARTS) * h->lde));
+  }
   return 0;
 }
 

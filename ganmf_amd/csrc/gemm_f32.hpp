@@ -46,11 +46,17 @@ namespace ganmf {
 // and the launch gap take).  Outside profiling it is a plain hipLaunchKernelGGL.
 struct LaunchProf { hipEvent_t start = nullptr, stop = nullptr; int count = 0; };
 inline LaunchProf& launch_prof() { static thread_local LaunchProf lp; return lp; }
+// A stream fork without a marker packet: the NEXT launch carries this event as its completion ("stop") event, so another stream
+// can wait for exactly that kernel; recording an event behind the kernel instead puts a marker packet into the producing
+// stream, which showed as ~5 us of idle lane per fork in the data-parallel step's timeline (profiles/r03_dp_timeline.md).
+inline hipEvent_t& launch_stop_event() { static thread_local hipEvent_t ev = nullptr; return ev; }
 
 template <class F, class... Args>
 inline void launch_kernel(F kernel, const dim3& grid, const dim3& block, unsigned shmem, hipStream_t st, Args... args) {
   LaunchProf& lp = launch_prof();
+  hipEvent_t& stop = launch_stop_event();
   if (lp.start && lp.count++ == 0) hipExtLaunchKernelGGL(kernel, grid, block, shmem, st, lp.start, lp.stop, 0, args...);
+  else if (stop) { hipExtLaunchKernelGGL(kernel, grid, block, shmem, st, nullptr, stop, 0, args...); stop = nullptr; }
   else hipLaunchKernelGGL(kernel, grid, block, shmem, st, args...);
 }
 #define GANMF_LAUNCH(...) ::ganmf::launch_kernel(__VA_ARGS__)
@@ -181,7 +187,54 @@ struct EpiD {
   float* adam_v;
   const float* adam_alpha; // device scalar lr_t of the step in flight
   float adam_reg;          // gradient += adam_reg * theta  (the L2 term of the loss)
+  // ---- sparse-aware real path of the discriminator step (GANMF.py:183-187): the real rows X stay CSR
+  // EPI_SUB_AUX_SQ, batch 0 (the real path): the subtracted operand X[m, n] is looked up in the CSR rows of the batch
+  // (row m of the tile = CSR row csr_rows[m]; columns sorted inside a row) instead of a dense aux matrix -- subtracting 0.0f
+  // is exact, so the residual and its sum of squares equal the dense path's bit for bit.
+  const long long* csr_indptr;
+  const int* csr_indices;
+  const float* csr_data;
+  const int* csr_rows;
+  // EPI_ADAM / EPI_STORE of the encoder gradient gWe_ext = [X;F|1]^T . dE: the GEMM runs over the generated rows only and the real
+  // rows' contribution  S[j, :] = sum_b X[b, j] * dE_r[b, :]  -- formed beforehand by csc_rows_kernel (kernels.hpp) from the CSC form
+  // of the matrix, in a fixed order -- is added here, before Adam / the store.  Rows sp_bias_row .. sp_bias_row + sp_bias_parts - 1
+  // of S hold partial column sums of dE_r (the real rows' share of the encoder-bias gradient): added in index order to row
+  // sp_bias_row of the gradient.
+  const float* sp_rows;    // S [sp_bias_row + sp_bias_parts, sp_ld]; nullptr: dense path
+  int sp_ld, sp_bias_row, sp_bias_parts;
 };
+
+// X[batch row m, column col .. col + 3] of the CSR rows of the batch (EpiD::csr_*): lower bound on the sorted column indices
+__device__ inline float4 csr_quad(const EpiD& e, int m, int col) {
+  const int r = e.csr_rows[m];
+  long long lo = e.csr_indptr[r];
+  const long long en = e.csr_indptr[r + 1];
+  long long hi = en;
+  while (lo < hi) {
+    const long long mid = (lo + hi) >> 1;
+    if (e.csr_indices[mid] < col) lo = mid + 1; else hi = mid;
+  }
+  float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (long long j = lo; j < en; ++j) {
+    const int c = e.csr_indices[j] - col;
+    if (c > 3) break;
+    const float v = e.csr_data[j];
+    if (c == 0) x.x = v; else if (c == 1) x.y = v; else if (c == 2) x.z = v; else x.w = v;
+  }
+  return x;
+}
+
+// the real rows' share of gWe_ext[row, col .. col + 3] (EpiD::sp_rows)
+__device__ inline float4 sparse_rows_quad(const EpiD& e, int row, int col) {
+  if (row > e.sp_bias_row) return make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 s = *reinterpret_cast<const float4*>(e.sp_rows + (size_t)row * e.sp_ld + col);
+  if (row == e.sp_bias_row)
+    for (int q = 1; q < e.sp_bias_parts; ++q) {
+      const float4 d = *reinterpret_cast<const float4*>(e.sp_rows + (size_t)(row + q) * e.sp_ld + col);
+      s.x += d.x; s.y += d.y; s.z += d.z; s.w += d.w;
+    }
+  return s;
+}
 
 // TF ApplyAdam on one element (GANMF.py:104-105,138; training_ops ApplyAdam functor)
 __device__ inline void adam_update(float g, float alpha, float reg, float& th, float& m, float& v, float& sq) {
@@ -197,7 +250,7 @@ __device__ inline float epi_apply(const EpiD& e, float v, int row, int col, int 
                                   float& sq) {
   switch (e.kind) {
     case EPI_SUB_AUX_SQ:
-      v -= aux[(size_t)row * e.ldaux + col];
+      if (aux) v -= aux[(size_t)row * e.ldaux + col];      // (aux == nullptr: the CSR path subtracted already, csr_quad)
       sq += v * v;
       break;
     case EPI_SUB_SCALED_AUX:
@@ -439,7 +492,9 @@ __device__ inline void gemm_epilogue(const GemmP& p, const f32x16 (&acc)[TM][TN]
   float* __restrict__ C = p.C + (size_t)sp * p.c_split_stride + (size_t)bz * p.c_batch_stride;
   const bool deferred = p.nsplit > 1;
   const EpiD& e = p.epi;
-  const float* __restrict__ aux = e.aux ? e.aux + (size_t)bz * e.aux_batch_stride : nullptr;
+  const bool csr0 = e.csr_indptr != nullptr && bz == 0 && e.kind == EPI_SUB_AUX_SQ;      // the real path's X stays CSR
+  const float* __restrict__ aux = (e.aux && !csr0) ? e.aux + (size_t)bz * e.aux_batch_stride : nullptr;
+  const bool sp_add = !(p.nsplit > 1) && e.sp_rows != nullptr;      // gWe_ext: the real rows' share comes from the CSC matrix
   float sq = 0.f;
   constexpr int C4 = BN / 4, RPP = NTHR / C4;
   static_assert(BM % RPP == 0, "row pass must cover the tile in whole steps");
@@ -481,6 +536,10 @@ __device__ inline void gemm_epilogue(const GemmP& p, const f32x16 (&acc)[TM][TN]
             const float4 w = *reinterpret_cast<const float4*>(ct + g * (BM * BN) + row_l * BN + tc * 4);
             v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
           }
+          if (sp_add) {
+            const float4 x = sparse_rows_quad(e, row, col);
+            v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+          }
           const size_t off = (size_t)row * p.ldc + col;
           if (col + 3 < p.N) {
             adam_update(v.x, alpha, e.adam_reg, t4[jj].x, m4[jj].x, v4[jj].x, sq);
@@ -511,6 +570,14 @@ __device__ inline void gemm_epilogue(const GemmP& p, const f32x16 (&acc)[TM][TN]
       for (int g = 1; g < KG; ++g) {
         const float4 w = *reinterpret_cast<const float4*>(ct + g * (BM * BN) + row_l * BN + tc * 4);
         v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+      }
+      if (sp_add) {
+        const float4 x = sparse_rows_quad(e, row, col);
+        v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+      }
+      if (csr0 && !deferred) {
+        const float4 x = csr_quad(e, row, col);
+        v.x -= x.x; v.y -= x.y; v.z -= x.z; v.w -= x.w;
       }
       float o[4] = {v.x, v.y, v.z, v.w};
       if (adam) {   // the tile is a gradient: update parameter and moments in place (never stored)
@@ -594,6 +661,10 @@ __device__ inline void gemm_epilogue(const GemmP& p, const f32x16 (&acc)[TM][TN]
         for (int k = 1; k < p.nsplit; ++k) {
           const float4 q = *reinterpret_cast<const float4*>(slab + (size_t)k * p.c_split_stride + off);
           s4.x += q.x; s4.y += q.y; s4.z += q.z; s4.w += q.w;
+        }
+        if (csr0) {
+          const float4 x = csr_quad(e, row, col);
+          s4.x -= x.x; s4.y -= x.y; s4.z -= x.z; s4.w -= x.w;
         }
         float o[4] = {s4.x, s4.y, s4.z, s4.w};
         if (col + 3 < p.N) {
@@ -809,9 +880,14 @@ __device__ __forceinline__ void splitk_reduce_body(const RedP& p, const int bx, 
   const float* __restrict__ part = p.part + (size_t)bz * p.batch_stride;
   float* __restrict__ out = p.out + (size_t)bz * p.batch_stride;
   const EpiD& e = p.epi;
-  const float* __restrict__ aux = e.aux ? e.aux + (size_t)bz * e.aux_batch_stride : nullptr;
+  const bool csr0 = e.csr_indptr != nullptr && bz == 0 && e.kind == EPI_SUB_AUX_SQ;
+  const float* __restrict__ aux = (e.aux && !csr0) ? e.aux + (size_t)bz * e.aux_batch_stride : nullptr;
   float sq = 0.f;
   auto finish = [&](float4 s, int m, int c, size_t off) {
+    if (csr0) {
+      const float4 x = csr_quad(e, m, c);
+      s.x -= x.x; s.y -= x.y; s.z -= x.z; s.w -= x.w;
+    }
     float o[4] = {s.x, s.y, s.z, s.w};
     if (c + 3 < p.N) {
 #pragma unroll

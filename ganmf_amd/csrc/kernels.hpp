@@ -165,6 +165,62 @@ __global__ __launch_bounds__(256) void sparse_front_kernel(const long long* __re
   }
 }
 
+// SURVEY 8(f)-3, sparse-aware real path of the DISCRIMINATOR step: the real rows' share of the encoder gradient,
+//     S[j, :] = sum_{b < nb} X[b, j] * dE_r[b, :]          (gWe = X^T.dE_r + F^T.dE_f, GANMF.py:138; X = the batch's real rows)
+// from the CSC form of the WHOLE matrix (column j = the rows u that store item j, ascending): u is in this batch iff
+// start <= pos[u] < start + nb (pos = inverse of the epoch permutation), its batch row is pos[u] - start.  One workgroup per
+// column, 256 threads = G entry groups x W float4 columns; group g takes the column's entries g, g + G, ... in order and the
+// G partial sums meet in LDS in group order: no float atomics, the same sum on every run and every rank.  Columns without
+// batch rows get zeros (S needs no memset).  Workgroups ncols .. ncols + CSC_BIAS_PARTS - 1 write partial column sums of dE_r
+// (rows b = part, part + CSC_BIAS_PARTS, ...): the real rows' share of the encoder-BIAS gradient, added up by the consumer
+// (gemm_f32.hpp sparse_rows_quad).  The consumer is the epilogue of the encoder-gradient GEMM, which then runs over the
+// generated rows only.
+constexpr int CSC_BIAS_PARTS = 16;
+__global__ __launch_bounds__(256) void csc_rows_kernel(const long long* __restrict__ colptr, const int* __restrict__ rowidx,
+                                                       const float* __restrict__ val, const int* __restrict__ pos, int start,
+                                                       int nb, int ncols, const float* __restrict__ dEr, int ld, int e,
+                                                       float* __restrict__ S) {
+  __shared__ float4 part[256];
+  const int j = blockIdx.x, tid = threadIdx.x;
+  const int c4n = (e + 3) / 4;
+  const bool bias = j >= ncols;
+  const long long a = bias ? 0 : colptr[j], z = bias ? 0 : colptr[j + 1];
+  for (int c0 = 0; c0 < c4n; c0 += 256) {
+    const int width = min(256, c4n - c0);
+    const int G = 256 / width, g = tid / width, c = c0 + tid % width;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g < G) {
+      if (!bias) {
+#pragma unroll 4
+        for (long long i = a + g; i < z; i += G) {      // (branch-free: four entries' lookups and row fetches in flight)
+          const int b = pos[rowidx[i]] - start;
+          const bool in = b >= 0 && b < nb;
+          const float w = in ? val[i] : 0.f;
+          const float4 d = *reinterpret_cast<const float4*>(dEr + (size_t)(in ? b : 0) * ld + 4 * c);
+          acc.x += w * d.x; acc.y += w * d.y; acc.z += w * d.z; acc.w += w * d.w;
+        }
+      } else {
+#pragma unroll 4
+        for (int b = (j - ncols) + g * CSC_BIAS_PARTS; b < nb; b += G * CSC_BIAS_PARTS) {
+          const float4 d = *reinterpret_cast<const float4*>(dEr + (size_t)b * ld + 4 * c);
+          acc.x += d.x; acc.y += d.y; acc.z += d.z; acc.w += d.w;
+        }
+      }
+    }
+    part[tid] = acc;
+    __syncthreads();
+    if (tid < width) {
+      float4 t = part[tid];
+      for (int q = 1; q < G; ++q) {
+        const float4 u = part[q * width + tid];
+        t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+      }
+      *reinterpret_cast<float4*>(S + (size_t)j * ld + 4 * c) = t;      // (pad columns of a row: sums of zero pads = 0)
+    }
+    __syncthreads();
+  }
+}
+
 // Opens an optimizer step without any rows (a data-parallel rank that ran out of rows).
 __global__ void open_step_kernel(float* __restrict__ scal, int which, int alpha_idx, float lr) {
   if (blockIdx.x == 0 && threadIdx.x == 0) {

@@ -141,12 +141,18 @@ def test_edge_shapes(U, N, k, e, B):
     eng.close()
 
 
-@pytest.mark.parametrize("k,e,B", [(10, 32, 32), (16, 100, 256)])
-def test_c1_sparse_generator_path(golden_dir, monkeypatch, k, e, B):
-    """SURVEY 8(f)-3 at BASELINE configs[0] (LastFM 1884 x 17632, 0.22 % dense; the reference's default k / emb_dim /
-    batch and a wider one): generator steps take the real rows' encodings from a CSR row-sum and never densify X.
-    One epoch (59 / 8 D + G updates, ragged last batch) with the sparse path, the dense path and the planner's own choice
-    (which must BE the sparse path at this density) against the fp64 oracle."""
+@pytest.mark.parametrize("k,e,B", [(10, 32, 32), (16, 100, 256), (67, 398, 1024)])
+def test_c1_sparse_real_path(golden_dir, monkeypatch, k, e, B):
+    """SURVEY 8(f)-3 at BASELINE configs[0] (LastFM 1884 x 17632, 0.22 % dense; the reference's default k / emb_dim / batch,
+    a wider one, and the reference's TUNED k = 67, emb_dim = 398, batch = 1024): the real rows X stay CSR.
+      generator step      Er = X.We + be as a CSR row-sum, X never expanded                              (GANMF.py:198-201)
+      discriminator step  the same for Er; the residual R - X takes X from a CSR lookup in the decode epilogue (bit-identical to
+                          the dense subtraction); the encoder gradient's real half X^T.dE_r comes from the CSC matrix in the
+                          epilogue of a GEMM that runs over the generated rows only                       (GANMF.py:183-187)
+    One epoch (ragged last batch) in every combination of the two paths and with the planner's own choice against the fp64
+    oracle; the planner must pick the sparse generator path at this density, and the sparse discriminator path exactly where
+    it removes >= 2 GFLOP per step (the tuned configuration).  Two handles of the sparse path end bit-identical (fixed summation
+    order: no float atomics)."""
     import os
     from ganmf_amd.engine import Engine
     urm = sps.load_npz(os.path.join(golden_dir, "LastFM_URM_train.npz")).tocsr().astype(np.float32)
@@ -158,11 +164,12 @@ def test_c1_sparse_generator_path(golden_dir, monkeypatch, k, e, B):
     perm = np.random.RandomState(4).permutation(U)
     dl_ref, gl_ref = o.train_epoch(urm, perm, B, 1, 1)
     got = {}
-    for mode in ("1", "0", None):
-        if mode is None:
-            monkeypatch.delenv("GANMF_SPARSE", raising=False)
-        else:
-            monkeypatch.setenv("GANMF_SPARSE", mode)
+    for mode in (("1", "1"), ("1", "1"), ("1", "0"), ("0", None), (None, None)):
+        for var, val in zip(("GANMF_SPARSE", "GANMF_SPARSE_D"), mode):
+            if val is None:
+                monkeypatch.delenv(var, raising=False)
+            else:
+                monkeypatch.setenv(var, val)
         eng = Engine(U, N, k, e, B, **hp)
         eng.set_urm(urm)
         for n, tid in NAME2ID.items():
@@ -170,10 +177,16 @@ def test_c1_sparse_generator_path(golden_dir, monkeypatch, k, e, B):
         dl, gl = eng.train_epoch(perm, 1, 1)
         np.testing.assert_allclose(dl, dl_ref, rtol=1e-4, atol=1e-7)
         np.testing.assert_allclose(gl, gl_ref, rtol=1e-4, atol=1e-7)
-        got[mode] = {n: eng.get_tensor(tid) for n, tid in NAME2ID.items()}
+        res = {n: eng.get_tensor(tid) for n, tid in NAME2ID.items()}
         for n in NAME2ID:
-            assert _err(got[mode][n], o.p[n]) <= 1e-4, (mode, n)
+            assert _err(res[n], o.p[n]) <= 1e-4, (mode, n)
+        if mode in got:      # second handle of the fully sparse path: bitwise reproducible
+            for n in NAME2ID:
+                assert np.array_equal(got[mode][n], res[n]), n
+        got[mode] = res
         eng.close()
+    expect = ("1", "1") if 4.0 * min(B, U) * N * e >= 2.0e9 else ("1", "0")
     for n in NAME2ID:
-        assert np.array_equal(got[None][n], got["1"][n]), n          # the planner chose the sparse path
-    assert any(not np.array_equal(got["0"][n], got["1"][n]) for n in NAME2ID)   # ... which is a different summation order
+        assert np.array_equal(got[(None, None)][n], got[expect][n]), (n, expect)          # the planner's choice
+    assert any(not np.array_equal(got[("0", None)][n], got[("1", "0")][n]) for n in NAME2ID)      # ... is a different summation order
+    assert any(not np.array_equal(got[("1", "1")][n], got[("1", "0")][n]) for n in NAME2ID)
