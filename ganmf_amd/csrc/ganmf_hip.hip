@@ -250,6 +250,8 @@ struct ganmf_handle {
   int d_alpha = S_ALPHA_D;             // scalar slot holding lr_t of the discriminator step in flight (alternates in data-parallel runs)
   int side_pending = 0;                // data-parallel: PEND_* bits of the replicated tensors the side lane still updates (dp_join
                                        // before their next use on the main lane)
+  bool merge_decode = true;            // GANMF_MERGE_DECODE: the discriminator step's two decode batches as one product (d_step)
+  int adam_nfast = 1;                  // GANMF_ADAM_NFAST: tile order of the fused-Adam weight-gradient launch (GemmP::n_fastest)
   bool fork_attach = true;             // GANMF_FORK_ATTACH: forks ride on the producing kernel's completion event (fork_arm / fork_wait)
   bool force_coll = false;             // GANMF_FORCE_COLLECTIVES=1: a one-rank communicator still issues its (in-place) reduce-scatter /
                                        // all-gather calls, so that the RCCL call sites execute on a one-GPU box (tests, bench)
@@ -762,6 +764,24 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
       if (h->sparse_d) {      // the real rows were never expanded: X[m, n] is looked up in the CSR rows of the batch
         g.epi.csr_indptr = h->indptr; g.epi.csr_indices = h->indices; g.epi.csr_data = h->data; g.epi.csr_rows = rows_dev;
       }
+      // [real ; generated] are contiguous in E, XF and Dl: with whole 64-row tiles per path the two batches are ONE product of
+      // 2.nb rows, whose list order (tile row fastest) puts the four row tiles of a tile column next to each other on one XCD --
+      // the decoder panel is fetched once instead of once per batch (rocprofv3 FETCH_SIZE: 42.5 MB per launch as two batches
+      // against 23.3 MB algorithmic, profiles/r02_traffic.json).  Same tiles, same K order, partial sums filed per path as before.
+      bool merged = false;
+      if (!h->sparse_d && nb % 64 == 0 && h->merge_decode) {
+        const GemmPlan p1 = gemm_plan(2 * nb, g.N, g.K, 1, true, h->tune), p2 = gemm_plan(g.M, g.N, g.K, 2, true, h->tune);
+        if (p1.tile == 64 && p2.tile == 64 && p1.nsplit == 1 && p2.nsplit == 1 && p1.mode == p2.mode && p1.kg == p2.kg && p1.ring == p2.ring) {
+          GemmP q = g;
+          q.M = 2 * nb; q.nbatch = 1; q.a_batch_stride = 0; q.c_batch_stride = 0; q.epi.aux_batch_stride = 0;
+          q.epi.sq_m_half = nb / 64;
+          int cnt = 0;
+          TRY(run_gemm(h, T_GEMM_DEC, T_RED_DEC, q, false, true, &cnt, 4.0 * 2 * nb * N));
+          sqn = p2.sq_count;      // per path, as the two-batch form counts them
+          merged = true;
+        }
+      }
+      if (!merged)
       TRY(run_gemm(h, T_GEMM_DEC, T_RED_DEC, g, false, true, &sqn, 4.0 * 2 * nb * N));
     }
   } else {
@@ -903,6 +923,13 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
         TRY(sparse_rows());
         fill_plan(g0, p0);
         fill_plan(g1, p1);
+        g0.n_fastest = g1.n_fastest = h->adam_nfast;
+#ifdef GANMF_PERSIST_DIAG_BUILD
+        // diagnostic build only (make DIAG=1; wrong results): GANMF_WGRAD_DIAG=1 empties the K range, i.e. the launch becomes its
+        // tile-wise Adam pass on a zero gradient -- how long do the twelve Adam streams take in THIS access pattern and occupancy
+        if (env_int("GANMF_WGRAD_DIAG", 0) & 1) { g0.K = 0; g1.K = 0; g0.k_per_split = g1.k_per_split = 0; }
+        g0.diag = g1.diag = env_int("GANMF_WGRAD_DIAG", 0);      // bit 1 (2): no 3-way split, bit 2 (4): 1/NC of the MFMAs, bit 3 (8): no Adam streams
+#endif
         regn[1] = p0.sq_count; regn[0] = p1.sq_count;
         const int n0 = p0.tiles_m * p0.tiles_n, n1 = p1.tiles_m * p1.tiles_n;
         Scope s(h, T_WPAIR, gemm_flops(g0.M, g0.N, g0.K) + gemm_flops(g1.M, g1.N, g1.K),
@@ -1552,6 +1579,8 @@ static int create_impl(const ganmf_cfg* cfg, ganmf_handle* h) {
   h->inlaunch_max = env_int("GANMF_INLAUNCH_MAX", 4);
   h->force_coll = env_int("GANMF_FORCE_COLLECTIVES", 0) != 0;
   h->fork_attach = env_int("GANMF_FORK_ATTACH", 1) != 0;
+  h->adam_nfast = env_int("GANMF_ADAM_NFAST", 1);
+  h->merge_decode = env_int("GANMF_MERGE_DECODE", 1) != 0;
   TRY(dalloc((float**)&h->counters, COUNTER_CAP));
   TRY(dalloc((float**)&h->counters2, COUNTER_CAP));
   const int U = h->U, N = h->N, k = h->k, e = h->e, B = h->B;

@@ -84,6 +84,7 @@ struct SplitStage {
   }
 
   // split / round and write the pieces to the planes at `planes` (piece q at planes + q * PLANE)
+  bool diag_nosplit = false;
   template <int NPIECE, bool F16 = false>
   __device__ inline void store(unsigned* __restrict__ planes, const float4 (&v)[NI][2], float scale = 1.f) const {
 #pragma unroll
@@ -96,6 +97,9 @@ struct SplitStage {
         constexpr int q = decltype(qq)::value;
         if constexpr (NPIECE == 3) {
           unsigned h, m, l;
+#ifdef GANMF_PERSIST_DIAG_BUILD
+          if (diag_nosplit) { h = cvt_pk_bf16(x0, x1); m = h; l = h; } else      // timing only: one conversion instead of the 3-way split
+#endif
           split_bf16x3(x0, x1, h, m, l);
           pc[0][q] = h; pc[1][q] = m; pc[2][q] = l;
         } else if constexpr (F16) {
@@ -179,6 +183,9 @@ __device__ __forceinline__ void gemm_bf16s_body(const GemmP& p, const int bid, c
   SB lb;
   la.init(p.A + (size_t)bz * p.a_batch_stride, p.lda, m0, p.M, kbeg, p.zero_page, tid);
   lb.init(p.B, p.ldb, n0, p.N, kbeg, p.zero_page, tid);
+#ifdef GANMF_PERSIST_DIAG_BUILD
+  la.diag_nosplit = lb.diag_nosplit = (p.diag & 2) != 0;
+#endif
 
   float4 ra[SA::NI][2], rb[SB::NI][2];
   int kleft = kend - kbeg;
@@ -241,14 +248,22 @@ __device__ __forceinline__ void gemm_bf16s_body(const GemmP& p, const int bid, c
   for (int it = 0; it < nt; ++it) {
     const bool more = it + 1 < nt;
     if (more) {                      // next K-tile into registers while this one is multiplied
+#ifdef GANMF_PERSIST_DIAG_BUILD
+      if (!(p.diag & 16))            // timing only: the first K-tile's registers are reused (no operand traffic after the prologue)
+#endif
+      {
       la.load(ra, p.lda, kleft);
       lb.load(rb, p.ldb, kleft);
+      }
       kleft -= BK;
     }
     load_frags(0, 0);
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       if (c + 1 < NC) load_frags((c + 1) & 1, c + 1);
+#ifdef GANMF_PERSIST_DIAG_BUILD
+      if (p.diag & 4) { if (c == 0) mfmas(0); continue; }      // timing only: one MFMA step per K-tile instead of NC
+#endif
       mfmas(c & 1);
     }
     __syncthreads();                 // every wave has read its fragments: the planes may be overwritten

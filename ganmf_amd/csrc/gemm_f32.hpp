@@ -176,6 +176,10 @@ struct EpiD {
   float cfm;
   float* sq_partials;      // [nbatch][sq_stride]
   int sq_stride;
+  int sq_m_half;           // > 0 (unsplit, unbatched products only): the rows are TWO stacked batches of sq_m_half row tiles each
+                           // ([real ; generated] of the decode GEMM); partials are filed as the two-batch form files them --
+                           // batch = tm / sq_m_half, slot tn * sq_m_half + tm % sq_m_half -- so the consumer sums the same numbers
+                           // in the same order, while the weight panel of a tile column is fetched once for both batches
   int act;                 // ActKind for EPI_ACT / EPI_MUL_ACTGRAD
   const float* r1_u;       // EPI_ACT: optional fp32 rank-1 term  acc += r1_u[m * r1_ld] * r1_w[n]  before the activation
   const float* r1_w;       //          (DisGANMF's float(uid) input column kept OUT of a low-precision K loop)
@@ -305,6 +309,10 @@ struct GemmP {
   // is walked in bands of xb_band tile rows, M-innermost, so an XCD's L2 keeps its A band and streams its B panels once per
   // band (tile_coords below; speed only, any order is correct).
   int xb_m, xb_n, xb_band;
+  int diag;                     // diagnostic builds only (make DIAG=1): timing experiments of the staged kernel's K loop
+  int n_fastest;                // list order with the tile COLUMN fastest (default: tile row fastest).  For the fused-Adam weight-gradient
+                                // products: workgroups that run at the same time then update neighbouring 256-byte segments of the same
+                                // parameter rows, i.e. whole DRAM pages of theta / m / v instead of one segment per 4-15 KiB row
 };
 
 #define GANMF_WAIT_VMCNT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
@@ -449,8 +457,13 @@ __device__ inline void tile_coords(const GemmP& p, int bid, int nblk, int& tm, i
     tn = nb0 + r / h;
     return;
   }
-  tm = t % p.tiles_m; t /= p.tiles_m;
-  tn = t % p.tiles_n; t /= p.tiles_n;
+  if (p.n_fastest) {
+    tn = t % p.tiles_n; t /= p.tiles_n;
+    tm = t % p.tiles_m; t /= p.tiles_m;
+  } else {
+    tm = t % p.tiles_m; t /= p.tiles_m;
+    tn = t % p.tiles_n; t /= p.tiles_n;
+  }
   sp = t % p.nsplit;
   bz = t / p.nsplit;
 }
@@ -507,6 +520,9 @@ __device__ inline void gemm_epilogue(const GemmP& p, const f32x16 (&acc)[TM][TN]
   const bool publish = deferred && p.counters != nullptr;
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   const __amdgpu_buffer_rsrc_t slab_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)C, (short)0, 0x7fffffff, 0x00020000);
+#ifdef GANMF_PERSIST_DIAG_BUILD
+  if (adam && (p.diag & 8)) return;      // timing only: the K phase without the Adam streams
+#endif
   if (adam && GANMF_ADAM_HOIST) {
     // The tile is a gradient: parameter and moments are updated in place, the gradient is never stored.  theta / m / v of up to
     // four row steps are fetched BEFORE the first of them is written back: written as one loop the stores of step j and the
@@ -688,7 +704,8 @@ __device__ inline void gemm_epilogue(const GemmP& p, const f32x16 (&acc)[TM][TN]
       float t = (smem[0] + smem[1]) + (smem[2] + smem[3]);
 #pragma unroll
       for (int g = 1; g < KG; ++g) t += (smem[4 * g] + smem[4 * g + 1]) + (smem[4 * g + 2] + smem[4 * g + 3]);
-      e.sq_partials[(size_t)bz * e.sq_stride + tn * p.tiles_m + tm] = t;
+      if (e.sq_m_half > 0) e.sq_partials[(size_t)(tm / e.sq_m_half) * (p.tiles_n * e.sq_m_half) + tn * e.sq_m_half + tm % e.sq_m_half] = t;
+      else e.sq_partials[(size_t)bz * e.sq_stride + tn * p.tiles_m + tm] = t;
     }
   }
 }

@@ -51,6 +51,8 @@ def algorithmic(cls, B, N, k, e, U):
     if name == "adam_rows_U": return 24 * U * k + 4 * B * k
     if name == "densify+gather": return 4 * B * (N + 2 * k)
     if name == "d_coef": return 8 * 2 * B * e
+    if name.startswith("scoring"):      # S-step rows of the bench's side measurement: U[6040, k] . V[N, k]^T -> [U, N], every operand once
+        return 4 * (U * k + N * k + U * N)
     if name.startswith("reduce("):
         inner = name[7:-1]
         M, Nn = {"encode": (2 * B, e), "decode": (B, N), "dE": ((2 * B if step == "D" else B), e), "dF": (B, N), "gUb": (B, k)}.get(inner, (0, 0))

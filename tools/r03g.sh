@@ -1,0 +1,15 @@
+set -x
+bash tools/profile_round.sh r03 > gpurun_out/r03_profile_round.log 2>&1; echo "profile_round rc=$?"
+python tools/config_profiles.py > gpurun_out/r03/config_profiles.md 2> gpurun_out/r03/config_profiles.err; echo "config_profiles rc=$?"; tail -2 gpurun_out/r03/config_profiles.err
+for c in c1_defaults c1_tuned c3 c4_e32 c5 c5_f16; do
+  bash tools/trace_stats.sh r03/trace_$c tools/config_profiles.py $c > /dev/null 2>&1; echo "trace $c rc=$?"
+done
+python tools/c1_bench.py > gpurun_out/r03/c1.log 2>&1
+GANMF_BENCH_FORCE_COMM=1 python bench.py --no-cpu-baseline > gpurun_out/r03/bench_fc.json 2> gpurun_out/r03/bench_fc.err
+cd /tmp && export TMPDIR=/tmp
+GANMF_BENCH_FORCE_COMM=1 rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r03/trace_fc -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps 64 --warmup 32 > $GRAFT_REPO_ROOT/gpurun_out/r03/trace_fc.log 2>&1
+cd $GRAFT_REPO_ROOT
+python3 tools/timeline.py "$(ls gpurun_out/r03/trace_fc/*/*_kernel_trace.csv | head -1)" 40 1 > gpurun_out/r03/timeline_fc_D.txt
+python3 tools/timeline.py "$(ls gpurun_out/r03/trace_fc/*/*_kernel_trace.csv | head -1)" 70 1 > gpurun_out/r03/timeline_fc_G.txt
+find gpurun_out/r03 -name "*_kernel_trace.csv" -delete
+du -sh gpurun_out/r03
