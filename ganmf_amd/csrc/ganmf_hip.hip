@@ -251,6 +251,7 @@ struct ganmf_handle {
   int side_pending = 0;                // data-parallel: PEND_* bits of the replicated tensors the side lane still updates (dp_join
                                        // before their next use on the main lane)
   bool merge_decode = true;            // GANMF_MERGE_DECODE: the discriminator step's two decode batches as one product (d_step)
+  int red_elems = 1;                   // GANMF_RED_ELEMS: float4 outputs per thread of the stand-alone slab sum (0: the fixed 512-block grid)
   int adam_nfast = 1;                  // GANMF_ADAM_NFAST: tile order of the fused-Adam weight-gradient launch (GemmP::n_fastest)
   bool fork_attach = true;             // GANMF_FORK_ATTACH: forks ride on the producing kernel's completion event (fork_arm / fork_wait)
   bool force_coll = false;             // GANMF_FORCE_COLLECTIVES=1: a one-rank communicator still issues its (in-place) reduce-scatter /
@@ -451,6 +452,15 @@ int all_gather(ganmf_handle* h, float* buf, size_t total, int lane) {
   return 0;
 }
 
+// Blocks of a stand-alone slab sum over an [M, N] output: one float4 of output per thread (GANMF_RED_ELEMS per thread), at most
+// GEMM_RED_GRID.  The step's outputs are 32 k - 118 k float4: a fixed 512-block grid left up to 3/4 of its threads without work
+// and the launch paid their dispatch.  (Also the number of sum-of-squares partials such a launch writes.)
+int red_grid(const ganmf_handle* h, long long M, long long N) {
+  const long long total4 = M * ((N + 3) / 4);
+  const long long per_block = 256LL * std::max(1, h->red_elems);
+  return (int)std::max<long long>(1, std::min<long long>(GEMM_RED_GRID, (total4 + per_block - 1) / per_block));
+}
+
 int ensure_slab(ganmf_handle* h, size_t elems, int lane) {
   float*& slab = lane ? h->slab2 : h->slab;
   size_t& cap = lane ? h->slab2_elems : h->slab_elems;
@@ -497,7 +507,8 @@ int run_gemm(ganmf_handle* h, int tag_gemm, int tag_red, GemmP g, bool akm, bool
   // reduction only pays for shallow splits; deep splits keep the chip-wide reduce kernel
   const bool in_launch = !deferred && pl.nsplit > 1 && pl.nsplit <= h->inlaunch_max && counters && n_tiles <= (size_t)COUNTER_CAP;
   const bool wants_sq = g.epi.sq_partials != nullptr;
-  const int sqc = !wants_sq ? 0 : (pl.nsplit > 1 && !in_launch ? GEMM_RED_GRID : pl.sq_count);
+  const int nredg = h->red_elems > 0 ? red_grid(h, g.M, g.N) : GEMM_RED_GRID;      // blocks (and partials) of a stand-alone slab sum
+  const int sqc = !wants_sq ? 0 : (pl.nsplit > 1 && !in_launch ? nredg : pl.sq_count);
   if (sq_count) *sq_count = sqc;
   if (h->debug_plan) {
     const long long key = ((long long)tag_gemm << 48) ^ ((long long)g.M << 32) ^ ((long long)g.N << 16) ^ g.K;
@@ -529,7 +540,7 @@ int run_gemm(ganmf_handle* h, int tag_gemm, int tag_red, GemmP g, bool akm, bool
     {
       Scope s(h, tag_red, 0, 4.0 * (attach->nsplit + 1) * attach->M * attach->N, st);
       RedP r = *attach;
-      GANMF_LAUNCH(splitk_reduce_kernel, dim3(GEMM_RED_GRID, 1), dim3(256), 0, st, r);
+      GANMF_LAUNCH(splitk_reduce_kernel, dim3(h->red_elems > 0 ? red_grid(h, r.M, r.N) : GEMM_RED_GRID, 1), dim3(256), 0, st, r);
       HIP_TRY(hipGetLastError());
     }
   }
@@ -541,10 +552,10 @@ int run_gemm(ganmf_handle* h, int tag_gemm, int tag_red, GemmP g, bool akm, bool
     HIP_TRY(gemm_dispatch(st, q, akm, bkm, pl));
     RedP r{};
     r.part = slab; r.nsplit = pl.nsplit; r.out = g.C; r.ld = g.ldc; r.M = g.M; r.N = g.N;
-    r.batch_stride = g.c_batch_stride; r.epi = g.epi; r.epi.sq_stride = GEMM_RED_GRID;
+    r.batch_stride = g.c_batch_stride; r.epi = g.epi; r.epi.sq_stride = nredg;
     r.split_stride = (long long)g.M * g.ldc;
     *defer_red = r;
-    if (sq_count && wants_sq) *sq_count = GEMM_RED_GRID;
+    if (sq_count && wants_sq) *sq_count = nredg;
     return 0;
   }
   if (deferred) {     // slabs only: the consumer sums them
@@ -558,7 +569,7 @@ int run_gemm(ganmf_handle* h, int tag_gemm, int tag_red, GemmP g, bool akm, bool
   }
   if (!h->prof || pl.nsplit == 1 || in_launch) {
     Scope s(h, tag_gemm, fl, by + (pl.nsplit > 1 ? 8.0 * pl.nsplit * g.nbatch * g.M * g.N : 0), st);
-    HIP_TRY(gemm_run(st, g, akm, bkm, pl, slab, slab_elems, in_launch ? counters : nullptr, COUNTER_CAP));
+    HIP_TRY(gemm_run(st, g, akm, bkm, pl, slab, slab_elems, in_launch ? counters : nullptr, COUNTER_CAP, nredg));
     return 0;
   }
   {  // profiled, separate reduce kernel: bracket the GEMM and the reduce separately
@@ -574,9 +585,9 @@ int run_gemm(ganmf_handle* h, int tag_gemm, int tag_red, GemmP g, bool akm, bool
     Scope s(h, tag_red, 0, 4.0 * (pl.nsplit + 1) * g.nbatch * g.M * g.N, st);
     RedP r{};
     r.part = slab; r.nsplit = pl.nsplit; r.out = g.C; r.ld = g.ldc; r.M = g.M; r.N = g.N;
-    r.batch_stride = g.c_batch_stride; r.epi = g.epi; r.epi.sq_stride = GEMM_RED_GRID;
+    r.batch_stride = g.c_batch_stride; r.epi = g.epi; r.epi.sq_stride = nredg;
     r.split_stride = (long long)g.nbatch * g.M * g.ldc;
-    GANMF_LAUNCH(splitk_reduce_kernel, dim3(GEMM_RED_GRID, g.nbatch), dim3(256), 0, st, r);
+    GANMF_LAUNCH(splitk_reduce_kernel, dim3(nredg, g.nbatch), dim3(256), 0, st, r);
     HIP_TRY(hipGetLastError());
   }
   return 0;
@@ -883,7 +894,7 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
     if (dcoef_done) {   // the slabs are there already: hand their sum (+ row scale) to the gWd launch
       dE_red = RedP{};
       dE_red.part = h->slab; dE_red.nsplit = pde.nsplit; dE_red.out = gde.C; dE_red.ld = gde.ldc; dE_red.M = gde.M; dE_red.N = gde.N;
-      dE_red.batch_stride = 0; dE_red.epi = gde.epi; dE_red.epi.sq_stride = GEMM_RED_GRID;
+      dE_red.batch_stride = 0; dE_red.epi = gde.epi; dE_red.epi.sq_stride = GEMM_RED_GRID;      // (no partials: EPI_ROWSCALE)
       dE_red.split_stride = (long long)gde.M * gde.ldc;
     } else {  // dE = rs * (Delta . Wd^T)          (bias row e of Wd_ext is not part of this product; reads the OLD Wd)
       GemmP g{};
@@ -917,7 +928,7 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
       if (staged(p0) && staged(p1)) {
         {
           Scope s(h, T_RED_DE, 0, 4.0 * (dE_red.nsplit + 1) * dE_red.M * dE_red.N);
-          GANMF_LAUNCH(splitk_reduce_kernel, dim3(GEMM_RED_GRID, 1), dim3(256), 0, h->st, dE_red);
+          GANMF_LAUNCH(splitk_reduce_kernel, dim3(h->red_elems > 0 ? red_grid(h, dE_red.M, dE_red.N) : GEMM_RED_GRID, 1), dim3(256), 0, h->st, dE_red);
           HIP_TRY(hipGetLastError());
         }
         TRY(sparse_rows());
@@ -942,7 +953,7 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
     }
     if (dist && dE_red.part) {     // (dcoef_done: the slabs of dE are waiting for their sum)
       Scope s(h, T_RED_DE, 0, 4.0 * (dE_red.nsplit + 1) * dE_red.M * dE_red.N);
-      GANMF_LAUNCH(splitk_reduce_kernel, dim3(GEMM_RED_GRID, 1), dim3(256), 0, h->st, dE_red);
+      GANMF_LAUNCH(splitk_reduce_kernel, dim3(h->red_elems > 0 ? red_grid(h, dE_red.M, dE_red.N) : GEMM_RED_GRID, 1), dim3(256), 0, h->st, dE_red);
       HIP_TRY(hipGetLastError());
       dE_red.part = nullptr;      // (summed: nothing to attach to the gWd launch)
     }
@@ -1580,6 +1591,7 @@ static int create_impl(const ganmf_cfg* cfg, ganmf_handle* h) {
   h->force_coll = env_int("GANMF_FORCE_COLLECTIVES", 0) != 0;
   h->fork_attach = env_int("GANMF_FORK_ATTACH", 1) != 0;
   h->adam_nfast = env_int("GANMF_ADAM_NFAST", 1);
+  h->red_elems = env_int("GANMF_RED_ELEMS", 1);
   h->merge_decode = env_int("GANMF_MERGE_DECODE", 1) != 0;
   TRY(dalloc((float**)&h->counters, COUNTER_CAP));
   TRY(dalloc((float**)&h->counters2, COUNTER_CAP));

@@ -1104,7 +1104,7 @@ inline hipError_t gemm_dispatch(hipStream_t st, const GemmP& p, bool akm, bool b
 // Logical GEMM: C[bz] = epi(op(A[bz]) . op(B)).  `p` carries the operands, shapes, batch strides
 // and the epilogue; C/ldc/c_batch_stride describe the FINAL output.  slab: workspace for split-K.
 inline hipError_t gemm_run(hipStream_t st, GemmP p, bool akm, bool bkm, const GemmPlan& pl, float* slab,
-                           size_t slab_elems, unsigned* counters = nullptr, size_t n_counters = 0) {
+                           size_t slab_elems, unsigned* counters = nullptr, size_t n_counters = 0, int red_blocks = GEMM_RED_GRID) {
   if (p.nbatch < 1) p.nbatch = 1;
   if (!p.zero_page || (p.lda % LD_ALIGN) || (p.ldb % LD_ALIGN)) return hipErrorInvalidValue;
   p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n;
@@ -1121,13 +1121,13 @@ inline hipError_t gemm_run(hipStream_t st, GemmP p, bool akm, bool bkm, const Ge
     r.split_stride = (long long)p.nbatch * p.M * p.ldc;
     if (p.nbatch > 1 && p.c_batch_stride != (long long)p.M * p.ldc) return hipErrorInvalidValue;
     if (in_launch) { p.counters = counters; p.Cf = p.C; p.cf_batch_stride = p.c_batch_stride; }
-    else if (p.epi.sq_partials) { p.epi.sq_stride = GEMM_RED_GRID; r.epi.sq_stride = GEMM_RED_GRID; }
+    else if (p.epi.sq_partials) { p.epi.sq_stride = red_blocks; r.epi.sq_stride = red_blocks; }
     p.C = slab; p.c_split_stride = r.split_stride; p.c_batch_stride = (long long)p.M * p.ldc;
   }
   hipError_t e;
   e = gemm_dispatch(st, p, akm, bkm, pl);
   if (e != hipSuccess || pl.nsplit == 1 || in_launch) return e;
-  GANMF_LAUNCH(splitk_reduce_kernel, dim3(GEMM_RED_GRID, p.nbatch), dim3(256), 0, st, r);
+  GANMF_LAUNCH(splitk_reduce_kernel, dim3(red_blocks, p.nbatch), dim3(256), 0, st, r);
   return hipGetLastError();
 }
 

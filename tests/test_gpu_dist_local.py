@@ -128,12 +128,12 @@ def test_disganmf_sharded_epoch_equals_union_batch():
 @pytest.mark.slow
 def test_c4_width_world8_step_equals_union_batch():
     """BASELINE configs[3] geometry as a MULTI-RANK run: 50 000 items, k = 250, emb_dim = 1024, B = 128 per rank, users
-    sharded over 8 ranks (ragged: 1000 users -> 125 rows per rank, so the global batch is 1000 rows and every scale uses
-    it), one discriminator + one generator update through the library's data-parallel path on the loopback communicator
-    (world 8 on one GPU), against the single-process oracle on the union batch.  Replicated tensors must be bitwise
-    identical on all 8 ranks."""
+    sharded over 8 ranks (2000 users -> 250 rows per rank: a full slice of 128 and a ragged one of 122 per rank, global
+    batches of 1024 and 976 rows, every scale uses them), a discriminator pass and a generator pass of two updates each through
+    the library's data-parallel path on the loopback communicator (world 8 on one GPU), against the single-process oracle on the
+    union batches.  Replicated tensors must be bitwise identical on all 8 ranks."""
     from ganmf_amd.engine import Engine
-    world, U, N, k, e, B = 8, 1000, 50000, 250, 1024, 128
+    world, U, N, k, e, B = 8, 2000, 50000, 250, 1024, 128
     rng = np.random.RandomState(4)
     nnz_per_row = 500                                   # 1 % density (SURVEY 8d: C4)
     cols = np.concatenate([rng.choice(N, nnz_per_row, replace=False) for _ in range(U)])
@@ -155,18 +155,19 @@ def test_c4_width_world8_step_equals_union_batch():
         return eng
 
     engines, out, steps = _run_ranks(world, make_engine, bounds, perms, B, group=808)
-    assert steps == 1
-    union = np.concatenate([bounds[r][0] + perms[r][:B] for r in range(world)])
-    X = urm[union].toarray()
-    dl_ref, gl_ref = o.d_step(union, X), o.g_step(union, X)
+    assert steps == 2
+    unions = [np.concatenate([bounds[r][0] + perms[r][i * B:(i + 1) * B] for r in range(world)]) for i in range(steps)]
+    assert [len(u) for u in unions] == [1024, 976]
+    dl_ref = [o.d_step(u, urm[u].toarray()) for u in unions]
+    gl_ref = [o.g_step(u, urm[u].toarray()) for u in unions]
     for r in range(world):
-        np.testing.assert_allclose(out[r][0], [dl_ref], rtol=1e-4, atol=1e-7)
-        np.testing.assert_allclose(out[r][1], [gl_ref], rtol=1e-4, atol=1e-7)
+        np.testing.assert_allclose(out[r][0], dl_ref, rtol=1e-4, atol=1e-7)
+        np.testing.assert_allclose(out[r][1], gl_ref, rtol=1e-4, atol=1e-7)
     for n, tid in (("We", 0), ("be", 1), ("Wd", 2), ("bd", 3), ("V", 101)):
         t0 = engines[0].get_tensor(tid)
-        # one Adam step moves every element by ~lr whatever the gradient: compare the UPDATE, normalised by its own scale
+        # the first Adam steps move every element by ~lr whatever the gradient: compare the UPDATE, normalised by its own scale
         upd, upd_ref = t0.astype(np.float64).reshape(p0[n].shape) - p0[n], o.p[n] - p0[n]
-        assert np.max(np.abs(upd - upd_ref)) <= 2e-3 * np.max(np.abs(upd_ref)) + 1e-12, n
+        assert np.max(np.abs(upd - upd_ref)) <= 4e-3 * np.max(np.abs(upd_ref)) + 1e-12, n
         assert _err(t0, o.p[n]) <= 1e-4, n
         for r in range(1, world):
             assert np.array_equal(engines[r].get_tensor(tid), t0), (n, r)

@@ -32,7 +32,7 @@ def _urm(rng, U, N, density):
     return sps.csr_matrix(m)
 
 
-@pytest.mark.parametrize("mode,world", [("user", 3), ("item", 4)])
+@pytest.mark.parametrize("mode,world", [("user", 3), ("item", 4), ("user", 8)])
 def test_sharded_ganmf_fit_follows_single_gpu_fit_and_oracle(mode, world):
     from ganmf_amd.GANMF import GANMF
     rng = np.random.RandomState(world)
