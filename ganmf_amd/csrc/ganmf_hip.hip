@@ -251,8 +251,8 @@ struct ganmf_handle {
   int side_pending = 0;                // data-parallel: PEND_* bits of the replicated tensors the side lane still updates (dp_join
                                        // before their next use on the main lane)
   bool merge_decode = true;            // GANMF_MERGE_DECODE: the discriminator step's two decode batches as one product (d_step)
-  int red_elems = 1;                   // GANMF_RED_ELEMS: float4 outputs per thread of the stand-alone slab sum (0: the fixed 512-block grid)
-  int adam_nfast = 1;                  // GANMF_ADAM_NFAST: tile order of the fused-Adam weight-gradient launch (GemmP::n_fastest)
+  int red_elems = 0;                   // GANMF_RED_ELEMS: float4 outputs per thread of the stand-alone slab sum (0: the fixed 512-block grid)
+  int adam_nfast = 3;                  // GANMF_ADAM_NFAST: tile order of the fused-Adam weight-gradient launch (GemmP::n_fastest)
   bool fork_attach = true;             // GANMF_FORK_ATTACH: forks ride on the producing kernel's completion event (fork_arm / fork_wait)
   bool force_coll = false;             // GANMF_FORCE_COLLECTIVES=1: a one-rank communicator still issues its (in-place) reduce-scatter /
                                        // all-gather calls, so that the RCCL call sites execute on a one-GPU box (tests, bench)
@@ -455,9 +455,10 @@ int all_gather(ganmf_handle* h, float* buf, size_t total, int lane) {
 // Blocks of a stand-alone slab sum over an [M, N] output: one float4 of output per thread (GANMF_RED_ELEMS per thread), at most
 // GEMM_RED_GRID.  The step's outputs are 32 k - 118 k float4: a fixed 512-block grid left up to 3/4 of its threads without work
 // and the launch paid their dispatch.  (Also the number of sum-of-squares partials such a launch writes.)
-int red_grid(const ganmf_handle* h, long long M, long long N) {
+int red_grid(const ganmf_handle* h, long long M, long long N, int nsplit) {
   const long long total4 = M * ((N + 3) / 4);
-  const long long per_block = 256LL * std::max(1, h->red_elems);
+  // (a deep split behind a small output is summed by reduce_groups() threads per element: 256 / G elements per block and pass)
+  const long long per_block = 256LL / reduce_groups(total4, nsplit) * std::max(1, h->red_elems);
   return (int)std::max<long long>(1, std::min<long long>(GEMM_RED_GRID, (total4 + per_block - 1) / per_block));
 }
 
@@ -489,6 +490,7 @@ int run_gemm(ganmf_handle* h, int tag_gemm, int tag_red, GemmP g, bool akm, bool
              RedP* defer_red = nullptr, const RedP* attach = nullptr) {
   if (g.nbatch < 1) g.nbatch = 1;
   g.zero_page = h->zero_page;
+  if (g.epi.kind == EPI_ADAM && (h->adam_nfast & 2)) g.n_fastest = 1;      // (GANMF_ADAM_NFAST bit 1: every fused-Adam product, not only the paired launch)
   hipStream_t st = lane ? h->st2 : h->st;
   const GemmTune& tn = force ? *force : h->tune;
   GemmPlan pl = gemm_plan(g.M, g.N, g.K, g.nbatch, g.epi.sq_partials != nullptr, tn, g.epi.kind == EPI_ADAM);
@@ -507,7 +509,7 @@ int run_gemm(ganmf_handle* h, int tag_gemm, int tag_red, GemmP g, bool akm, bool
   // reduction only pays for shallow splits; deep splits keep the chip-wide reduce kernel
   const bool in_launch = !deferred && pl.nsplit > 1 && pl.nsplit <= h->inlaunch_max && counters && n_tiles <= (size_t)COUNTER_CAP;
   const bool wants_sq = g.epi.sq_partials != nullptr;
-  const int nredg = h->red_elems > 0 ? red_grid(h, g.M, g.N) : GEMM_RED_GRID;      // blocks (and partials) of a stand-alone slab sum
+  const int nredg = h->red_elems > 0 ? red_grid(h, g.M, g.N, pl.nsplit) : GEMM_RED_GRID;      // blocks (and partials) of a stand-alone slab sum
   const int sqc = !wants_sq ? 0 : (pl.nsplit > 1 && !in_launch ? nredg : pl.sq_count);
   if (sq_count) *sq_count = sqc;
   if (h->debug_plan) {
@@ -540,7 +542,7 @@ int run_gemm(ganmf_handle* h, int tag_gemm, int tag_red, GemmP g, bool akm, bool
     {
       Scope s(h, tag_red, 0, 4.0 * (attach->nsplit + 1) * attach->M * attach->N, st);
       RedP r = *attach;
-      GANMF_LAUNCH(splitk_reduce_kernel, dim3(h->red_elems > 0 ? red_grid(h, r.M, r.N) : GEMM_RED_GRID, 1), dim3(256), 0, st, r);
+      GANMF_LAUNCH(splitk_reduce_kernel, dim3(h->red_elems > 0 ? red_grid(h, r.M, r.N, r.nsplit) : GEMM_RED_GRID, 1), dim3(256), 0, st, r);
       HIP_TRY(hipGetLastError());
     }
   }
@@ -928,13 +930,13 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
       if (staged(p0) && staged(p1)) {
         {
           Scope s(h, T_RED_DE, 0, 4.0 * (dE_red.nsplit + 1) * dE_red.M * dE_red.N);
-          GANMF_LAUNCH(splitk_reduce_kernel, dim3(h->red_elems > 0 ? red_grid(h, dE_red.M, dE_red.N) : GEMM_RED_GRID, 1), dim3(256), 0, h->st, dE_red);
+          GANMF_LAUNCH(splitk_reduce_kernel, dim3(h->red_elems > 0 ? red_grid(h, dE_red.M, dE_red.N, dE_red.nsplit) : GEMM_RED_GRID, 1), dim3(256), 0, h->st, dE_red);
           HIP_TRY(hipGetLastError());
         }
         TRY(sparse_rows());
         fill_plan(g0, p0);
         fill_plan(g1, p1);
-        g0.n_fastest = g1.n_fastest = h->adam_nfast;
+        g0.n_fastest = g1.n_fastest = (h->adam_nfast & 1);
 #ifdef GANMF_PERSIST_DIAG_BUILD
         // diagnostic build only (make DIAG=1; wrong results): GANMF_WGRAD_DIAG=1 empties the K range, i.e. the launch becomes its
         // tile-wise Adam pass on a zero gradient -- how long do the twelve Adam streams take in THIS access pattern and occupancy
@@ -953,7 +955,7 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
     }
     if (dist && dE_red.part) {     // (dcoef_done: the slabs of dE are waiting for their sum)
       Scope s(h, T_RED_DE, 0, 4.0 * (dE_red.nsplit + 1) * dE_red.M * dE_red.N);
-      GANMF_LAUNCH(splitk_reduce_kernel, dim3(h->red_elems > 0 ? red_grid(h, dE_red.M, dE_red.N) : GEMM_RED_GRID, 1), dim3(256), 0, h->st, dE_red);
+      GANMF_LAUNCH(splitk_reduce_kernel, dim3(h->red_elems > 0 ? red_grid(h, dE_red.M, dE_red.N, dE_red.nsplit) : GEMM_RED_GRID, 1), dim3(256), 0, h->st, dE_red);
       HIP_TRY(hipGetLastError());
       dE_red.part = nullptr;      // (summed: nothing to attach to the gWd launch)
     }
@@ -1078,6 +1080,7 @@ int gen_update(ganmf_handle* h, int nb, int start, int b_global, int* regn_v, fl
       g0.c_batch_stride = (long long)g0.M * g0.ldc;
       fill_plan(g0, p0);
       fill_plan(g1, p1);
+      if (fused && (h->adam_nfast & 2)) g1.n_fastest = 1;
       if (fused) *regn_v = p1.sq_count;
       const int n0 = p0.tiles_m * p0.tiles_n * p0.nsplit, n1 = p1.tiles_m * p1.tiles_n;
       {
@@ -1590,8 +1593,8 @@ static int create_impl(const ganmf_cfg* cfg, ganmf_handle* h) {
   h->inlaunch_max = env_int("GANMF_INLAUNCH_MAX", 4);
   h->force_coll = env_int("GANMF_FORCE_COLLECTIVES", 0) != 0;
   h->fork_attach = env_int("GANMF_FORK_ATTACH", 1) != 0;
-  h->adam_nfast = env_int("GANMF_ADAM_NFAST", 1);
-  h->red_elems = env_int("GANMF_RED_ELEMS", 1);
+  h->adam_nfast = env_int("GANMF_ADAM_NFAST", 3);
+  h->red_elems = env_int("GANMF_RED_ELEMS", 0);
   h->merge_decode = env_int("GANMF_MERGE_DECODE", 1) != 0;
   TRY(dalloc((float**)&h->counters, COUNTER_CAP));
   TRY(dalloc((float**)&h->counters2, COUNTER_CAP));
