@@ -35,6 +35,7 @@
 #include "gemm_f32.hpp"
 #include "gemm_bf16s.hpp"
 #include "gemm_persist.hpp"
+#include "gemm_bf16p.hpp"
 #include "kernels.hpp"
 #include "gemm_multi.hpp"
 
@@ -243,6 +244,12 @@ struct ganmf_handle {
   size_t sc_ids_cap = 0;
   float *sc_rows = nullptr, *sc_out = nullptr;
   size_t sc_rows_cap = 0, sc_out_cap = 0;
+  unsigned *sc_pa = nullptr, *sc_pb = nullptr;      // bf16 x 3 planes of the scored rows / of the other factor (gemm_bf16p.hpp)
+  size_t sc_pa_cap = 0, sc_pb_cap = 0;
+  const float* sc_pb_src = nullptr;                 // what sc_pb holds: the planes of this parameter buffer ...
+  long long sc_pb_version = -1, param_version = 0;  // ... as of this parameter version (bumped by training, set_tensor, restore_best)
+  int sc_pb_rows = 0;
+  bool score_presplit = true;                       // GANMF_SCORE_PRESPLIT: many-tile scoring products on the pre-split persistent kernel
   // RCCL
   ncclComm_t comm = nullptr;
   bool has_comm = false;
@@ -1592,6 +1599,7 @@ static int create_impl(const ganmf_cfg* cfg, ganmf_handle* h) {
   h->inkernel_reduce = env_int("GANMF_INKERNEL_REDUCE", 0) != 0;   // measured slower than the chip-wide reduce kernel
   h->inlaunch_max = env_int("GANMF_INLAUNCH_MAX", 4);
   h->force_coll = env_int("GANMF_FORCE_COLLECTIVES", 0) != 0;
+  h->score_presplit = env_int("GANMF_SCORE_PRESPLIT", 1) != 0;
   h->fork_attach = env_int("GANMF_FORK_ATTACH", 1) != 0;
   h->adam_nfast = env_int("GANMF_ADAM_NFAST", 3);
   h->red_elems = env_int("GANMF_RED_ELEMS", 0);
@@ -1695,7 +1703,7 @@ int ganmf_destroy(ganmf_handle* h) {
   hipFree(h->XF); hipFree(h->Ub); hipFree(h->E); hipFree(h->Dl); hipFree(h->dE); hipFree(h->dF); hipFree(h->gUb);
   hipFree(h->slab); hipFree(h->rs); hipFree(h->scal); hipFree(h->sqp);
   hipFree(h->seen_indptr); hipFree(h->seen_indices); hipFree(h->topk_items); hipFree(h->topk_vals); hipFree(h->sc_ids);
-  hipFree(h->colbuf); hipFree(h->parts_all); hipFree(h->sc_rows); hipFree(h->sc_out);
+  hipFree(h->colbuf); hipFree(h->parts_all); hipFree(h->sc_rows); hipFree(h->sc_out); hipFree(h->sc_pa); hipFree(h->sc_pb);
   for (auto& r : h->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
   if (h->st2) hipStreamSynchronize(h->st2);
   if (h->ev_fork) hipEventDestroy(h->ev_fork);
@@ -1843,6 +1851,7 @@ static int copy_view(ganmf_handle* h, int tensor_id, int slot, float* host, int6
 }
 
 int ganmf_set_tensor(ganmf_handle* h, int tensor_id, int slot, const float* host, int64_t n) {
+  if (h) ++h->param_version;
   return copy_view(h, tensor_id, slot, const_cast<float*>(host), n, true, "ganmf_set_tensor");
 }
 
@@ -1882,6 +1891,7 @@ int ganmf_train_epoch_ragged(ganmf_handle* h, const int32_t* perm, int64_t n, in
   const bool dist = h->has_comm && h->cfg.world_size > 1;
   if (dist && !global_batch_rows) return fail(-1, "ganmf_train_epoch: global_batch_rows required when world_size > 1");
   HIP_TRY(hipSetDevice(h->dev));
+  ++h->param_version;
   static const bool time_it = getenv("GANMF_TIME_EPOCH") != nullptr;
   const auto tp0 = std::chrono::steady_clock::now();
   auto since = [&]() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tp0).count(); };
@@ -1986,6 +1996,7 @@ int ganmf_train_step(ganmf_handle* h, int kind, const int32_t* uids, int32_t n, 
   if (kind != 0 && kind != 1) return fail(-1, "ganmf_train_step: kind must be 0 (D) or 1 (G)");
   if (h->has_comm && h->cfg.world_size > 1) return fail(-1, "ganmf_train_step: single-GPU entry; use ganmf_train_epoch");
   HIP_TRY(hipSetDevice(h->dev));
+  ++h->param_version;
   std::vector<int> pos(h->U, -1);
   for (int i = 0; i < n; ++i) {
     if (uids[i] < 0 || uids[i] >= h->U) return fail(-1, "ganmf_train_step: row id %d out of range", uids[i]);
@@ -2010,30 +2021,74 @@ int ganmf_train_step(ganmf_handle* h, int kind, const int32_t* uids, int32_t n, 
   return 0;
 }
 
-static int scores_device(ganmf_handle* h, const int* ids_dev, int64_t n, int transposed, float** out_dev, int* width,
-                         int* ld_out) {
-  Tensor& rowsT = transposed ? h->V : h->Ue;   // rows we gather
-  Tensor& colsT = transposed ? h->Ue : h->V;   // the other factor
-  const int W = colsT.rows, ldw = round_up(W, LD_ALIGN);
-  const size_t need_rows = (size_t)n * h->ldk, need_out = (size_t)n * ldw;
+// The scoring product itself: out[n, ldw] = rows[ids] . cols^T.  Many-tile shapes under the fp32-accurate default arithmetic take
+// the pre-split persistent kernel (gemm_bf16p.hpp): both factors are split ONCE into their three bf16 planes (the gather of the
+// scored rows rides in that pass), then one persistent launch; everything else goes through the planner (run_gemm).
+static int score_product(ganmf_handle* h, const int* ids_dev, int64_t n, int transposed, int W, int ldw, bool gemm_only = false) {
+  Tensor& rowsT = transposed ? h->V : h->Ue;
+  Tensor& colsT = transposed ? h->Ue : h->V;
+  const bool presplit = h->score_presplit && (h->tune.mode == MFMA_AUTO || h->tune.mode == MFMA_BF16X3) &&
+                        h->tune.tile != 64 && bf16p_eligible((int)n, W, h->k);
+  if (presplit) {
+    const int mpad = round_up((int)n, BF16P_TILE), npad = round_up(W, BF16P_TILE), kp2 = round_up(h->k, BF16P_BK) / 2;
+    const size_t need_a = (size_t)3 * mpad * kp2, need_b = (size_t)3 * npad * kp2;
+    if (need_a > h->sc_pa_cap) {
+      HIP_TRY(hipStreamSynchronize(h->st));
+      hipFree(h->sc_pa); h->sc_pa = nullptr; h->sc_pa_cap = 0;
+      HIP_TRY(hipMalloc((void**)&h->sc_pa, need_a * sizeof(unsigned))); h->sc_pa_cap = need_a;
+    }
+    if (need_b > h->sc_pb_cap) {
+      HIP_TRY(hipStreamSynchronize(h->st));
+      hipFree(h->sc_pb); h->sc_pb = nullptr; h->sc_pb_cap = 0;
+      HIP_TRY(hipMalloc((void**)&h->sc_pb, need_b * sizeof(unsigned))); h->sc_pb_cap = need_b;
+    }
+    const double fl = gemm_flops((double)n, W, h->k);
+    Scope s(h, T_SCORE_GEMM, fl, gemm_bytes((double)n, W, h->k));
+    if (gemm_only) {      // (ganmf_bench_scores: operands prepared by the call before)
+      HIP_TRY(gemm_bf16p_launch(h->st, h->sc_pa, mpad, h->sc_pb, npad, kp2, h->sc_out, ldw, (int)n, W));
+      return 0;
+    }
+    // one split pass: the scored rows (gathered through ids) and, unless its planes are still those of the current parameters,
+    // the other factor (h->param_version counts every call that can change a parameter)
+    const bool b_cached = h->sc_pb_src == colsT.p && h->sc_pb_version == h->param_version && h->sc_pb_rows == W;
+    const int ga = (int)std::min<long long>(4096, ((long long)mpad * kp2 + 255) / 256);
+    const int gb = b_cached ? 0 : (int)std::min<long long>(4096, ((long long)npad * kp2 + 255) / 256);
+    const PresplitJob ja{rowsT.p, h->ldk, ids_dev, (int)n, mpad, h->sc_pa}, jb{colsT.p, h->ldk, nullptr, W, npad, h->sc_pb};
+    GANMF_LAUNCH(presplit_rows_kernel, dim3(ga + gb), dim3(256), 0, h->st, ja, jb, ga, h->k, kp2);
+    HIP_TRY(hipGetLastError());
+    h->sc_pb_src = colsT.p; h->sc_pb_version = h->param_version; h->sc_pb_rows = W;
+    HIP_TRY(gemm_bf16p_launch(h->st, h->sc_pa, mpad, h->sc_pb, npad, kp2, h->sc_out, ldw, (int)n, W));
+    return 0;
+  }
+  const size_t need_rows = (size_t)n * h->ldk;
   if (need_rows > h->sc_rows_cap) {
     HIP_TRY(hipStreamSynchronize(h->st));
     hipFree(h->sc_rows); h->sc_rows = nullptr; h->sc_rows_cap = 0;
     TRY(dalloc(&h->sc_rows, need_rows)); h->sc_rows_cap = need_rows;
   }
+  if (!gemm_only) {
+    const long long total = (long long)n * (h->ldk / 4);
+    GANMF_LAUNCH(gather_rows_kernel, dim3((int)std::min<long long>(2048, (total + 255) / 256)), dim3(256), 0,
+                       h->st, rowsT.p, h->ldk, ids_dev, (int)n, h->sc_rows);
+    HIP_TRY(hipGetLastError());
+  }
+  GemmP g{};
+  g.A = h->sc_rows; g.lda = h->ldk; g.B = colsT.p; g.ldb = h->ldk;
+  g.C = h->sc_out; g.ldc = ldw; g.M = (int)n; g.N = W; g.K = h->k; g.epi.kind = EPI_STORE; g.c_pad_writable = 1;
+  return run_gemm(h, T_SCORE_GEMM, T_RED_SCORE, g, false, false);
+}
+
+static int scores_device(ganmf_handle* h, const int* ids_dev, int64_t n, int transposed, float** out_dev, int* width,
+                         int* ld_out) {
+  Tensor& colsT = transposed ? h->Ue : h->V;   // the other factor
+  const int W = colsT.rows, ldw = round_up(W, LD_ALIGN);
+  const size_t need_out = (size_t)n * ldw;
   if (need_out > h->sc_out_cap) {
     HIP_TRY(hipStreamSynchronize(h->st));
     hipFree(h->sc_out); h->sc_out = nullptr; h->sc_out_cap = 0;
     TRY(dalloc(&h->sc_out, need_out)); h->sc_out_cap = need_out;
   }
-  const long long total = (long long)n * (h->ldk / 4);
-  GANMF_LAUNCH(gather_rows_kernel, dim3((int)std::min<long long>(2048, (total + 255) / 256)), dim3(256), 0,
-                     h->st, rowsT.p, h->ldk, ids_dev, (int)n, h->sc_rows);
-  HIP_TRY(hipGetLastError());
-  GemmP g{};
-  g.A = h->sc_rows; g.lda = h->ldk; g.B = colsT.p; g.ldb = h->ldk;
-  g.C = h->sc_out; g.ldc = ldw; g.M = (int)n; g.N = W; g.K = h->k; g.epi.kind = EPI_STORE; g.c_pad_writable = 1;
-  TRY(run_gemm(h, T_SCORE_GEMM, T_RED_SCORE, g, false, false));
+  TRY(score_product(h, ids_dev, n, transposed, W, ldw));
   *out_dev = h->sc_out; *width = W; *ld_out = ldw;
   return 0;
 }
@@ -2231,17 +2286,20 @@ int ganmf_bench_scores(ganmf_handle* h, int64_t n, int transposed, int32_t iters
   float* od; int W, ldw;
   int rc = scores_device(h, ids_dev, n, transposed, &od, &W, &ldw);  // warm-up + allocation
   if (rc) return rc;
-  Tensor& colsT = transposed ? h->Ue : h->V;
-  GemmP g{};
-  g.A = h->sc_rows; g.lda = h->ldk; g.B = colsT.p; g.ldb = h->ldk;
-  g.C = h->sc_out; g.ldc = ldw; g.M = (int)n; g.N = W; g.K = h->k; g.epi.kind = EPI_STORE; g.c_pad_writable = 1;
   hipEvent_t a, b;
   hipEventCreate(&a); hipEventCreate(&b);
   const bool was = h->prof;
   h->prof = false;
-  run_gemm(h, T_SCORE_GEMM, T_RED_SCORE, g, false, false);
+  // Default: the GEMM launch alone on prepared operands (what this entry has always timed).  GANMF_BENCH_SCORES_PRODUCT=1: the whole
+  // product per iteration -- the gather of the scored rows, or on the pre-split kernel BOTH split passes (as the first scoring
+  // call after a training epoch pays them), + the GEMM.
+  const bool whole = env_int("GANMF_BENCH_SCORES_PRODUCT", 0) != 0;
+  score_product(h, ids_dev, n, transposed, W, ldw);
   hipEventRecord(a, h->st);
-  for (int i = 0; i < iters; ++i) run_gemm(h, T_SCORE_GEMM, T_RED_SCORE, g, false, false);
+  for (int i = 0; i < iters; ++i) {
+    if (whole) h->sc_pb_version = -1;
+    score_product(h, ids_dev, n, transposed, W, ldw, !whole);
+  }
   h->prof = was;
   hipEventRecord(b, h->st);
   hipError_t e = hipEventSynchronize(b);
@@ -2265,6 +2323,7 @@ int ganmf_snapshot_best(ganmf_handle* h) {
 int ganmf_restore_best(ganmf_handle* h) {
   if (!h) return fail(-1, "null handle");
   HIP_TRY(hipSetDevice(h->dev));
+  ++h->param_version;
   for (Tensor* t : all_tensors(h))
     HIP_TRY(hipMemcpyAsync(t->p, t->best, t->padded() * sizeof(float), hipMemcpyDeviceToDevice, h->st));
   HIP_TRY(hipStreamSynchronize(h->st));

@@ -51,6 +51,9 @@ def algorithmic(cls, B, N, k, e, U):
     if name == "adam_rows_U": return 24 * U * k + 4 * B * k
     if name == "densify+gather": return 4 * B * (N + 2 * k)
     if name == "d_coef": return 8 * 2 * B * e
+    if name.startswith("scoring split pass"):      # fp32 in once, three bf16 planes out (K padded to 32, rows to 128)
+        kp = (k + 31) // 32 * 32
+        return 4 * (U * k + N * k) + 6 * kp * ((U + 127) // 128 * 128 + (N + 127) // 128 * 128)
     if name.startswith("scoring"):      # S-step rows of the bench's side measurement: U[6040, k] . V[N, k]^T -> [U, N], every operand once
         return 4 * (U * k + N * k + U * N)
     if name.startswith("reduce("):

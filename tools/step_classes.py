@@ -62,6 +62,10 @@ def label(disp):
             out.append(("S:scoring 6040x3706x250 (fp32 MFMA, persistent)", d))
         elif "gemm_bf16s_mfma<128, 128, 32, false, false, 3" in n:
             out.append(("S:scoring 6040x3706x250 (split-bf16)", d))
+        elif "gemm_bf16p_persist" in n:
+            out.append(("S:scoring 6040x3706x250 (split-bf16, pre-split planes, persistent)", d))
+        elif "presplit_rows_kernel" in n:
+            out.append(("S:scoring split pass (both factors -> bf16 x 3 planes)", d))
     for st in steps:
         is_d = any("d_coef_kernel" in d["name"] or "de_dcoef_kernel" in d["name"] for d in st)
         paired = any("pair_kernel" in d["name"] and "wgrad" not in d["name"] for d in st)
