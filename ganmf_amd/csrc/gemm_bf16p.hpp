@@ -28,8 +28,12 @@ namespace ganmf {
 constexpr int BF16P_TILE = 128, BF16P_BK = 32;
 
 // One split pass for up to two matrices (blocks [0, blocks0): job 0, the rest: job 1).  Rows [0, nrows) of `src` (row r = src +
-// (ids ? ids[r] : r) * ld, K valid floats) -> planes [3][rows_pad][kp2] dwords; rows >= nrows and k >= K are zero.  One thread
-// per (row, k pair) and pass.
+// (ids ? ids[r] : r) * ld, K valid floats) -> three bf16 planes in TILE-MAJOR order, the exact LDS image the GEMM's K loop reads:
+//   planes[((tile * nt + kt) * 3 + piece) * 2048 + row * 16 + 4 * (chunk ^ swz(row)) + d]
+// for row block `tile` (128 rows), K-tile kt (32 k = 16 dwords of two consecutive k each), row inside the block, 16-byte chunk
+// of the row's 64 bytes, dword d of the chunk: one K-tile of one operand is 24 KiB of CONTIGUOUS memory, so the GEMM's loads are
+// whole cache lines (a [piece][row][K/2] layout hands every wave-level load sixteen half-used lines: measured 13 B/clk per CU of
+// operand ingest, 3 660 cycles per K-step against 1 536 of MFMA).  Rows >= nrows and k >= K are zero.  One thread per dword.
 struct PresplitJob {
   const float* src;
   int ld;
@@ -42,9 +46,9 @@ __global__ __launch_bounds__(256) void presplit_rows_kernel(const PresplitJob j0
   const PresplitJob& j = second ? j1 : j0;
   const int bx = second ? (int)blockIdx.x - blocks0 : (int)blockIdx.x, nbx = second ? (int)gridDim.x - blocks0 : blocks0;
   const long long total = (long long)j.rows_pad * kp2;
-  const size_t plane = (size_t)j.rows_pad * kp2;
+  const int nt = kp2 / 16;
   for (long long i = (long long)bx * blockDim.x + threadIdx.x; i < total; i += (long long)nbx * blockDim.x) {
-    const int r = (int)(i / kp2), k2 = (int)(i % kp2);
+    const int r = (int)(i / kp2), k2 = (int)(i % kp2);      // (reads coalesce along k; the tiled writes land as 64-byte runs)
     float x0 = 0.f, x1 = 0.f;
     if (r < j.nrows) {
       const float* s = j.src + (size_t)(j.ids ? j.ids[r] : r) * j.ld;
@@ -53,18 +57,23 @@ __global__ __launch_bounds__(256) void presplit_rows_kernel(const PresplitJob j0
     }
     unsigned h, m, l;
     split_bf16x3(x0, x1, h, m, l);
-    j.planes[i] = h; j.planes[plane + i] = m; j.planes[2 * plane + i] = l;
+    const int tile = r >> 7, row = r & 127, kt = k2 >> 4, dw = k2 & 15;
+    const int chunk = dw >> 2, d = dw & 3;
+    const size_t at = ((size_t)(tile * nt + kt) * 3) * 2048 + row * 16 + 4 * (chunk ^ ((row >> 2) & 3)) + d;
+    j.planes[at] = h; j.planes[at + 2048] = m; j.planes[at + 4096] = l;
   }
 }
 
 struct Bf16pP {
-  const unsigned* A;      // [3][a_rows_pad][kp2]
-  const unsigned* B;      // [3][b_rows_pad][kp2]
+  const unsigned* A;      // tile-major planes of the scored rows (presplit_rows_kernel): [a_rows_pad / 128][nt][3][128][16]
+  const unsigned* B;      // ... of the other factor
   int a_rows_pad, b_rows_pad, kp2;
   float* C;
   int ldc, M, N;          // rows >= M and columns >= ldc of a tile are not written
   int tiles_m, tiles_n, nt;      // nt = K-tiles per output tile (kp2 / 16)
   int xb_m, xb_n, wgs_per_xcd;
+  int late_mask;                 // experiment: which waves take the MFMA-first order (0: waves NW/2 ..)
+  unsigned long long* dbg;       // diagnostic builds (make DIAG=1, GANMF_BF16P_STAMPS=1): s_memtime sums per loop phase of workgroup 0
 };
 
 template <int WGM, int WGN>
@@ -112,11 +121,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16p_persist(const Bf16p
 #pragma unroll
       for (int r = 0; r < 16; ++r) { acc[a][b][r] = 0.f; accl[a][b][r] = 0.f; }
 
-  // ---- issue side.  A K-tile is 3 072 16-byte chunks (48 KiB); thread t stages chunks J * NTHR + t, J = 0 .. LOADS - 1, through
-  // registers: chunk c belongs to 1-KiB piece c / 64 -- pieces [0, 24) are A's (plane = piece / 8, 16-row block = piece % 8),
-  // [24, 48) B's -- and inside the piece to row (c % 64) >> 2, LDS slot c & 3, whose SOURCE chunk is slot ^ swz(row); its LDS
-  // address is simply 16 c.  (LDS-DMA, the fp32 kernels' route, delivers 16 B/clk per CU on this part: 48 KiB per K-tile would
-  // take 3 072 cycles against 1 536 of MFMA -- measured 86 us for the ML-1M product; vector loads into VGPRs come at the L1's rate.)
+  // ---- issue side.  A K-tile is 3 072 16-byte chunks (48 KiB: A's three planes, then B's); thread t stages chunks J * NTHR + t,
+  // J = 0 .. LOADS - 1, through registers.  The operands are stored tile-major in exactly this image (presplit_rows_kernel), so
+  // chunk c of A comes from 16 c bytes into the (row block, K-tile) record and goes to 16 c bytes into the ring slot: linear,
+  // whole cache lines.  (LDS-DMA, the fp32 kernels' route, was measured at the same speed: the ingest limit was the layout.)
   const unsigned* src[LOADS];      // per chunk: source dword address at the next K-tile to load
   u32x4 stage[LOADS];              // the K-tile in flight
   int issue_l = j, ktiles_left = nt;
@@ -127,29 +135,29 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16p_persist(const Bf16p
 #pragma unroll
     for (int J = 0; J < LOADS; ++J) {
       const int c = J * NTHR + tid;
-      const int piece = c >> 6, lp = c & 63;
-      const bool isb = piece >= PIECES / 2;
-      const int pp = isb ? piece - PIECES / 2 : piece;
-      const int q = pp >> 3, rb = pp & 7;
-      const int row = rb * 16 + (lp >> 2), slot = lp & 3;
+      const bool isb = c >= OPER / 4;
       const unsigned* base = isb ? p.B : p.A;
-      const int rows_pad = isb ? p.b_rows_pad : p.a_rows_pad;
-      src[J] = base + ((size_t)q * rows_pad + (isb ? n0 : m0) + row) * p.kp2 + 4 * (slot ^ SF::swz(row));
+      const int tile = (isb ? n0 : m0) >> 7;
+      src[J] = base + (size_t)tile * nt * OPER + (isb ? c - OPER / 4 : c) * 4;
     }
   };
-  auto load_tile = [&]() {          // the next K-tile of the issue stream -> registers
-    if (reinit) { issue_l += W; issue_init(); ktiles_left = nt; reinit = false; }
-#pragma unroll
-    for (int J = 0; J < LOADS; ++J) {
-      stage[J] = *reinterpret_cast<const u32x4*>(src[J]);
-      src[J] += BK / 2;
-    }
-    if (--ktiles_left == 0 && issue_l + W < bt) reinit = true;
+  auto load_begin = [&]() { if (reinit) { issue_l += W; issue_init(); ktiles_left = nt; reinit = false; } };
+  auto load_one = [&](auto JJ) {    // chunk J of the next K-tile of the issue stream -> registers
+    constexpr int J = decltype(JJ)::value;
+    stage[J] = *reinterpret_cast<const u32x4*>(src[J]);
+    src[J] += OPER;
   };
-  auto write_tile = [&](unsigned* slot_base) {      // registers -> ring slot
-#pragma unroll
-    for (int J = 0; J < LOADS; ++J) *reinterpret_cast<u32x4*>(slot_base + (J * NTHR + tid) * 4) = stage[J];
+  auto load_end = [&]() { if (--ktiles_left == 0 && issue_l + W < bt) reinit = true; };
+  auto load_tile = [&]() {
+    load_begin();
+    static_for<0, LOADS>([&](auto JJ) { load_one(JJ); });
+    load_end();
   };
+  auto write_one = [&](auto JJ, unsigned* slot_base) {      // registers -> ring slot
+    constexpr int J = decltype(JJ)::value;
+    *reinterpret_cast<u32x4*>(slot_base + (J * NTHR + tid) * 4) = stage[J];
+  };
+  auto write_tile = [&](unsigned* slot_base) { static_for<0, LOADS>([&](auto JJ) { write_one(JJ, slot_base); }); };
   issue_init();
 
   u32x4 pa[2][TM][3], pb[2][TN][3];
@@ -163,22 +171,35 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16p_persist(const Bf16p
 #pragma unroll
       for (int q = 0; q < 3; ++q) pb[set][b][q] = SF::frag(tile + OPER + q * PLANE, wc * WN + b * 32, c, li, lh);
   };
-  auto mfmas = [&](int set) {
-    // piece products in increasing weight, blocks innermost: (mid,mid) (hi,lo) (lo,hi) (mid,hi) (hi,mid) -> accl, (hi,hi) -> acc
+  // One fragment of fragment set `set`: f < 3 TM: A block f / 3, piece f % 3; else B.
+  constexpr int NFRAG = 3 * (TM + TN);
+  auto load_frag = [&](auto set_c, auto ff, const unsigned* __restrict__ tile, int c) {
+    constexpr int set = decltype(set_c)::value, f = decltype(ff)::value;
+    if constexpr (f < 3 * TM) pa[set][f / 3][f % 3] = SF::frag(tile + (f % 3) * PLANE, wr * WM + (f / 3) * 32, c, li, lh);
+    else pb[set][(f - 3 * TM) / 3][(f - 3 * TM) % 3] = SF::frag(tile + OPER + ((f - 3 * TM) % 3) * PLANE, wc * WN + ((f - 3 * TM) / 3) * 32, c, li, lh);
+  };
+  // The MFMAs of one chunk (piece products in increasing weight, blocks innermost: (mid,mid) (hi,lo) (lo,hi) (mid,hi) (hi,mid) ->
+  // accl, (hi,hi) -> acc); side(i) is issued behind MFMA i and pinned there.  In-kernel stamps (make DIAG=1, GANMF_BF16P_STAMPS):
+  // per K-step 555 + 837 cycles of LDS issue phases (fragment reads; plane writes + fragment reads) and 840 of barrier skew beside
+  // 855 of MFMA -- the two waves of a SIMD move in lockstep behind the workgroup's one barrier, so nothing covers the LDS phases
+  // (208 KiB per K-step at the 128 B/clk the CU's LDS delivers).  Dealing the fragment reads, plane writes and operand loads out
+  // over the MFMA gaps was tried (97 instead of 86 us: a stalled LDS or VMEM issue then holds back the wave's next MFMA while its
+  // SIMD partner is stalled in the same place).
+  constexpr int NMFMA = 6 * TM * TN;
+  auto mfmas_with = [&](auto set_c, auto&& side) {
+    constexpr int set = decltype(set_c)::value;
     constexpr int ta[6] = {1, 0, 2, 1, 0, 0}, tb[6] = {1, 2, 0, 0, 1, 0};
-#pragma unroll
-    for (int t6 = 0; t6 < 6; ++t6)
-#pragma unroll
-      for (int a = 0; a < TM; ++a)
-#pragma unroll
-        for (int b = 0; b < TN; ++b) {
-          if (t6 < 5)
-            accl[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pa[set][a][ta[t6]]),
-                                                                 __builtin_bit_cast(bf16x8, pb[set][b][tb[t6]]), accl[a][b], 0, 0, 0);
-          else
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pa[set][a][ta[t6]]),
-                                                                __builtin_bit_cast(bf16x8, pb[set][b][tb[t6]]), acc[a][b], 0, 0, 0);
-        }
+    static_for<0, NMFMA>([&](auto ii) {
+      constexpr int i = decltype(ii)::value, t6 = i / (TM * TN), a = (i % (TM * TN)) / TN, b = i % TN;
+      if constexpr (t6 < 5)
+        accl[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pa[set][a][ta[t6]]),
+                                                             __builtin_bit_cast(bf16x8, pb[set][b][tb[t6]]), accl[a][b], 0, 0, 0);
+      else
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pa[set][a][ta[t6]]),
+                                                            __builtin_bit_cast(bf16x8, pb[set][b][tb[t6]]), acc[a][b], 0, 0, 0);
+      side(ii);
+      __builtin_amdgcn_sched_barrier(0);
+    });
   };
 
   // ---- deferred C stores (gemm_persist.hpp): piece i of a thread = row tr + i * RPP of the staged tile, one float4 per lane;
@@ -233,28 +254,50 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16p_persist(const Bf16p
   load_frags(0, smem, 0);
 
   int slot = 0, cur_l = j, kstep = 0;
+  const bool late = p.late_mask ? ((p.late_mask >> wave) & 1) != 0 : wave >= NW / 2;            // (uniform per wave: a scalar branch)
+#ifdef GANMF_PERSIST_DIAG_BUILD
+  unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
+  const bool stamping = p.dbg != nullptr && blockIdx.x == 8 && (tid == 0 || tid == 64);
+#define BF16P_STAMP(i) if (stamping) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph[i] += t_ - tprev; tprev = t_; }
+  if (stamping) tprev = __builtin_amdgcn_s_memtime();
+#else
+#define BF16P_STAMP(i)
+#endif
   for (int s = 0; s < total; ++s) {
     const unsigned* __restrict__ cur = smem + slot * BUF;
     const int nslot = slot ^ 1;
-    // chunk 0 (k 0..15): the piece of the drained tile that was read one K-step ago is stored first; fragments of chunk 1; the
-    // next piece leaves the staging area
+    // The two waves of a SIMD (waves w and w + NW / 2) take the two halves of each chunk in OPPOSITE order: the early half issues its
+    // LDS / VMEM work and then its MFMAs, the late half its MFMAs first -- so one wave's fragment reads, plane writes and operand
+    // loads run under its SIMD partner's MFMAs although both sit behind the same workgroup barrier (in lockstep, stamps showed
+    // 555 + 837 cycles of LDS phases and 840 of barrier skew per K-step beside 855 of MFMA).
+    // chunk 0 (k 0..15): the piece of the drained tile that was read one K-step ago is stored first and the next one leaves the
+    // staging area; fragments of chunk 1
     piece_write();
-    load_frags(1, cur, 1);
     piece_read();
+    if (!late) load_frags(1, cur, 1);
     __builtin_amdgcn_sched_barrier(0);
-    mfmas(0);
-    __builtin_amdgcn_sched_barrier(0);         // (hipcc hoists the wait and the barrier below over the MFMAs otherwise)
+    BF16P_STAMP(0)
+    mfmas_with(std::integral_constant<int, 0>{}, [](auto) {});
+    if (late) { load_frags(1, cur, 1); __builtin_amdgcn_sched_barrier(0); }
+    BF16P_STAMP(1)
     // chunk 1 (k 16..31): once its fragments are in registers nothing reads slot `slot` any more
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    BF16P_STAMP(2)
     __builtin_amdgcn_s_barrier();              // every wave is done with slot `slot`; K-tile s+1 (written one K-step ago) is visible
-    if (s + 2 < total) {                       // K-tile s+2 has been in flight for a whole K-step: into the freed slot ...
-      write_tile(smem + slot * BUF);
-      if (loaded < total) { load_tile(); ++loaded; }      // ... and K-tile s+3 takes its place in the registers
-    }
-    if (s + 1 < total) load_frags(0, smem + nslot * BUF, 0);
+    BF16P_STAMP(3)
+    auto refill = [&]() {
+      if (s + 2 < total) {                     // K-tile s+2 has been in flight for a whole K-step: into the freed slot ...
+        write_tile(smem + slot * BUF);
+        if (loaded < total) { load_tile(); ++loaded; }      // ... and K-tile s+3 takes its place in the registers
+      }
+      if (s + 1 < total) load_frags(0, smem + nslot * BUF, 0);
+    };
+    if (!late) refill();
     __builtin_amdgcn_sched_barrier(0);
-    mfmas(1);
-    __builtin_amdgcn_sched_barrier(0);
+    BF16P_STAMP(4)
+    mfmas_with(std::integral_constant<int, 1>{}, [](auto) {});
+    if (late) { refill(); __builtin_amdgcn_sched_barrier(0); }
+    BF16P_STAMP(5)
     slot = nslot;
     if (++kstep == nt) {
       // ---- output tile complete: hi + corrections -> staging; its stores ride under the next tile's K-steps
@@ -281,6 +324,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16p_persist(const Bf16p
     }
   }
   flush_pieces();           // the last tile
+#ifdef GANMF_PERSIST_DIAG_BUILD
+  if (stamping) { for (int i = 0; i < 6; ++i) p.dbg[(tid ? 8 : 0) + i] = ph[i]; p.dbg[(tid ? 8 : 0) + 6] = total; }
+#endif
 }
 
 inline bool bf16p_eligible(int M, int N, int K) {
@@ -301,8 +347,31 @@ inline hipError_t gemm_bf16p_launch(hipStream_t st, const unsigned* a_planes, in
   const PersistPlan pp = persist_plan(M, N, 2 * kp2, BF16P_TILE, GEMM_CUS);
   q.xb_m = pp.xb_m; q.xb_n = pp.xb_n; q.wgs_per_xcd = pp.grid / 8;
   static const int waves = [] { const char* e = getenv("GANMF_BF16P_WAVES"); return e ? atoi(e) : 8; }();
+  static const int late_mask = [] { const char* e = getenv("GANMF_BF16P_LATE"); return e ? (int)strtol(e, nullptr, 0) : 0; }();
+  q.late_mask = late_mask;
+#ifdef GANMF_PERSIST_DIAG_BUILD
+  static unsigned long long* dbg = nullptr;
+  static int printed = 0;
+  if (getenv("GANMF_BF16P_STAMPS")) {
+    if (!dbg) { if (hipMalloc((void**)&dbg, 16 * 8) != hipSuccess) return hipErrorOutOfMemory; }
+    (void)hipMemset(dbg, 0, 16 * 8);
+    q.dbg = dbg;
+  }
+#endif
   if (waves == 4) GANMF_LAUNCH((gemm_bf16p_persist<2, 2>), dim3(pp.grid), dim3(256), 0, st, q);
   else GANMF_LAUNCH((gemm_bf16p_persist<2, 4>), dim3(pp.grid), dim3(512), 0, st, q);
+#ifdef GANMF_PERSIST_DIAG_BUILD
+  if (q.dbg && printed++ < 3) {
+    (void)hipDeviceSynchronize();
+    unsigned long long hs[16];
+    (void)hipMemcpy(hs, dbg, sizeof hs, hipMemcpyDeviceToHost);
+    for (int w = 0; w < 2; ++w)
+      fprintf(stderr, "[bf16p stamps wave %d, %llu K-steps] per K-step: top->frags issued %llu | mfmas(0) %llu | lgkm wait %llu | barrier %llu | "
+              "write+load+frags %llu | mfmas(1) %llu   (s_memtime ticks)\n", w, hs[8 * w + 6],
+              hs[8 * w + 0] / hs[8 * w + 6], hs[8 * w + 1] / hs[8 * w + 6], hs[8 * w + 2] / hs[8 * w + 6], hs[8 * w + 3] / hs[8 * w + 6],
+              hs[8 * w + 4] / hs[8 * w + 6], hs[8 * w + 5] / hs[8 * w + 6]);
+  }
+#endif
   return hipGetLastError();
 }
 
