@@ -4,7 +4,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libganmf_hip.so")
+_LIB_PATH = os.environ.get("GANMF_LIB_PATH") or os.path.join(_HERE, "libganmf_hip.so")      # (GANMF_LIB_PATH: A/B runs of two builds)
 _lib = None
 
 ABI_VERSION = 1
