@@ -267,6 +267,7 @@ struct ganmf_handle {
   GemmTune tune;
   bool debug_plan = false;
   int fused_bk = 0;               // K-tile depth of those GEMMs (GANMF_FUSED_BK)
+  int fused_tile = 64;            // their output tile (GANMF_FUSED_TILE: 64 | 128)
   int fused_mode = MFMA_BF16X3;   // K-loop arithmetic of the fused-Adam weight-gradient GEMMs under MFMA_AUTO: the two
                                   // [~1000 x ~3700 x 2B] TN GEMMs run 10 % faster on the split-bf16 loop (+2.7 % steps/s)
   std::vector<long long> seen_plans;
@@ -858,7 +859,7 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
     const bool regD = h->cfg.d_reg != 0.f;
     fused = h->fuse_adam && !dist;
     GemmTune ft;
-    ft.tile = 64; ft.ring = 2; ft.nsplit = 1;
+    ft.tile = h->fused_tile; ft.ring = 2; ft.nsplit = 1;
     ft.mode = h->tune.mode != MFMA_AUTO ? h->tune.mode : h->fused_mode;
     ft.bk = h->fused_bk;
     // the data-parallel path runs the same two GEMMs with a plain store epilogue: same tile, split and arithmetic,
@@ -1577,6 +1578,7 @@ static int create_impl(const ganmf_cfg* cfg, ganmf_handle* h) {
   if (h->tune.kg != 0 && h->tune.kg != 1 && h->tune.kg != 2 && h->tune.kg != 4) h->tune.kg = 0;
   h->debug_plan = env_int("GANMF_DEBUG_PLAN", 0) != 0;
   h->fused_mode = env_int("GANMF_FUSED_X3", 1) ? MFMA_BF16X3 : MFMA_F32;
+  h->fused_tile = env_int("GANMF_FUSED_TILE", 64) == 128 ? 128 : 64;
   h->fused_bk = env_int("GANMF_FUSED_BK", 32);   // 24 KiB of LDS per workgroup: six co-resident workgroups hide the
                                                  // theta / m / v round trip of each other (33.6 / 28.8 us against 37.2 / 32.0 at 64)
   HIP_TRY(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
