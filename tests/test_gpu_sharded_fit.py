@@ -141,6 +141,52 @@ def test_ml1m_sharded_world4_reaches_published_map(golden_dir):
     model.engine.close()
 
 
+@pytest.mark.parametrize("e", [32, 1024])
+def test_c4_full_shape_sharded_fit_trains_and_scores(e):
+    """BASELINE configs[3] through the product entry point: a 200 000 x 50 000 matrix (0.2 % dense), k = 250, eight row shards
+    of 25 000 users on the loopback communicator, emb_dim 32 and 1024, one epoch of the reference's schedule at global batch 8 x 128 (196 D + 196 G
+    updates), then scores / recommend on the gathered factors -- against the same fit on one unsharded engine."""
+    from ganmf_amd.GANMF import GANMF
+    from ganmf_amd.synthetic import glorot_params
+    U, N, k, B, world, per_row = 200000, 50000, 250, 1024, 8, 100
+    rng = np.random.RandomState(11)
+    strides = np.array([3, 7, 9, 11, 13, 17, 19, 21, 23, 27, 29, 31, 33, 37, 39, 41])      # coprime with N = 2^4 . 5^5: distinct columns
+    cols = (rng.randint(0, N, U)[:, None].astype(np.int64) + strides[rng.randint(0, len(strides), U)][:, None] * np.arange(per_row)[None, :] * 97) % N
+    urm = sps.csr_matrix((np.ones(U * per_row, np.float32), cols.astype(np.int32).ravel(), np.arange(0, U * per_row + 1, per_row)), shape=(U, N))
+    urm.sort_indices()
+    assert urm.nnz == U * per_row and int(np.diff(urm.indptr).min()) == per_row and urm.data.max() == 1.0
+    hp = dict(d_lr=1e-4, g_lr=1e-3, d_reg=1e-4, g_reg=0.0, m=1.0, recon_coefficient=0.05)
+    w0 = glorot_params(U, N, k, e, seed=9)
+    w0["be"] = (rng.randn(e) * 0.01).astype(np.float32)
+    models = {}
+    for name, kw in (("single", {}), ("sharded", dict(dist_backend="local", world_size=world))):
+        np.random.seed(5)
+        m = GANMF(urm, mode="user", seed=1, is_experiment=True, **kw)
+        m.initial_weights = w0
+        assert m.fit(num_factors=k, emb_dim=e, epochs=1, batch_size=B, **hp) == 2
+        models[name] = m
+    sh, one = models["sharded"], models["single"]
+    assert type(sh.engine).__name__ == "ShardedEngine" and sh.engine.world == world
+    assert len(sh.train_d_loss) == 1 and np.isfinite(sh.train_d_loss[-1]) and np.isfinite(sh.train_g_loss[-1])
+    np.testing.assert_allclose(sh.train_d_loss[-1], one.train_d_loss[-1], rtol=1e-4)
+    np.testing.assert_allclose(sh.train_g_loss[-1], one.train_g_loss[-1], rtol=1e-4)
+    for n, tid in (("We", 0), ("be", 1), ("Wd", 2), ("bd", 3), ("U", 100), ("V", 101)):
+        a, b = sh.engine.get_tensor(tid), one.engine.get_tensor(tid).astype(np.float64)
+        assert _err(a, b) <= 1e-4, n
+        assert _err(a, np.asarray(w0[n], np.float64).reshape(b.shape)) > 1e-4 or n == "bd", n      # ... and it did train
+    ids = np.concatenate([np.arange(world) * (U // world) + r for r in (0, 1, 12345, U // world - 1)])      # every shard, its edges included
+    s_sh, s_one = sh._compute_item_score(ids), one._compute_item_score(ids)
+    assert s_sh.shape == (len(ids), N) and _err(s_sh, s_one.astype(np.float64)) <= 1e-4
+    uf = sh.engine.get_tensor(100)[ids].astype(np.float64) @ sh.engine.get_tensor(101).astype(np.float64).T      # USER_factors[ids] @ ITEM_factors.T
+    assert _err(s_sh, uf) <= 1e-5
+    rec = sh.recommend(ids[:8], cutoff=10)
+    masked = np.where(urm[ids[:8]].toarray() > 0, -np.inf, s_sh[:8])
+    for u, r in enumerate(rec):
+        assert len(r) == 10 and np.allclose(np.sort(masked[u])[::-1][:10], masked[u][r], rtol=1e-4, atol=1e-7)
+    for m in models.values():
+        m.engine.close()
+
+
 def test_process_backend_one_rank_rccl_collectives_execute(monkeypatch):
     """One rank process on the GPU, RCCL communicator, GANMF_FORCE_COLLECTIVES=1 (inherited by the rank process): the
     reduce-scatter / Adam-on-slice / all-gather path with the REAL in-place RCCL calls, ragged owner-split schedule, against
