@@ -34,6 +34,9 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
 #include <cmath>
 #include <type_traits>
 
@@ -310,6 +313,7 @@ struct GemmP {
   // band (tile_coords below; speed only, any order is correct).
   int xb_m, xb_n, xb_band;
   int diag;                     // diagnostic builds only (make DIAG=1): timing experiments of the staged kernel's K loop
+  unsigned long long* stamps;   // diagnostic builds only: four s_memrealtime stamps per workgroup (entry, first K-tile landed, K loop done, exit)
   int n_fastest;                // list order with the tile COLUMN fastest (default: tile row fastest).  For the fused-Adam weight-gradient
                                 // products: workgroups that run at the same time then update neighbouring 256-byte segments of the same
                                 // parameter rows, i.e. whole DRAM pages of theta / m / v instead of one segment per 4-15 KiB row
@@ -738,6 +742,12 @@ __device__ __forceinline__ void gemm_f32_body(const GemmP& p, const int bid, con
 
   int tm, tn, sp, bz;
   tile_coords(p, bid, nblk, tm, tn, sp, bz);
+#ifdef GANMF_PERSIST_DIAG_BUILD
+#define GANMF_GEMM_STAMP(i) do { if (p.stamps && tid == 0) p.stamps[(size_t)bid * 4 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define GANMF_GEMM_STAMP(i) do { } while (0)
+#endif
+  GANMF_GEMM_STAMP(0);
 
   const int m0 = tm * BM, n0 = tn * BN;
   const int kbeg = sp * p.k_per_split;
@@ -794,6 +804,7 @@ __device__ __forceinline__ void gemm_f32_body(const GemmP& p, const int bid, con
   if (nt >= NS) GANMF_WAIT_VMCNT((NS - 1) * LOADS);   // tile 0 of this wave has landed ...
   else GANMF_WAIT_VMCNT(0);
   __builtin_amdgcn_s_barrier();                        // ... and of every other wave
+  GANMF_GEMM_STAMP(1);
   load_frags(0, smem, 0);
 
   // The refill of a freed ring slot is spread over the chunks of the FOLLOWING tile, LOADS / NC glds per
@@ -858,8 +869,13 @@ __device__ __forceinline__ void gemm_f32_body(const GemmP& p, const int bid, con
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
+  GANMF_GEMM_STAMP(2);
   static_assert(KG * BM * BN <= NS * BUF, "the ring must hold the KG staged partial tiles");
   gemm_epilogue<BM, BN, TM, TN, KG>(p, acc, smem, TileCoord{tm, tn, sp, bz, m0, n0});
+#ifdef GANMF_PERSIST_DIAG_BUILD
+  if (p.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
+#endif
+  GANMF_GEMM_STAMP(3);
 }
 
 template <int BM, int BN, int BK, int NS, bool AKM, bool BKM, int KG = 1>
@@ -1169,6 +1185,43 @@ inline hipError_t gemm_dispatch(hipStream_t st, const GemmP& p0, bool akm, bool 
   if (pl.mode == MFMA_BF16 || pl.mode == MFMA_BF16X3 || pl.mode == MFMA_F16) return gemm_dispatch_staged(st, p, akm, bkm, pl);
   if (pl.tile == 128) return pl.ring >= 3 ? gemm_launch_t<128, 128, 32, 3>(st, p, akm, bkm) : gemm_launch_t<128, 128, 32, 2>(st, p, akm, bkm);
   if (pl.kg == 2) return pl.ring == 3 ? gemm_launch_t<64, 64, 64, 3, 2>(st, p, akm, bkm) : gemm_launch_t<64, 64, 64, 2, 2>(st, p, akm, bkm);
+#ifdef GANMF_PERSIST_DIAG_BUILD
+  // diagnostic build (make DIAG=1), GANMF_GEMM_STAMPS=1: where the time of a 16-wave launch goes -- dispatch ramp, first K-tile,
+  // K loop, epilogue + store drain -- from four 100 MHz stamps per workgroup, printed for the first launches of every shape
+  if (pl.kg == 4 && getenv("GANMF_GEMM_STAMPS") && atoi(getenv("GANMF_GEMM_STAMPS"))) {
+    const int grid = p.tiles_m * p.tiles_n * p.nsplit * p.nbatch;
+    static unsigned long long* dbg = nullptr;
+    static int cap = 0;
+    if (grid > cap) { if (dbg) (void)hipFree(dbg); if (hipMalloc((void**)&dbg, (size_t)grid * 32) != hipSuccess) return hipErrorOutOfMemory; cap = grid; }
+    (void)hipMemsetAsync(dbg, 0, (size_t)grid * 32, st);
+    p.stamps = dbg;
+    const hipError_t e = gemm_launch_t<64, 64, 64, 3, 4>(st, p, akm, bkm);
+    (void)hipStreamSynchronize(st);
+    static std::vector<long long> seen;
+    const long long key = ((long long)p.M << 40) ^ ((long long)p.N << 20) ^ p.K ^ ((long long)akm << 62) ^ ((long long)bkm << 61) ^ ((long long)p.epi.kind << 56);
+    if (std::count(seen.begin(), seen.end(), key) < 3) {
+      seen.push_back(key);
+      std::vector<unsigned long long> hs((size_t)grid * 4);
+      (void)hipMemcpy(hs.data(), dbg, hs.size() * 8, hipMemcpyDeviceToHost);
+      unsigned long long t_min = ~0ull, t_max = 0;
+      for (int b = 0; b < grid; ++b) { t_min = std::min(t_min, hs[4 * b]); t_max = std::max(t_max, hs[4 * b + 3]); }
+      auto stat = [&](auto f, const char* name) {
+        std::vector<double> v(grid);
+        for (int b = 0; b < grid; ++b) v[b] = f(b) * 0.01;      // 100 MHz ticks -> us
+        std::sort(v.begin(), v.end());
+        fprintf(stderr, "  %-34s min %6.2f  median %6.2f  p90 %6.2f  max %6.2f us\n", name, v[0], v[grid / 2], v[(size_t)(grid * 0.9)], v[grid - 1]);
+      };
+      fprintf(stderr, "[gemm stamps] M=%d N=%d K=%d nsplit %d epi %d akm %d bkm %d: %d workgroups, first entry -> last exit %.2f us\n", p.M, p.N, p.K, p.nsplit,
+              (int)p.epi.kind, (int)akm, (int)bkm, grid, (t_max - t_min) * 0.01);
+      stat([&](int b) { return (double)(hs[4 * b] - t_min); }, "entry after the first entry");
+      stat([&](int b) { return (double)(hs[4 * b + 1] - hs[4 * b]); }, "entry -> first K-tile in LDS");
+      stat([&](int b) { return (double)(hs[4 * b + 2] - hs[4 * b + 1]); }, "K loop");
+      stat([&](int b) { return (double)(hs[4 * b + 3] - hs[4 * b + 2]); }, "epilogue + store drain");
+      stat([&](int b) { return (double)(t_max - hs[4 * b + 3]); }, "exit before the last exit");
+    }
+    return e;
+  }
+#endif
   if (pl.kg == 4) return gemm_launch_t<64, 64, 64, 3, 4>(st, p, akm, bkm);
   if (pl.ring == 4) return gemm_launch_t<64, 64, 64, 4>(st, p, akm, bkm);   // 128 KiB ring: three K-tiles (96 KiB) in flight
   return pl.ring == 3 ? gemm_launch_t<64, 64, 64, 3>(st, p, akm, bkm) : gemm_launch_t<64, 64, 64, 2>(st, p, akm, bkm);
