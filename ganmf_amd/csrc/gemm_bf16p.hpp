@@ -171,13 +171,6 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16p_persist(const Bf16p
 #pragma unroll
       for (int q = 0; q < 3; ++q) pb[set][b][q] = SF::frag(tile + OPER + q * PLANE, wc * WN + b * 32, c, li, lh);
   };
-  // One fragment of fragment set `set`: f < 3 TM: A block f / 3, piece f % 3; else B.
-  constexpr int NFRAG = 3 * (TM + TN);
-  auto load_frag = [&](auto set_c, auto ff, const unsigned* __restrict__ tile, int c) {
-    constexpr int set = decltype(set_c)::value, f = decltype(ff)::value;
-    if constexpr (f < 3 * TM) pa[set][f / 3][f % 3] = SF::frag(tile + (f % 3) * PLANE, wr * WM + (f / 3) * 32, c, li, lh);
-    else pb[set][(f - 3 * TM) / 3][(f - 3 * TM) % 3] = SF::frag(tile + OPER + ((f - 3 * TM) % 3) * PLANE, wc * WN + ((f - 3 * TM) / 3) * 32, c, li, lh);
-  };
   // The MFMAs of one chunk (piece products in increasing weight, blocks innermost: (mid,mid) (hi,lo) (lo,hi) (mid,hi) (hi,mid) ->
   // accl, (hi,hi) -> acc); side(i) is issued behind MFMA i and pinned there.  In-kernel stamps (make DIAG=1, GANMF_BF16P_STAMPS):
   // per K-step 555 + 837 cycles of LDS issue phases (fragment reads; plane writes + fragment reads) and 840 of barrier skew beside
