@@ -107,7 +107,7 @@ enum Tag : int {
   T_DENSIFY, T_GEMM_GEN, T_RED_GEN, T_GEMM_ENC, T_RED_ENC, T_GEMM_DEC, T_RED_DEC, T_DCOEF, T_GEMM_DE, T_RED_DE,
   T_GEMM_GWD, T_RED_GWD, T_GEMM_GWE, T_RED_GWE, T_ADAM_D, T_GEMM_DF, T_RED_DF, T_GEMM_GUB, T_RED_GUB, T_GEMM_GV,
   T_RED_GV, T_ADAM_V, T_ADAM_U, T_MULTIRED, T_ALLREDUCE, T_SCORE_GEMM, T_RED_SCORE, T_DIS_FWD, T_RED_DIS_FWD, T_DIS_HEAD,
-  T_DIS_GW, T_RED_DIS_GW, T_DIS_BWD, T_RED_DIS_BWD, T_FRONT, T_GWD_RED, T_PAIR, T_DE_DCOEF, T_WPAIR, T_TSPLIT, T_COUNT
+  T_DIS_GW, T_RED_DIS_GW, T_DIS_BWD, T_RED_DIS_BWD, T_FRONT, T_GWD_RED, T_PAIR, T_DE_DCOEF, T_WPAIR, T_COUNT
 };
 const char* const kTagName[T_COUNT] = {
   "densify_rows+gather", "gemm_generator[B,k]x[N,k]^T", "reduce_generator", "gemm_encode[2B,N]x[N,e]",
@@ -118,7 +118,7 @@ const char* const kTagName[T_COUNT] = {
   "gemm_dis_layer_fwd", "reduce_dis_layer_fwd", "dis_head", "gemm_dis_gW", "reduce_dis_gW", "gemm_dis_bwd",
   "reduce_dis_bwd", "gemm_generator[B,k]x[N,k]^T + CSR rows (one launch)", "gemm_gWd[2B,e]^Tx[2B,N] + reduce_dE (one launch)",
   "gemm_gUb[B,N]x[N,k] + gemm_gV[B,N]^Tx[B,k] (one launch)", "gemm_dE[2B,N]x[e,N]^T + d_coef (one launch)",
-  "gemm_gWd + gemm_gWe, fused Adam (one launch)", "split of the weight-gradient operands (bf16 x 3 planes)"};
+  "gemm_gWd + gemm_gWe, fused Adam (one launch)"};
 
 struct ProfRec { int tag; hipEvent_t a, b; double flops, bytes; };
 
@@ -268,10 +268,6 @@ struct ganmf_handle {
   bool debug_plan = false;
   int fused_bk = 0;               // K-tile depth of those GEMMs (GANMF_FUSED_BK)
   int fused_tile = 64;            // their output tile (GANMF_FUSED_TILE: 64 | 128)
-  int wgrad_lds_pad = 0;          // KiB of unused LDS per workgroup of that launch: fewer resident workgroups per CU (GANMF_WGRAD_LDS_PAD)
-  bool wgrad_presplit = true;     // their operands split once per step by tsplit_kernel (GANMF_WGRAD_PRESPLIT; gemm_bf16s.hpp)
-  unsigned* wp[4] = {nullptr, nullptr, nullptr, nullptr};      // planes of Es, Delta, [X;F|1], dE
-  size_t wp_cap[4] = {0, 0, 0, 0};
   int fused_mode = MFMA_BF16X3;   // K-loop arithmetic of the fused-Adam weight-gradient GEMMs under MFMA_AUTO: the two
                                   // [~1000 x ~3700 x 2B] TN GEMMs run 10 % faster on the split-bf16 loop (+2.7 % steps/s)
   std::vector<long long> seen_plans;
@@ -957,38 +953,6 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
 #endif
         regn[1] = p0.sq_count; regn[0] = p1.sq_count;
         const int n0 = p0.tiles_m * p0.tiles_n, n1 = p1.tiles_m * p1.tiles_n;
-        const bool pre = h->wgrad_presplit && !h->sparse_d && p0.tile_order == 0 && p1.tile_order == 0;
-        if (pre) {
-          // the four [2B, cols] operands split once, transposed into K-contiguous piece blocks (tsplit_kernel), then the pair on them
-          TsplitP tp{};
-          tp.K = 2 * nb; tp.nkt = (2 * nb + 31) / 32;
-          const float* srcs[4] = {h->Es, h->Dl, h->XF, h->dE};
-          const int lds[4] = {h->lde, h->ldN, h->ldN, h->lde}, cols[4] = {e + 1, N, N + 1, e};
-          int blocks = 0;
-          for (int i = 0; i < 4; ++i) {
-            const int ct = (cols[i] + 63) / 64;
-            const size_t need = (size_t)ct * tp.nkt * 3 * 1024;
-            if (need > h->wp_cap[i]) {
-              HIP_TRY(hipStreamSynchronize(h->st));
-              if (h->wp[i]) HIP_TRY(hipFree(h->wp[i]));
-              h->wp[i] = nullptr; h->wp_cap[i] = 0;
-              const size_t want = (size_t)ct * ((2 * (size_t)h->B + 31) / 32) * 3 * 1024;      // (the largest batch: allocated once)
-              TRY(dalloc((float**)&h->wp[i], std::max(want, need)));
-              h->wp_cap[i] = std::max(want, need);
-            }
-            tp.j[i] = TsplitJob{srcs[i], lds[i], cols[i], h->wp[i], ct};
-            blocks += ct * tp.nkt;
-            tp.end[i] = blocks;
-          }
-          {
-            Scope s2(h, T_TSPLIT, 0, 10.0 * 2 * nb * (double)(2 * (N + 1) + 2 * (e + 1)));
-            GANMF_LAUNCH(tsplit_kernel, dim3(blocks), dim3(256), 0, h->st, tp);
-            HIP_TRY(hipGetLastError());
-          }
-          g0.A = reinterpret_cast<const float*>(h->wp[0]); g0.B = reinterpret_cast<const float*>(h->wp[1]);
-          g1.A = reinterpret_cast<const float*>(h->wp[2]); g1.B = reinterpret_cast<const float*>(h->wp[3]);
-          g0.lda = g0.ldb = g1.lda = g1.ldb = tp.nkt;
-        }
         Scope s(h, T_WPAIR, gemm_flops(g0.M, g0.N, g0.K) + gemm_flops(g1.M, g1.N, g1.K),
                 // operands once + the six Adam streams; the gradients themselves never reach HBM
                 4.0 * ((double)g0.K * (g0.M + g0.N) + (double)g1.K * (g1.M + g1.N)) + 24.0 * ((double)g0.M * g0.N + (double)g1.M * g1.N));
@@ -1004,8 +968,6 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
           g0.stamps = wst; g1.stamps = wst + (size_t)n0 * 64;
         }
 #endif
-        if (pre) GANMF_LAUNCH(wgrad_pair_pre_kernel, dim3(n0 + n1), dim3(256), (size_t)h->wgrad_lds_pad * 1024, h->st, g0, g1);
-        else
         GANMF_LAUNCH(wgrad_pair_kernel, dim3(n0 + n1), dim3(256), 0, h->st, g0, g1);
         HIP_TRY(hipGetLastError());
 #ifdef GANMF_PERSIST_DIAG_BUILD
@@ -1660,8 +1622,6 @@ static int create_impl(const ganmf_cfg* cfg, ganmf_handle* h) {
   h->debug_plan = env_int("GANMF_DEBUG_PLAN", 0) != 0;
   h->fused_mode = env_int("GANMF_FUSED_X3", 1) ? MFMA_BF16X3 : MFMA_F32;
   h->fused_tile = env_int("GANMF_FUSED_TILE", 64) == 128 ? 128 : 64;
-  h->wgrad_presplit = env_int("GANMF_WGRAD_PRESPLIT", 1) != 0;
-  h->wgrad_lds_pad = std::max(0, std::min(100, env_int("GANMF_WGRAD_LDS_PAD", 0)));
   h->fused_bk = env_int("GANMF_FUSED_BK", 32);   // 24 KiB of LDS per workgroup: six co-resident workgroups hide the
                                                  // theta / m / v round trip of each other (33.6 / 28.8 us against 37.2 / 32.0 at 64)
   HIP_TRY(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
@@ -1799,7 +1759,6 @@ int ganmf_destroy(ganmf_handle* h) {
   if (h->st2) hipStreamDestroy(h->st2);
   if (h->st) hipStreamDestroy(h->st);
   hipFree(h->slab2); hipFree(h->counters); hipFree(h->counters2);
-  for (int i = 0; i < 4; ++i) hipFree(h->wp[i]);
   delete h;
   return 0;
 }

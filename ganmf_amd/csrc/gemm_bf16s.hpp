@@ -309,234 +309,6 @@ __device__ __forceinline__ void gemm_bf16s_body(const GemmP& p, const int bid, c
   GANMF_S_STAMP(63);
 }
 
-// ---- operands split AHEAD of the product (the fused-Adam weight-gradient pair of the discriminator step) ------------------
-// The TN products gWd_ext = Es^T . Delta and gWe_ext = [X;F|1]^T . dE contract over the batch rows: both operands are K-major, every
-// 64 x 64 tile of the 1 856 re-splits its two 64 x 256 operand panels, and the in-kernel stamps (profiles/r03_gemm_stamps.md) show
-// the K loop bound by instruction issue -- 11 VALU per element pair for the split, 48 ds_read_b32 per K-tile for the K-major fragment
-// image, the bounds logic of the K-major loads -- with 0.19 us of MFMA in a 1.38 us K-tile.  tsplit_kernel splits the four
-// [2B, cols] matrices ONCE per step and writes them transposed, as K-contiguous piece blocks in exactly the LDS image of
-// SplitStage<64, 32, false> (block = 64 operand rows x 32 k of one piece = 4 KiB; planes[col tile][k tile][piece][1024 dwords]);
-// the product's K loop is then 16-byte copies, ds_read_b128 fragments and MFMAs (PlaneStage, gemm_bf16s_pre_body).  Same pieces,
-// same chunk and product order as the in-kernel split: bitwise the same sums.
-struct TsplitJob {
-  const float* src;      // [K][ld] row-major: k = row
-  int ld, cols;          // operand rows of the product = columns [0, cols) of src
-  unsigned* planes;      // [col_tiles][nkt][3][1024]
-  int col_tiles;
-};
-struct TsplitP {
-  TsplitJob j[4];
-  int end[4];            // blocks of jobs 0..i (one block = one 64-column x 32-k patch)
-  int K, nkt;            // valid k rows; 32-k tiles written (k >= K and columns >= cols as zeros)
-};
-
-__global__ __launch_bounds__(256) void tsplit_kernel(const TsplitP p) {
-  __shared__ float tile[32][65];
-  const int bid = (int)blockIdx.x;
-  const int ji = bid < p.end[0] ? 0 : bid < p.end[1] ? 1 : bid < p.end[2] ? 2 : 3;
-  const TsplitJob& j = p.j[ji];
-  const int lb = bid - (ji ? p.end[ji - 1] : 0);
-  const int ct = lb / p.nkt, kt = lb % p.nkt;
-  const int tid = threadIdx.x;
-#pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    const int w = r * 256 + tid, k = w >> 4, c4 = w & 15;
-    const int gk = kt * 32 + k, gc = ct * 64 + 4 * c4;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (gk < p.K && gc < j.ld) v = *reinterpret_cast<const float4*>(j.src + (size_t)gk * j.ld + gc);      // (ld is a multiple of 64 floats)
-    if (gc + 0 >= j.cols) v.x = 0.f;
-    if (gc + 1 >= j.cols) v.y = 0.f;
-    if (gc + 2 >= j.cols) v.z = 0.f;
-    if (gc + 3 >= j.cols) v.w = 0.f;
-    tile[k][4 * c4 + 0] = v.x; tile[k][4 * c4 + 1] = v.y; tile[k][4 * c4 + 2] = v.z; tile[k][4 * c4 + 3] = v.w;
-  }
-  __syncthreads();
-  const int col = tid >> 2, c8 = tid & 3;
-  u32x4 pc[3];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    unsigned h, m, l;
-    split_bf16x3(tile[8 * c8 + 2 * q][col], tile[8 * c8 + 2 * q + 1][col], h, m, l);
-    pc[0][q] = h; pc[1][q] = m; pc[2][q] = l;
-  }
-  unsigned* out = j.planes + ((size_t)(ct * p.nkt + kt) * 3) * 1024 + col * 16 + 4 * (c8 ^ ((col >> 2) & 3));
-#pragma unroll
-  for (int q = 0; q < 3; ++q) *reinterpret_cast<u32x4*>(out + q * 1024) = pc[q];
-}
-
-struct PlaneStage {       // one operand's 64-row panel of tsplit_kernel's planes, K-tile 32: 16 bytes per piece and thread
-  static constexpr int PLANE = 1024;
-  const unsigned* ptr;
-  int dst;
-  __device__ inline void init(const unsigned* planes, int nkt, int row_tile, int tid) {
-    const int row = tid >> 2, c8 = tid & 3;
-    dst = row * 16 + 4 * (c8 ^ ((row >> 2) & 3));
-    ptr = planes + ((size_t)row_tile * nkt * 3) * PLANE + dst;
-  }
-  __device__ inline void load(u32x4 (&v)[3]) {
-#pragma unroll
-    for (int q = 0; q < 3; ++q) v[q] = *reinterpret_cast<const u32x4*>(ptr + q * PLANE);
-    ptr += 3 * PLANE;
-  }
-  __device__ inline void store(unsigned* __restrict__ planes, const u32x4 (&v)[3]) const {
-#pragma unroll
-    for (int q = 0; q < 3; ++q) *reinterpret_cast<u32x4*>(planes + q * PLANE + dst) = v[q];
-  }
-};
-
-// 64 x 64 tile, K-tile 32, three pieces, unsplit K range: p.A / p.B are tsplit planes (as const float*), p.lda = p.ldb = their
-// K-tiles per panel.  The loop below is gemm_bf16s_body's with the staging replaced.
-__device__ __forceinline__ void gemm_bf16s_pre_body(const GemmP& p, const int bid, const int nblk, float* __restrict__ smem) {
-  constexpr int BM = 64, BN = 64, BK = 32, TM = 1, TN = 1, NC = BK / 16, WM = 32, WN = 32;
-  using SF = SplitStage<64, BK, false>;
-  unsigned* const planes_a = reinterpret_cast<unsigned*>(smem);
-  unsigned* const planes_b = planes_a + 3 * PlaneStage::PLANE;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 1, wc = wave & 1;
-  const int li = lane & 31, lh = lane >> 5;
-  int tm, tn, sp, bz;
-  tile_coords(p, bid, nblk, tm, tn, sp, bz);
-  const int m0 = tm * BM, n0 = tn * BN;
-  const int nt = (p.K + BK - 1) / BK;
-  GANMF_S_STAMP(0);
-
-  f32x16 acc[TM][TN], accl[TM][TN];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { acc[0][0][r] = 0.f; accl[0][0][r] = 0.f; }
-
-  // The tile is a gradient and its epilogue is TF-Adam on theta / m / v in place (EPI_ADAM, unsplit): the three streams of the tile --
-  // 12 x 16 bytes per lane -- are requested HERE, before the K loop, so that the HBM round trip runs under the workgroup's own
-  // products.  (With the fetch in the epilogue the launch ran as its phases one after the other: most of the 1 856 workgroups are
-  // resident at once, so they all multiplied first -- HBM idle -- and all streamed afterwards -- matrix cores idle: 48 us for a
-  // 30 us K phase and a 32 us stream phase, profiles/r03_gemm_stamps.md.)
-  const EpiD& e = p.epi;
-  constexpr int C4 = BN / 4, RPP = 256 / C4, J = BM / RPP;      // 16 float4 columns, 16 rows per step, 4 steps
-  const int tc = tid % C4, tr = tid / C4;
-  const int col = n0 + tc * 4;
-  const bool quad = col + 3 < p.N;
-  float4 t4[J], m4[J], v4[J];
-#pragma unroll
-  for (int jj = 0; jj < J; ++jj) {
-    const int row = m0 + tr + jj * RPP;
-    if (row < p.M && quad) {
-      const size_t off = (size_t)row * p.ldc + col;
-      t4[jj] = *reinterpret_cast<const float4*>(e.adam_theta + off);
-      m4[jj] = *reinterpret_cast<const float4*>(e.adam_m + off);
-      v4[jj] = *reinterpret_cast<const float4*>(e.adam_v + off);
-    }
-  }
-
-  PlaneStage la, lb;
-  la.init(reinterpret_cast<const unsigned*>(p.A), p.lda, tm, tid);
-  lb.init(reinterpret_cast<const unsigned*>(p.B), p.ldb, tn, tid);
-  u32x4 ra[3], rb[3];
-  la.load(ra);
-  lb.load(rb);
-  la.store(planes_a, ra);
-  lb.store(planes_b, rb);
-  __syncthreads();
-
-  u32x4 pa[2][TM][3], pb[2][TN][3];
-  auto load_frags = [&](int set, int c) {
-#pragma unroll
-    for (int q = 0; q < 3; ++q) pa[set][0][q] = SF::frag(planes_a + q * SF::PLANE, wr * WM, c, li, lh);
-#pragma unroll
-    for (int q = 0; q < 3; ++q) pb[set][0][q] = SF::frag(planes_b + q * SF::PLANE, wc * WN, c, li, lh);
-  };
-  auto mfmas = [&](int set) {      // (the order of gemm_bf16s_body::mfmas)
-    constexpr int ta[6] = {1, 0, 2, 1, 0, 0}, tb[6] = {1, 2, 0, 0, 1, 0};
-#pragma unroll
-    for (int t6 = 0; t6 < 6; ++t6) {
-      if (t6 < 5)
-        accl[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pa[set][0][ta[t6]]),
-                                                             __builtin_bit_cast(bf16x8, pb[set][0][tb[t6]]), accl[0][0], 0, 0, 0);
-      else
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pa[set][0][ta[t6]]),
-                                                            __builtin_bit_cast(bf16x8, pb[set][0][tb[t6]]), acc[0][0], 0, 0, 0);
-    }
-  };
-  for (int it = 0; it < nt; ++it) {
-    const bool more = it + 1 < nt;
-    if (more) {
-#ifdef GANMF_PERSIST_DIAG_BUILD
-      if (!(p.diag & 16))            // timing only: the first K-tile's registers are reused (no operand traffic after the prologue)
-#endif
-      {
-      la.load(ra);
-      lb.load(rb);
-      }
-    }
-    if (it < 12) GANMF_S_STAMP(1 + 5 * it);
-    load_frags(0, 0);
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      if (c + 1 < NC) load_frags((c + 1) & 1, c + 1);
-      mfmas(c & 1);
-    }
-    if (it < 12) GANMF_S_STAMP(2 + 5 * it);
-    __syncthreads();
-    if (it < 12) GANMF_S_STAMP(3 + 5 * it);
-    if (more) {
-      la.store(planes_a, ra);
-      lb.store(planes_b, rb);
-      if (it < 12) GANMF_S_STAMP(4 + 5 * it);
-      __syncthreads();
-      if (it < 12) GANMF_S_STAMP(5 + 5 * it);
-    }
-  }
-  GANMF_S_STAMP(62);
-  acc[0][0] += accl[0][0];
-  // epilogue = gemm_epilogue's EPI_ADAM row pass on the prefetched streams: same staging, same element order, same sums of squares
-  float* __restrict__ ct = smem;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) ct[(wr * WM + (r & 3) + 8 * (r >> 2) + 4 * lh) * BN + wc * WN + li] = acc[0][0][r];
-  __syncthreads();
-  const float alpha = *e.adam_alpha;
-  float* __restrict__ theta_out = e.adam_theta_out ? e.adam_theta_out : e.adam_theta;
-  float sq = 0.f;
-#ifdef GANMF_PERSIST_DIAG_BUILD
-  if (p.diag & 8) return;      // timing only: the K phase (the stream fetches were issued, nothing is stored)
-#endif
-#pragma unroll
-  for (int jj = 0; jj < J; ++jj) {
-    const int row_l = tr + jj * RPP, row = m0 + row_l;
-    if (row < p.M && col < p.N) {
-      const float4 v = *reinterpret_cast<const float4*>(ct + row_l * BN + tc * 4);
-      const size_t off = (size_t)row * p.ldc + col;
-      if (quad) {
-        adam_update(v.x, alpha, e.adam_reg, t4[jj].x, m4[jj].x, v4[jj].x, sq);
-        adam_update(v.y, alpha, e.adam_reg, t4[jj].y, m4[jj].y, v4[jj].y, sq);
-        adam_update(v.z, alpha, e.adam_reg, t4[jj].z, m4[jj].z, v4[jj].z, sq);
-        adam_update(v.w, alpha, e.adam_reg, t4[jj].w, m4[jj].w, v4[jj].w, sq);
-        *reinterpret_cast<float4*>(theta_out + off) = t4[jj];
-        *reinterpret_cast<float4*>(e.adam_m + off) = m4[jj];
-        *reinterpret_cast<float4*>(e.adam_v + off) = v4[jj];
-      } else {
-        const float o[4] = {v.x, v.y, v.z, v.w};
-        for (int q = 0; q < 4 && col + q < p.N; ++q) {
-          float th = e.adam_theta[off + q];
-          adam_update(o[q], alpha, e.adam_reg, th, e.adam_m[off + q], e.adam_v[off + q], sq);
-          theta_out[off + q] = th;
-        }
-      }
-    }
-  }
-  if (e.sq_partials) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
-    __syncthreads();   // every wave is done reading the staged tile
-    if (lane == 0) smem[wave] = sq;
-    __syncthreads();
-    if (tid == 0) e.sq_partials[(size_t)bz * e.sq_stride + tn * p.tiles_m + tm] = (smem[0] + smem[1]) + (smem[2] + smem[3]);
-  }
-#ifdef GANMF_PERSIST_DIAG_BUILD
-  if (p.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
-#endif
-  GANMF_S_STAMP(63);
-}
-
 template <int BM, int BN, int BK, bool AKM, bool BKM, int NPIECE, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void gemm_bf16s_mfma(const GemmP p) {
   __shared__ __attribute__((aligned(16))) float smem[Bf16sLds<BM, BN, BK, NPIECE>::DW];

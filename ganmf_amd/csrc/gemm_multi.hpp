@@ -86,15 +86,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_pair_kernel(const GemmP g0, cons
   else gemm_bf16s_body<64, 64, 32, true, true, 3>(g1, (int)blockIdx.x - n0, n1, smem);
 }
 
-// the same pair on operands that tsplit_kernel split ahead of the launch (gemm_bf16s.hpp)
-__global__ __launch_bounds__(256, 4) void wgrad_pair_pre_kernel(const GemmP g0, const GemmP g1) {
-  __shared__ __attribute__((aligned(16))) float smem[Bf16sLds<64, 64, 32, 3>::DW];
-  const int n0 = g0.tiles_m * g0.tiles_n;
-  const int n1 = g1.tiles_m * g1.tiles_n;
-  if ((int)blockIdx.x < n0) gemm_bf16s_pre_body(g0, (int)blockIdx.x, n0, smem);
-  else gemm_bf16s_pre_body(g1, (int)blockIdx.x - n0, n1, smem);
-}
-
 // ---- host side: can this plan ride in the combined launch?
 inline bool plan_is_f32_64_kg(const GemmPlan& pl, int kg) {
   return pl.mode == MFMA_F32 && pl.tile == 64 && pl.ring == 3 && pl.kg == kg && !pl.persist;
