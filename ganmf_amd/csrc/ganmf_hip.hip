@@ -200,6 +200,7 @@ struct ganmf_handle {
   size_t slab2_elems = 0;
   unsigned *counters = nullptr, *counters2 = nullptr;   // split-K arrival counters (zero between launches)
   bool inkernel_reduce = true;
+  int inlaunch_tags = 0;
   int inlaunch_max = 4;
   float* rs = nullptr;
   float* scal = nullptr;
@@ -511,7 +512,10 @@ int run_gemm(ganmf_handle* h, int tag_gemm, int tag_red, GemmP g, bool akm, bool
   if (pl.nsplit > 1) TRY(ensure_slab(h, gemm_slab_elems(pl, g.M, g.ldc, g.nbatch), slab_lane));
   float* slab = slab_lane ? h->slab2 : h->slab;
   const size_t slab_elems = slab_lane ? h->slab2_elems : h->slab_elems;
-  unsigned* counters = h->inkernel_reduce ? (lane ? h->counters2 : h->counters) : nullptr;
+  // in-launch split-K reduction (the last workgroup to arrive at a tile sums its slabs, gemm_f32.hpp): for every product
+  // (GANMF_INKERNEL_REDUCE=1) or for the classes of GANMF_INLAUNCH_TAGS (1 encode, 2 decode, 4 dF, 8 dE of the generator step)
+  const int tag_bit = tag_gemm == T_GEMM_ENC ? 1 : tag_gemm == T_GEMM_DEC ? 2 : tag_gemm == T_GEMM_DF ? 4 : tag_gemm == T_GEMM_DE ? 8 : 0;
+  unsigned* counters = (h->inkernel_reduce || (h->inlaunch_tags & tag_bit)) ? (lane ? h->counters2 : h->counters) : nullptr;
   const size_t n_tiles = (size_t)pl.tiles_m * pl.tiles_n * g.nbatch;
   // the last-arriving workgroup reads nsplit slab tiles alone (~60-120 GB/s per block): in-launch
   // reduction only pays for shallow splits; deep splits keep the chip-wide reduce kernel
@@ -1643,6 +1647,7 @@ static int create_impl(const ganmf_cfg* cfg, ganmf_handle* h) {
   h->pair_ring = env_int("GANMF_PAIR_RING", 2) == 3 ? 3 : 2;
   h->inkernel_reduce = env_int("GANMF_INKERNEL_REDUCE", 0) != 0;   // measured slower than the chip-wide reduce kernel
   h->inlaunch_max = env_int("GANMF_INLAUNCH_MAX", 4);
+  h->inlaunch_tags = env_int("GANMF_INLAUNCH_TAGS", 0);
   h->force_coll = env_int("GANMF_FORCE_COLLECTIVES", 0) != 0;
   h->score_presplit = env_int("GANMF_SCORE_PRESPLIT", 1) != 0;
   h->fork_attach = env_int("GANMF_FORK_ATTACH", 1) != 0;
