@@ -118,6 +118,35 @@ def test_sharded_fit_early_stopping_matches_single_gpu(golden_dir):
     assert abs(out["single"][1] - out["sharded"][1]) <= 0.004 and abs(out["single"][2] - out["sharded"][2]) <= 0.004
 
 
+def test_sharded_model_saves_and_loads_in_reference_format(tmp_path):
+    """saveModel / loadModel (GANMF.py:309-339) on a row-sharded model: the bundle holds the GATHERED user embeddings and loads into a
+    sharded model (rows scattered back to their owners: one more epoch continues bit-identically on both) and into an unsharded one."""
+    from ganmf_amd.GANMF import GANMF
+    rng = np.random.RandomState(5)
+    urm = _urm(rng, 90, 70, 0.1)
+    kw = dict(dist_backend="local", world_size=3)
+    hp = dict(num_factors=5, emb_dim=9, batch_size=16, d_lr=1e-3, g_lr=1e-3, d_reg=1e-4, recon_coefficient=0.1)
+    np.random.seed(3)
+    a = GANMF(urm, mode="user", seed=4, is_experiment=True, **kw)
+    a.fit(epochs=2, **hp)
+    ids = np.arange(urm.shape[0])
+    before = a._compute_item_score(ids)
+    a.saveModel(str(tmp_path))
+    b = GANMF(urm, mode="user", is_experiment=True, **kw)
+    b.loadModel(str(tmp_path))
+    assert type(b.engine).__name__ == "ShardedEngine"
+    np.testing.assert_array_equal(b._compute_item_score(ids), before)
+    c = GANMF(urm, mode="user", is_experiment=True)
+    c.loadModel(str(tmp_path))
+    np.testing.assert_array_equal(c._compute_item_score(ids), before)
+    for tid in (0, 1, 2, 3, 100, 101):
+        np.testing.assert_array_equal(b.engine.get_tensor(tid), a.engine.get_tensor(tid))
+        np.testing.assert_array_equal(c.engine.get_tensor(tid), a.engine.get_tensor(tid))
+    assert b.recommend(ids[:10], cutoff=5) == a.recommend(ids[:10], cutoff=5)
+    for m in (a, b, c):
+        m.engine.close()
+
+
 @pytest.mark.slow
 def test_ml1m_sharded_world4_reaches_published_map(golden_dir):
     """BASELINE configs[1] trained through the sharded entry point with four ranks: same band as the single-GPU KAT."""
