@@ -105,3 +105,29 @@ def test_sharded_engine_argument_checks():
         ShardedEngine(3, 5, 2, 2, 4, world_size=4, backend="local", engine_factory=recording_factory)
     with pytest.raises(ValueError):
         ShardedEngine(10, 5, 2, 2, 4, backend="threads", engine_factory=recording_factory)
+
+
+def test_host_class_reads_the_sharding_request_from_the_environment(monkeypatch):
+    """The reference's drivers construct GANMF(URM_train, mode=..., seed=..., is_experiment=True) (RunBestParameters.py:86-88): the
+    row-sharded fit is asked for through GANMF_DEVICES / GANMF_DIST_BACKEND / GANMF_WORLD_SIZE without touching them; explicit
+    constructor arguments win."""
+    import scipy.sparse as sps
+    from ganmf_amd.DisGANMF import DisGANMF
+    from ganmf_amd.GANMF import GANMF
+    urm = sps.identity(12, format="csr", dtype=np.float32)
+    for k in ("GANMF_DEVICES", "GANMF_DIST_BACKEND", "GANMF_WORLD_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    m = GANMF(urm, mode="user", is_experiment=True)
+    assert m.devices is None and m.dist_backend == "process" and m.world_size is None and not m._sharded()
+    monkeypatch.setenv("GANMF_DEVICES", "0, 1,2,3")
+    for cls in (GANMF, DisGANMF):
+        m = cls(urm, mode="item", is_experiment=True)
+        assert m.devices == [0, 1, 2, 3] and m._sharded()
+    assert GANMF(urm, is_experiment=True, devices=[5]).devices == [5] and not GANMF(urm, is_experiment=True, devices=[5])._sharded()
+    monkeypatch.delenv("GANMF_DEVICES")
+    monkeypatch.setenv("GANMF_DIST_BACKEND", "local")
+    monkeypatch.setenv("GANMF_WORLD_SIZE", "4")
+    m = GANMF(urm, is_experiment=True)
+    assert m.dist_backend == "local" and m.world_size == 4 and m._sharded()
+    assert not GANMF(urm, is_experiment=True, world_size=1)._sharded()
+    assert GANMF(urm, is_experiment=True, dist_backend="process").dist_backend == "process"
