@@ -80,6 +80,7 @@ __device__ __forceinline__ void body(const P& p, unsigned* smem) {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (t + NS - 1 < nt) issue((t + NS - 1) % NS);      // slot of tile t-1: every wave is past its reads
+#ifndef BF16W_STREAM_ONLY
     if ((kg >> 1) == (t & 1)) {
       const unsigned* s = smem + (t % NS) * STAGE;
       const int c = kg & 1;      // 16-wide chunk of the K-tile
@@ -106,6 +107,7 @@ __device__ __forceinline__ void body(const P& p, unsigned* smem) {
           else acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, acc[a], 0, 0, 0);
         }
     }
+#endif      // (-DBF16W_STREAM_ONLY: the LDS-DMA ring alone, no fragment reads, no MFMAs: what the operand streaming costs by itself)
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
