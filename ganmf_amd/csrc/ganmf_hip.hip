@@ -34,6 +34,7 @@
 #include "../../include/ganmf_hip.h"
 #include "gemm_f32.hpp"
 #include "gemm_bf16s.hpp"
+#include "gemm_bf16k.hpp"
 #include "gemm_persist.hpp"
 #include "gemm_bf16p.hpp"
 #include "kernels.hpp"
@@ -199,6 +200,7 @@ struct ganmf_handle {
   float* slab2 = nullptr;                // split-K workspace of the side lane
   size_t slab2_elems = 0;
   unsigned *counters = nullptr, *counters2 = nullptr;   // split-K arrival counters (zero between launches)
+  int x3kg = 3;                   // GANMF_X3KG bits: 16-wave split-bf16 loop for the plans of the 16-wave fp32 ring kernel (1 NT, 2 K-major B)
   bool inkernel_reduce = true;
   int inlaunch_tags = 0;
   int inlaunch_max = 4;
@@ -504,6 +506,10 @@ int run_gemm(ganmf_handle* h, int tag_gemm, int tag_red, GemmP g, bool akm, bool
   const GemmTune& tn = force ? *force : h->tune;
   GemmPlan pl = gemm_plan(g.M, g.N, g.K, g.nbatch, g.epi.sq_partials != nullptr, tn, g.epi.kind == EPI_ADAM);
   pl.persist = gemm_persist_eligible(g, akm, bkm, pl, tn.persist) ? (tn.persist >= 2 ? tn.persist : 1) : 0;
+  // a plan for the 16-wave fp32 ring kernel (one 64 x 64 tile per CU) runs the 16-wave split-bf16 loop instead: same grid, same split,
+  // same epilogue, 6 / 16 of the MFMA cycles (gemm_bf16k.hpp)
+  if (!force && pl.mode == MFMA_F32 && pl.tile == 64 && pl.kg == 4 && pl.ring == 3 && !pl.persist && !(akm && !bkm) && tag_gemm != T_GEMM_GUB && tag_gemm != T_GEMM_GV &&      // (gUb / gV: their other form is the fp32 pair_kernel)
+      ((h->x3kg & 1) && !akm && !bkm || (h->x3kg & 2) && bkm)) pl.mode = MFMA_BF16X3;      // bit 0: NT products, bit 1: products with a K-major B
   if (defer) *defer = SlabRef{g.C, 1, 0};
   // (a deep split behind a small output is summed 16 threads per element by the reduce kernel: not left to the consumer)
   const bool deferred = defer && pl.nsplit > 1 && g.epi.kind == EPI_STORE && g.nbatch == 1 &&
@@ -711,7 +717,8 @@ int rows_and_generator(ganmf_handle* h, const int* rows_dev, int nb, int which, 
     Scope s(h, T_FRONT, gemm_flops(g.M, g.N, g.K), gemm_bytes(g.M, g.N, g.K) + 4.0 * nb * (N + 2 * k));
     g.A = h->Ue.p; g.a_gather = rows_dev;        // A row r = U[rows[r]]: the lookup rides in the operand fetch
     fill_plan(g, pl);
-    GANMF_LAUNCH(front_kernel<4>, dim3(pl.tiles_m * pl.tiles_n + nb), dim3(1024), 0, h->st, g, d);
+    if (h->x3kg & 1) GANMF_LAUNCH((front_kernel<4, true>), dim3(pl.tiles_m * pl.tiles_n + nb), dim3(1024), 0, h->st, g, d);
+    else GANMF_LAUNCH(front_kernel<4>, dim3(pl.tiles_m * pl.tiles_n + nb), dim3(1024), 0, h->st, g, d);
     HIP_TRY(hipGetLastError());
     return 0;
   }
@@ -848,7 +855,8 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
       q.C = h->slab; q.c_split_stride = (long long)gde.M * gde.ldc; q.c_batch_stride = (long long)gde.M * gde.ldc;
       const int ng = pde.tiles_m * pde.tiles_n * pde.nsplit;
       const int nd = h->dcoef_spread ? 0 : (int)std::max<long long>(1, std::min<long long>(32, (dc_total + 4095) / 4096));
-      GANMF_LAUNCH(de_dcoef_kernel<4>, dim3(ng + nd), dim3(1024), 0, h->st, q, dc, nd);
+      if (h->x3kg & 1) GANMF_LAUNCH((de_dcoef_kernel<4, true>), dim3(ng + nd), dim3(1024), 0, h->st, q, dc, nd);
+      else GANMF_LAUNCH(de_dcoef_kernel<4>, dim3(ng + nd), dim3(1024), 0, h->st, q, dc, nd);
       HIP_TRY(hipGetLastError());
       dcoef_done = true;
     }
@@ -1643,6 +1651,7 @@ static int create_impl(const ganmf_cfg* cfg, ganmf_handle* h) {
   h->defer_gub = env_int("GANMF_DEFER_GUB", 1) != 0;
   h->multi = env_int("GANMF_MULTI", 31);
   h->dis_fuse_hidden = env_int("GANMF_DIS_FUSE_HIDDEN", 1) != 0;
+  h->x3kg = env_int("GANMF_X3KG", 3);      // +10 % steps/s at the ML-1M shape (profiles/r03_gemm_stamps.md)
   h->dcoef_spread = env_int("GANMF_DCOEF_SPREAD", 1) != 0;
   h->pair_ring = env_int("GANMF_PAIR_RING", 2) == 3 ? 3 : 2;
   h->inkernel_reduce = env_int("GANMF_INKERNEL_REDUCE", 0) != 0;   // measured slower than the chip-wide reduce kernel
@@ -2439,6 +2448,7 @@ int ganmf_gemm_f32(int device, const float* A, const float* B, float* C, int64_t
   if (tune.kg != 0 && tune.kg != 1 && tune.kg != 2 && tune.kg != 4) tune.kg = 0;
   GemmPlan pl = gemm_plan(g.M, g.N, g.K, 1, false, tune);
   pl.persist = gemm_persist_eligible(g, a_kmajor, b_kmajor, pl, tune.persist) ? (tune.persist >= 2 ? tune.persist : 1) : 0;
+  if (env_int("GANMF_X3KG", 0) && pl.mode == MFMA_F32 && pl.tile == 64 && pl.kg == 4 && pl.ring == 3 && !pl.persist) pl.mode = MFMA_BF16X3;      // (tests: the 16-wave split-bf16 kernel)
   const size_t slab_elems = gemm_slab_elems(pl, g.M, ldc, 1);
   if (slab_elems) TRY(dalloc(&slab, slab_elems));
   unsigned* counters = nullptr;

@@ -1,0 +1,217 @@
+// The split-bf16 loop (gemm_bf16s.hpp: exact three-way split, six piece products, fp32 accumulate) in the 16-wave form of the
+// fp32 ring kernel: ONE 64 x 64 tile per workgroup of 1024 threads = 4 K groups x (2 x 2 waves), K-tile 64 = four 16-wide
+// chunks, chunk g of every K-tile to K group g.  For the step's K-heavy small-M products (256 / 128 rows, K = 1000 .. 3700,
+// <= 256 workgroups: one per CU), where the 4-wave staged kernel is latency-bound (27 us against the fp32 ring kernel's 21 on the
+// encode GEMM) and the fp32 ring kernel is MFMA-bound at the 2.0 GHz the chip holds (profiles/r03_gemm_stamps.md).
+//   * staging: waves 0-7 own the A tile, waves 8-15 the B tile, one item of 8 elements per thread and K-tile (two 16-byte loads,
+//     four pair splits, three 16-byte plane stores); the loads of PD = 4 K-tiles are in flight in registers (32 registers), so the
+//     fetch latency is covered without an LDS ring and without more workgroups per CU;
+//   * two plane buffers (2 x 48 KiB) and ONE barrier per K-tile: in iteration t every wave reads its fragments of buffer t & 1 and
+//     issues its six MFMAs, then splits K-tile t + 1 into buffer (t + 1) & 1 (last read in iteration t - 1, behind the barrier);
+//   * per K-tile and SIMD: 4 x 6 MFMAs = 768 cycles of matrix pipe against 2 048 for the fp32 MFMA, beside ~800 cycles of VALU issue
+//     for the splits; 144 KiB of LDS traffic (256 B/clk: 560 cycles);
+//   * same pieces, same product order and the same two accumulators as gemm_bf16s_body; the K groups' partial sums meet in the
+//     epilogue in group order (gemm_epilogue, KG = 4).
+#pragma once
+#include "gemm_bf16s.hpp"
+
+namespace ganmf {
+
+typedef float f32x4k __attribute__((ext_vector_type(4)));      // (a native vector: HIP's float4 is a struct, which inline asm takes through memory)
+
+// One thread's item of a K-tile: 8 elements of ONE operand (waves 0-7: A, waves 8-15: B), two 16-byte loads.  The item's operand
+// and layout (K-contiguous / K-major, the layouts of SplitStage<64, 64, KM>) are run-time, wave-uniform properties: address
+// arithmetic and the pairing of the split branch on them, the loads and the plane stores themselves are the same instructions for
+// every thread -- with the loads inside role branches hipcc cannot count them and waits with vmcnt(0) before every split, which
+// serialises the whole prefetch (first build of this kernel: 34 us for the encode GEMM, 20 us without its fetches).
+struct SplitItemK {
+  const float* zp;
+  const float* ptr;
+  long long inc;      // floats per K-tile
+  int aux, dst, ld;
+  bool km;
+  __device__ inline void init(bool km_, const float* __restrict__ base, int ld_, int r0, int rlimit, int kbeg, const float* zero, int w,
+                              const int* __restrict__ gather = nullptr) {
+    km = km_; ld = ld_;
+    zp = zero + (w & 255) * 8;
+    if (!km) {
+      using S = SplitStage<64, 64, false>;
+      const int row = w / S::CH, c8 = w % S::CH;
+      const bool ok = (r0 + row) < rlimit;
+      const int src_row = (ok && gather) ? gather[r0 + row] : r0 + row;      // (GemmP::a_gather: the embedding lookup rides in the fetch)
+      ptr = ok ? base + (size_t)src_row * ld + kbeg + 8 * c8 : zp;
+      inc = ok ? 64 : 0;
+      aux = 0;
+      dst = row * 32 + 4 * (c8 ^ S::swz(row));
+    } else {
+      using S = SplitStage<64, 64, true>;
+      const int kp = w / S::RQ, rq = w % S::RQ;
+      const bool ok = (r0 + 4 * rq) < ld;
+      ptr = base + (size_t)(kbeg + 2 * kp) * ld + r0 + 4 * rq;
+      inc = (long long)64 * ld;
+      aux = ok ? 2 * kp : -1;
+      dst = kp * 64 + ((4 * rq) ^ (((kp >> 2) & 1) << 5));
+    }
+  }
+  // the two source addresses of the item in the K-tile that starts kleft k's before the end of the range (no memory access here)
+  __device__ inline void addresses(int kleft, const float*& s0, const float*& s1) {
+    if (!km) { s0 = ptr; s1 = ptr + 4; }
+    else {
+      s0 = (aux >= 0 && aux < kleft) ? ptr : zp;
+      s1 = (aux >= 0 && aux + 1 < kleft) ? ptr + ld : zp;
+    }
+    ptr += inc;
+  }
+  __device__ inline void split(const f32x4k (&v)[2], u32x4 (&pc)[3], const bool km) const {
+    // the four (k, k + 1) pairs: 8 consecutive k of one row, or two k-rows of four consecutive rows.  (Scalars and selects, no
+    // private arrays: hipcc parks those in LDS / scratch and then waits for every load where it is issued.)
+    const f32x4k a = v[0], b = v[1];
+    const float p0a = a.x,               p0b = km ? b.x : a.y;
+    const float p1a = km ? a.y : a.z,    p1b = km ? b.y : a.w;
+    const float p2a = km ? a.z : b.x,    p2b = km ? b.z : b.y;
+    const float p3a = km ? a.w : b.z,    p3b = b.w;
+    unsigned h, m, l;
+    split_bf16x3(p0a, p0b, h, m, l); pc[0][0] = h; pc[1][0] = m; pc[2][0] = l;
+    split_bf16x3(p1a, p1b, h, m, l); pc[0][1] = h; pc[1][1] = m; pc[2][1] = l;
+    split_bf16x3(p2a, p2b, h, m, l); pc[0][2] = h; pc[1][2] = m; pc[2][2] = l;
+    split_bf16x3(p3a, p3b, h, m, l); pc[0][3] = h; pc[1][3] = m; pc[2][3] = l;
+  }
+};
+
+constexpr int BF16K_OPER = 3 * (64 * 64 / 2) * 2;      // dwords of one plane buffer: three pieces x (A + B) = 48 KiB
+constexpr int BF16K_PD = 4;                            // K-tiles in flight in registers (32 registers)
+
+template <bool AKM, bool BKM>
+__device__ __forceinline__ void gemm_bf16k_body(const GemmP& p, const int bid, const int nblk, float* __restrict__ smem) {
+  constexpr int BM = 64, BN = 64, BK = 64, PD = BF16K_PD;
+  using FA = SplitStage<64, 64, AKM>;
+  using FB = SplitStage<64, 64, BKM>;
+  unsigned* const buf = reinterpret_cast<unsigned*>(smem);      // [2][A planes x 3 | B planes x 3]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kg = wave >> 2;
+  const int wr = (wave >> 1) & 1, wc = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+  const bool stage_a = wave < 8;      // (wave-uniform)
+
+  int tm, tn, sp, bz;
+  tile_coords(p, bid, nblk, tm, tn, sp, bz);
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int kbeg = sp * p.k_per_split;
+  const int kend = min(p.K, kbeg + p.k_per_split);
+  const int nt = (kend - kbeg + BK - 1) / BK;
+
+  f32x16 acc[1][1], accl;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc[0][0][r] = 0.f; accl[r] = 0.f; }
+
+  SplitItemK it;
+  if (stage_a) it.init(AKM, p.A + (size_t)bz * p.a_batch_stride, p.lda, m0, p.M, kbeg, p.zero_page, tid, AKM ? nullptr : p.a_gather);
+  else it.init(BKM, p.B, p.ldb, n0, p.N, kbeg, p.zero_page, tid - 512);
+  unsigned* const my_planes = buf + (stage_a ? 0 : 3 * FA::PLANE) + it.dst;      // this thread's 16 bytes of piece 0, buffer 0
+
+  f32x4k rg[PD][2];
+#pragma unroll
+  for (int s = 0; s < PD; ++s) { rg[s][0] = f32x4k{0.f, 0.f, 0.f, 0.f}; rg[s][1] = f32x4k{0.f, 0.f, 0.f, 0.f}; }      // (slots >= nt are never requested)
+  int kleft = kend - kbeg;      // k's from the next tile to load to the end of the range
+  auto load_tile = [&](auto ss) {
+    constexpr int s = decltype(ss)::value;
+    const float *s0, *s1;
+    it.addresses(kleft, s0, s1);
+    // issued from inline asm: hipcc cannot count register loads across the loop's back edge and waits with vmcnt(0) in front of
+    // two splits out of three -- i.e. for the loads it has just issued -- which puts the whole fetch latency back into the loop
+    // (18.5 us on the encode GEMM); an asm load is invisible to its wait insertion, the waits below are counted by hand
+    f32x4k l0, l1;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(l0) : "v"(s0) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(l1) : "v"(s1) : "memory");
+    rg[s][0] = l0; rg[s][1] = l1;
+    kleft -= BK;
+  };
+  // `younger` = K-tiles requested after the one in slot s (two loads each; loads return in order)
+  auto store_tile = [&](auto ss, int b, int younger) {
+    constexpr int s = decltype(ss)::value;
+    // The wait hands out a token (always 0) that every first use of the loaded registers depends on -- it is folded into the
+    // layout predicate of the pair selects -- so that no consumer can be scheduled above the wait.  (A wait tied to the registers
+    // themselves, "+v", made hipcc COPY them in front of it on some paths: a read of a register whose load is still in flight.)
+    const f32x4k v[2] = {rg[s][0], rg[s][1]};
+    int tok;
+    if (younger >= 3) asm volatile("s_waitcnt vmcnt(6)\n\ts_mov_b32 %0, 0" : "=s"(tok) : "v"(v[0]), "v"(v[1]));
+    else if (younger == 2) asm volatile("s_waitcnt vmcnt(4)\n\ts_mov_b32 %0, 0" : "=s"(tok) : "v"(v[0]), "v"(v[1]));
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(2)\n\ts_mov_b32 %0, 0" : "=s"(tok) : "v"(v[0]), "v"(v[1]));
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_mov_b32 %0, 0" : "=s"(tok) : "v"(v[0]), "v"(v[1]));
+    u32x4 pc[3];
+    it.split(v, pc, it.km != (tok != 0));
+    unsigned* o = my_planes + b * BF16K_OPER;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) *reinterpret_cast<u32x4*>(o + q * FA::PLANE) = pc[q];
+  };
+  // prologue: K-tiles 0 .. PD-1 requested, tile 0 split into buffer 0
+  static_for<0, PD>([&](auto ss) { if (decltype(ss)::value < nt) load_tile(ss); });
+  store_tile(std::integral_constant<int, 0>{}, 0, min(nt, PD) - 1);
+  // everything requested so far lands before the loop is entered (the requests went out back to back with tile 0's, which the split
+  // above has waited for): should hipcc move a prefetch register at the loop header, it moves a register that is complete
+  asm volatile("s_waitcnt vmcnt(0)" :: "v"(rg[0][0]), "v"(rg[0][1]), "v"(rg[1][0]), "v"(rg[1][1]), "v"(rg[2][0]), "v"(rg[2][1]), "v"(rg[3][0]), "v"(rg[3][1]));
+  static_assert(PD == 4, "the wait above names every prefetch register");
+  __syncthreads();
+
+  auto step = [&](auto ss, int t) {      // K-tile t, whose registers were slot s = t % PD (consumed in iteration t - 1)
+    constexpr int s = decltype(ss)::value, s1 = (s + 1) % PD;
+    const unsigned* planes = buf + (t & 1) * BF16K_OPER;
+    u32x4 pa[3], pb[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) pa[q] = FA::frag(planes + q * FA::PLANE, wr * 32, kg, li, lh);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) pb[q] = FB::frag(planes + 3 * FA::PLANE + q * FB::PLANE, wc * 32, kg, li, lh);
+    // the registers of tile t are free: request tile t + PD into them (before the MFMAs: the longer the fetch has)
+#ifdef GANMF_PERSIST_DIAG_BUILD
+    if (p.diag & 16) { if (t + PD < nt) kleft -= BK; } else      // timing only: no operand fetches after the prologue
+#endif
+    if (t + PD < nt) load_tile(ss);
+    constexpr int ta[6] = {1, 0, 2, 1, 0, 0}, tb[6] = {1, 2, 0, 0, 1, 0};   // (mid,mid) (hi,lo) (lo,hi) (mid,hi) (hi,mid) (hi,hi): gemm_bf16s_body
+#ifdef GANMF_PERSIST_DIAG_BUILD
+    if (!(p.diag & 4))             // timing only: no MFMAs
+#endif
+#pragma unroll
+    for (int t6 = 0; t6 < 6; ++t6) {
+      if (t6 < 5)
+        accl = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pa[ta[t6]]), __builtin_bit_cast(bf16x8, pb[tb[t6]]), accl, 0, 0, 0);
+      else
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pa[ta[t6]]), __builtin_bit_cast(bf16x8, pb[tb[t6]]), acc[0][0], 0, 0, 0);
+    }
+#ifdef GANMF_PERSIST_DIAG_BUILD
+    if (!(p.diag & 2))             // timing only: no split / plane stores after the prologue
+#endif
+    // under the MFMAs: split K-tile t + 1 into the other buffer (requested after it: tiles t + 2 .. min(t + PD, nt - 1))
+    if (t + 1 < nt) store_tile(std::integral_constant<int, s1>{}, (t + 1) & 1, min(t + PD, nt - 1) - (t + 1));
+    __syncthreads();
+  };
+  for (int t = 0; t < nt; t += PD)
+    static_for<0, PD>([&](auto ss) { if (t + decltype(ss)::value < nt) step(ss, t + decltype(ss)::value); });
+
+  acc[0][0] += accl;
+  static_assert(4 * BM * BN <= 2 * BF16K_OPER, "the plane buffers must hold the four staged partial tiles");
+  gemm_epilogue<BM, BN, 1, 1, 4>(p, acc, smem, TileCoord{tm, tn, sp, bz, m0, n0});
+}
+
+template <bool AKM, bool BKM>
+__global__ __launch_bounds__(1024) void gemm_bf16k_mfma(const GemmP p) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * BF16K_OPER];      // 96 KiB: one workgroup per CU
+  gemm_bf16k_body<AKM, BKM>(p, (int)blockIdx.x, (int)gridDim.x, smem);
+}
+
+inline hipError_t gemm_bf16k_launch(hipStream_t st, const GemmP& p0, bool akm, bool bkm) {
+  GemmP p = p0;
+#ifdef GANMF_PERSIST_DIAG_BUILD
+  if (getenv("GANMF_BF16K_DIAG")) p.diag = atoi(getenv("GANMF_BF16K_DIAG"));      // 2 no splits, 4 no MFMAs, 16 no fetches (wrong results)
+#endif
+  const int grid = p.tiles_m * p.tiles_n * p.nsplit * p.nbatch;
+  if (grid <= 0) return hipSuccess;
+  if (!akm && !bkm) GANMF_LAUNCH((gemm_bf16k_mfma<false, false>), dim3(grid), dim3(1024), 0, st, p);
+  else if (!akm && bkm) GANMF_LAUNCH((gemm_bf16k_mfma<false, true>), dim3(grid), dim3(1024), 0, st, p);
+  else if (akm && bkm) GANMF_LAUNCH((gemm_bf16k_mfma<true, true>), dim3(grid), dim3(1024), 0, st, p);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+}  // namespace ganmf

@@ -21,26 +21,32 @@
 // summation order, bit-identical results to the separate launches.
 #pragma once
 #include "gemm_bf16s.hpp"
+#include "gemm_bf16k.hpp"
 #include "gemm_f32.hpp"
 #include "kernels.hpp"
 
 namespace ganmf {
 
 // blocks [0, ng): 64 x 64 tiles of the NT GEMM; blocks [ng, ng + d.nb): one CSR row each
-template <int KG>
+// (X3: the 16-wave split-bf16 loop instead of the fp32 MFMA, gemm_bf16k.hpp -- whichever the stand-alone product would run)
+template <int KG, bool X3 = false>
 __global__ __launch_bounds__(256 * KG) void front_kernel(const GemmP g, const DensP d) {
   __shared__ __attribute__((aligned(16))) float smem[3 * (64 + 64) * 64];
+  static_assert(!X3 || KG == 4, "the split-bf16 form has four K groups");
   const int ng = g.tiles_m * g.tiles_n * g.nsplit * g.nbatch;
-  if ((int)blockIdx.x < ng) gemm_f32_body<64, 64, 64, 3, false, false, KG>(g, (int)blockIdx.x, ng, smem);
-  else densify_row_body(d, (int)blockIdx.x - ng);
+  if ((int)blockIdx.x < ng) {
+    if constexpr (X3) gemm_bf16k_body<false, false>(g, (int)blockIdx.x, ng, smem);
+    else gemm_f32_body<64, 64, 64, 3, false, false, KG>(g, (int)blockIdx.x, ng, smem);
+  } else densify_row_body(d, (int)blockIdx.x - ng);
 }
 
 // blocks [0, ng): 64 x 64 tiles of the NT GEMM dE = Delta . Wd^T, which here only writes its split-K slabs; blocks [ng, ng + nd):
 // the discriminator scalars and Es = rs (.) E (kernels.hpp d_coef_body), whose outputs the GEMM does not read -- the row scale
 // of dE is applied by the slab sum, in the NEXT launch
-template <int KG>
+template <int KG, bool X3 = false>
 __global__ __launch_bounds__(256 * KG) void de_dcoef_kernel(const GemmP g, const DCoefP d, const int nd) {
   __shared__ __attribute__((aligned(16))) float smem[3 * (64 + 64) * 64];
+  static_assert(!X3 || KG == 4, "the split-bf16 form has four K groups");
   const int ng = g.tiles_m * g.tiles_n * g.nsplit * g.nbatch;
   if (nd == 0) {
     // every GEMM workgroup first does its 1 / ng share of d_coef (a few hundred float4 of Es; the two scalar sums are formed
@@ -48,11 +54,14 @@ __global__ __launch_bounds__(256 * KG) void de_dcoef_kernel(const GemmP g, const
     // as a tail behind the GEMM's (24.8 vs 21.6 us for the same product without them)
     d_coef_body(d, (int)blockIdx.x, ng, smem);
     __syncthreads();
-    gemm_f32_body<64, 64, 64, 3, false, false, KG>(g, (int)blockIdx.x, ng, smem);
+    if constexpr (X3) gemm_bf16k_body<false, false>(g, (int)blockIdx.x, ng, smem);
+    else gemm_f32_body<64, 64, 64, 3, false, false, KG>(g, (int)blockIdx.x, ng, smem);
     return;
   }
-  if ((int)blockIdx.x < ng) gemm_f32_body<64, 64, 64, 3, false, false, KG>(g, (int)blockIdx.x, ng, smem);
-  else d_coef_body(d, (int)blockIdx.x - ng, nd, smem);
+  if ((int)blockIdx.x < ng) {
+    if constexpr (X3) gemm_bf16k_body<false, false>(g, (int)blockIdx.x, ng, smem);
+    else gemm_f32_body<64, 64, 64, 3, false, false, KG>(g, (int)blockIdx.x, ng, smem);
+  } else d_coef_body(d, (int)blockIdx.x - ng, nd, smem);
 }
 
 // blocks [0, n0): g0, an NN GEMM; blocks [n0, n0 + n1): g1, a TN GEMM

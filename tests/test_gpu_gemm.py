@@ -147,3 +147,29 @@ def test_gemm_deep_split_small_output(akm, bkm, shape, nsplit):
     assert np.all(err <= 4e-7 * bound * np.sqrt(K) + 1e-30), float((err / (bound + 1e-30)).max())
     again, _ = gemm_f32(A, B, akm, bkm, tile=64, nsplit=nsplit)
     np.testing.assert_array_equal(out, again)
+
+
+@pytest.mark.parametrize("akm,bkm", LAYOUTS)
+@pytest.mark.parametrize("shape,nsplit", [((256, 992, 3707), 4), ((128, 992, 3706), 8), ((128, 3706, 993), 2), ((16, 7, 54), 1), ((1, 1, 1), 1),
+                                           ((64, 64, 64), 1), ((65, 70, 130), 1), ((64, 64, 192), 1), ((130, 129, 256), 1), ((200, 100, 321), 1),
+                                           ((200, 3706, 96), 1), ((70, 65, 1000), 3)])
+def test_gemm_split_bf16_k_groups(akm, bkm, shape, nsplit, monkeypatch):
+    """gemm_bf16k.hpp: the 16-wave split-bf16 kernel that takes the plans of the 16-wave fp32 ring kernel (GANMF_X3KG) -- every layout,
+    K ranges of 1 .. 58 K-tiles (fewer tiles than the four prefetch slots, tile counts that are no multiple of four, K tails, a
+    short last K slice), ragged tile edges, split-K.  fp32-accurate like the staged split-bf16 kernel, and run-to-run identical."""
+    from ganmf_amd.engine import gemm_f32
+    M, N, K = shape
+    rng = np.random.RandomState(M + 3 * N + 7 * K)
+    A, B, ref, bound = _mk(rng, M, N, K, akm, bkm)
+    monkeypatch.setenv("GANMF_MFMA", "f32")
+    monkeypatch.setenv("GANMF_KG", "4")
+    monkeypatch.setenv("GANMF_RING", "3")
+    monkeypatch.setenv("GANMF_X3KG", "3")
+    out, _ = gemm_f32(A, B, akm, bkm, tile=64, nsplit=nsplit)
+    err = np.abs(out - ref)
+    assert np.all(err <= 4e-7 * bound * np.sqrt(K) + 1e-30), float((err / (bound + 1e-30)).max())
+    again, _ = gemm_f32(A, B, akm, bkm, tile=64, nsplit=nsplit)
+    np.testing.assert_array_equal(out, again)
+    monkeypatch.setenv("GANMF_X3KG", "0")
+    plain, _ = gemm_f32(A, B, akm, bkm, tile=64, nsplit=nsplit)
+    assert not np.array_equal(plain, out) or K == 1      # (it IS another kernel)
