@@ -360,9 +360,10 @@ def main():
             "config": {"workload": "GANMF --user, MovieLens-1M shape %dx%d per GPU, k=%d, emb_dim=%d, batch=%d/GPU, "
                                    "tuned hyper-parameters (BASELINE.json configs[1])" % (w["U"], w["N"], w["k"], w["e"], w["B"]),
                        "step": "one 128-row minibatch update (D or G), K/2 D then K/2 G",
-                       "arithmetic": "float32 tensors throughout; GEMM K loops on the fp32 MFMA (16-wave workgroups), except the "
-                                     "two fused-Adam weight-gradient GEMMs of the D-step, which run the fp32-accurate split-bf16 "
-                                     "loop (3 exact bf16 pieces per operand, 6 piece products, fp32 accumulate)",
+                       "arithmetic": "float32 tensors throughout; the K loops of the step's GEMMs run the fp32-accurate split-bf16 loop "
+                                     "(3 exact bf16 pieces per operand, 6 piece products on v_mfma_f32_32x32x16_bf16, fp32 accumulate) in "
+                                     "16-wave workgroups (gemm_bf16k.hpp) or, for the two fused-Adam weight-gradient GEMMs, 4-wave "
+                                     "workgroups; gUb + gV on the fp32 MFMA",
                        "launches": "D-step 7, G-step 11 (generator GEMM + CSR rows, dE + d_coef, gWd + gWe, gUb + gV share a launch)",
                        "global_steps_per_s": round(done / el, 2), "rows_per_s": round(world * done * w["B"] / el, 1),
                        "parallelism": "dp%d (users sharded row-wise; RCCL reduce-scatter of the D and V gradients, Adam on the rank's "
