@@ -200,7 +200,7 @@ struct ganmf_handle {
   float* slab2 = nullptr;                // split-K workspace of the side lane
   size_t slab2_elems = 0;
   unsigned *counters = nullptr, *counters2 = nullptr;   // split-K arrival counters (zero between launches)
-  int x3kg = 3;                   // GANMF_X3KG bits: 16-wave split-bf16 loop for the plans of the 16-wave fp32 ring kernel (1 NT, 2 K-major B)
+  int x3kg = 7;                   // GANMF_X3KG bits: 16-wave split-bf16 loop for the plans of the 16-wave fp32 ring kernel (1 NT, 2 K-major B), 4: its one-piece form for bf16 / fp16 plans
   bool inkernel_reduce = true;
   int inlaunch_tags = 0;
   int inlaunch_max = 4;
@@ -510,6 +510,9 @@ int run_gemm(ganmf_handle* h, int tag_gemm, int tag_red, GemmP g, bool akm, bool
   // same epilogue, 6 / 16 of the MFMA cycles (gemm_bf16k.hpp)
   if (!force && pl.mode == MFMA_F32 && pl.tile == 64 && pl.kg == 4 && pl.ring == 3 && !pl.persist && !(akm && !bkm) && tag_gemm != T_GEMM_GUB && tag_gemm != T_GEMM_GV &&      // (gUb / gV: their other form is the fp32 pair_kernel)
       ((h->x3kg & 1) && !akm && !bkm || (h->x3kg & 2) && bkm)) pl.mode = MFMA_BF16X3;      // bit 0: NT products, bit 1: products with a K-major B
+  // ... and a single-piece (bf16 / fp16) plan with a CU per workgroup takes the same 16-wave kernel in its one-piece form (bit 2)
+  if (!force && (h->x3kg & 4) && (pl.mode == MFMA_F16 || pl.mode == MFMA_BF16) && pl.tile == 64 && pl.ring == 3 && pl.bk != 32 && !pl.persist &&
+      !(akm && !bkm)) pl.kg = 4;
   if (defer) *defer = SlabRef{g.C, 1, 0};
   // (a deep split behind a small output is summed 16 threads per element by the reduce kernel: not left to the consumer)
   const bool deferred = defer && pl.nsplit > 1 && g.epi.kind == EPI_STORE && g.nbatch == 1 &&
@@ -1651,7 +1654,7 @@ static int create_impl(const ganmf_cfg* cfg, ganmf_handle* h) {
   h->defer_gub = env_int("GANMF_DEFER_GUB", 1) != 0;
   h->multi = env_int("GANMF_MULTI", 31);
   h->dis_fuse_hidden = env_int("GANMF_DIS_FUSE_HIDDEN", 1) != 0;
-  h->x3kg = env_int("GANMF_X3KG", 3);      // +10 % steps/s at the ML-1M shape (profiles/r03_gemm_stamps.md)
+  h->x3kg = env_int("GANMF_X3KG", 7);      // +10 % steps/s at the ML-1M shape (profiles/r03_gemm_stamps.md)
   h->dcoef_spread = env_int("GANMF_DCOEF_SPREAD", 1) != 0;
   h->pair_ring = env_int("GANMF_PAIR_RING", 2) == 3 ? 3 : 2;
   h->inkernel_reduce = env_int("GANMF_INKERNEL_REDUCE", 0) != 0;   // measured slower than the chip-wide reduce kernel

@@ -62,7 +62,8 @@ struct SplitItemK {
     }
     ptr += inc;
   }
-  __device__ inline void split(const f32x4k (&v)[2], u32x4 (&pc)[3], const bool km) const {
+  template <int NPIECE, bool F16>
+  __device__ inline void split(const f32x4k (&v)[2], u32x4 (&pc)[3], const bool km, const float scale) const {
     // the four (k, k + 1) pairs: 8 consecutive k of one row, or two k-rows of four consecutive rows.  (Scalars and selects, no
     // private arrays: hipcc parks those in LDS / scratch and then waits for every load where it is issued.)
     const f32x4k a = v[0], b = v[1];
@@ -70,20 +71,33 @@ struct SplitItemK {
     const float p1a = km ? a.y : a.z,    p1b = km ? b.y : a.w;
     const float p2a = km ? a.z : b.x,    p2b = km ? b.z : b.y;
     const float p3a = km ? a.w : b.z,    p3b = b.w;
-    unsigned h, m, l;
-    split_bf16x3(p0a, p0b, h, m, l); pc[0][0] = h; pc[1][0] = m; pc[2][0] = l;
-    split_bf16x3(p1a, p1b, h, m, l); pc[0][1] = h; pc[1][1] = m; pc[2][1] = l;
-    split_bf16x3(p2a, p2b, h, m, l); pc[0][2] = h; pc[1][2] = m; pc[2][2] = l;
-    split_bf16x3(p3a, p3b, h, m, l); pc[0][3] = h; pc[1][3] = m; pc[2][3] = l;
+    if constexpr (NPIECE == 3) {
+      unsigned h, m, l;
+      split_bf16x3(p0a, p0b, h, m, l); pc[0][0] = h; pc[1][0] = m; pc[2][0] = l;
+      split_bf16x3(p1a, p1b, h, m, l); pc[0][1] = h; pc[1][1] = m; pc[2][1] = l;
+      split_bf16x3(p2a, p2b, h, m, l); pc[0][2] = h; pc[1][2] = m; pc[2][2] = l;
+      split_bf16x3(p3a, p3b, h, m, l); pc[0][3] = h; pc[1][3] = m; pc[2][3] = l;
+    } else if constexpr (F16) {      // one IEEE fp16 piece after the exact power-of-two scale (static loss scaling per GEMM, gemm_f32.hpp)
+      pc[0][0] = cvt_pk_f16(p0a * scale, p0b * scale); pc[0][1] = cvt_pk_f16(p1a * scale, p1b * scale);
+      pc[0][2] = cvt_pk_f16(p2a * scale, p2b * scale); pc[0][3] = cvt_pk_f16(p3a * scale, p3b * scale);
+    } else {                         // one bf16 piece, round to nearest even
+      pc[0][0] = cvt_pk_bf16(p0a, p0b); pc[0][1] = cvt_pk_bf16(p1a, p1b);
+      pc[0][2] = cvt_pk_bf16(p2a, p2b); pc[0][3] = cvt_pk_bf16(p3a, p3b);
+    }
   }
 };
 
 constexpr int BF16K_OPER = 3 * (64 * 64 / 2) * 2;      // dwords of one plane buffer: three pieces x (A + B) = 48 KiB
 constexpr int BF16K_PD = 4;                            // K-tiles in flight in registers (32 registers)
 
-template <bool AKM, bool BKM>
+// NPIECE = 3: the exact three-way split (fp32-accurate).  NPIECE = 1: every operand rounded to ONE bf16, or with F16 to one IEEE fp16
+// after its power-of-two scale (MFMA_BF16 / MFMA_F16, gemm_f32.hpp): one MFMA per wave and K-tile, same staging and pipeline.
+template <bool AKM, bool BKM, int NPIECE = 3, bool F16 = false>
 __device__ __forceinline__ void gemm_bf16k_body(const GemmP& p, const int bid, const int nblk, float* __restrict__ smem) {
+  static_assert(NPIECE == 3 || NPIECE == 1, "pieces per operand");
+  static_assert(!F16 || NPIECE == 1, "fp16 pieces only in the single-piece mode");
   constexpr int BM = 64, BN = 64, BK = 64, PD = BF16K_PD;
+  const float sa = (F16 && p.a_scale != 0.f) ? p.a_scale : 1.f, sb = (F16 && p.b_scale != 0.f) ? p.b_scale : 1.f;
   using FA = SplitStage<64, 64, AKM>;
   using FB = SplitStage<64, 64, BKM>;
   unsigned* const buf = reinterpret_cast<unsigned*>(smem);      // [2][A planes x 3 | B planes x 3]
@@ -110,6 +124,7 @@ __device__ __forceinline__ void gemm_bf16k_body(const GemmP& p, const int bid, c
   if (stage_a) it.init(AKM, p.A + (size_t)bz * p.a_batch_stride, p.lda, m0, p.M, kbeg, p.zero_page, tid, AKM ? nullptr : p.a_gather);
   else it.init(BKM, p.B, p.ldb, n0, p.N, kbeg, p.zero_page, tid - 512);
   unsigned* const my_planes = buf + (stage_a ? 0 : 3 * FA::PLANE) + it.dst;      // this thread's 16 bytes of piece 0, buffer 0
+  const float my_scale = stage_a ? sa : sb;
 
   f32x4k rg[PD][2];
 #pragma unroll
@@ -141,10 +156,10 @@ __device__ __forceinline__ void gemm_bf16k_body(const GemmP& p, const int bid, c
     else if (younger == 1) asm volatile("s_waitcnt vmcnt(2)\n\ts_mov_b32 %0, 0" : "=s"(tok) : "v"(v[0]), "v"(v[1]));
     else asm volatile("s_waitcnt vmcnt(0)\n\ts_mov_b32 %0, 0" : "=s"(tok) : "v"(v[0]), "v"(v[1]));
     u32x4 pc[3];
-    it.split(v, pc, it.km != (tok != 0));
+    it.template split<NPIECE, F16>(v, pc, it.km != (tok != 0), my_scale);
     unsigned* o = my_planes + b * BF16K_OPER;
 #pragma unroll
-    for (int q = 0; q < 3; ++q) *reinterpret_cast<u32x4*>(o + q * FA::PLANE) = pc[q];
+    for (int q = 0; q < NPIECE; ++q) *reinterpret_cast<u32x4*>(o + q * FA::PLANE) = pc[q];
   };
   // prologue: K-tiles 0 .. PD-1 requested, tile 0 split into buffer 0
   static_for<0, PD>([&](auto ss) { if (decltype(ss)::value < nt) load_tile(ss); });
@@ -160,9 +175,9 @@ __device__ __forceinline__ void gemm_bf16k_body(const GemmP& p, const int bid, c
     const unsigned* planes = buf + (t & 1) * BF16K_OPER;
     u32x4 pa[3], pb[3];
 #pragma unroll
-    for (int q = 0; q < 3; ++q) pa[q] = FA::frag(planes + q * FA::PLANE, wr * 32, kg, li, lh);
+    for (int q = 0; q < NPIECE; ++q) pa[q] = FA::frag(planes + q * FA::PLANE, wr * 32, kg, li, lh);
 #pragma unroll
-    for (int q = 0; q < 3; ++q) pb[q] = FB::frag(planes + 3 * FA::PLANE + q * FB::PLANE, wc * 32, kg, li, lh);
+    for (int q = 0; q < NPIECE; ++q) pb[q] = FB::frag(planes + 3 * FA::PLANE + q * FB::PLANE, wc * 32, kg, li, lh);
     // the registers of tile t are free: request tile t + PD into them (before the MFMAs: the longer the fetch has)
 #ifdef GANMF_PERSIST_DIAG_BUILD
     if (p.diag & 16) { if (t + PD < nt) kleft -= BK; } else      // timing only: no operand fetches after the prologue
@@ -172,12 +187,20 @@ __device__ __forceinline__ void gemm_bf16k_body(const GemmP& p, const int bid, c
 #ifdef GANMF_PERSIST_DIAG_BUILD
     if (!(p.diag & 4))             // timing only: no MFMAs
 #endif
+    {
+      if constexpr (NPIECE == 3) {
 #pragma unroll
-    for (int t6 = 0; t6 < 6; ++t6) {
-      if (t6 < 5)
-        accl = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pa[ta[t6]]), __builtin_bit_cast(bf16x8, pb[tb[t6]]), accl, 0, 0, 0);
-      else
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pa[ta[t6]]), __builtin_bit_cast(bf16x8, pb[tb[t6]]), acc[0][0], 0, 0, 0);
+        for (int t6 = 0; t6 < 6; ++t6) {
+          if (t6 < 5)
+            accl = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pa[ta[t6]]), __builtin_bit_cast(bf16x8, pb[tb[t6]]), accl, 0, 0, 0);
+          else
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pa[ta[t6]]), __builtin_bit_cast(bf16x8, pb[tb[t6]]), acc[0][0], 0, 0, 0);
+        }
+      } else if constexpr (F16) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, pa[0]), __builtin_bit_cast(f16x8, pb[0]), acc[0][0], 0, 0, 0);
+      } else {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pa[0]), __builtin_bit_cast(bf16x8, pb[0]), acc[0][0], 0, 0, 0);
+      }
     }
 #ifdef GANMF_PERSIST_DIAG_BUILD
     if (!(p.diag & 2))             // timing only: no split / plane stores after the prologue
@@ -189,17 +212,21 @@ __device__ __forceinline__ void gemm_bf16k_body(const GemmP& p, const int bid, c
   for (int t = 0; t < nt; t += PD)
     static_for<0, PD>([&](auto ss) { if (t + decltype(ss)::value < nt) step(ss, t + decltype(ss)::value); });
 
-  acc[0][0] += accl;
+  if constexpr (NPIECE == 3) acc[0][0] += accl;
+  if constexpr (F16) {
+    if (sa != 1.f || sb != 1.f) acc[0][0] *= 1.f / (sa * sb);      // undo the operand scaling in fp32 (powers of two: exact)
+  }
   static_assert(4 * BM * BN <= 2 * BF16K_OPER, "the plane buffers must hold the four staged partial tiles");
   gemm_epilogue<BM, BN, 1, 1, 4>(p, acc, smem, TileCoord{tm, tn, sp, bz, m0, n0});
 }
 
-template <bool AKM, bool BKM>
+template <bool AKM, bool BKM, int NPIECE = 3, bool F16 = false>
 __global__ __launch_bounds__(1024) void gemm_bf16k_mfma(const GemmP p) {
   __shared__ __attribute__((aligned(16))) float smem[2 * BF16K_OPER];      // 96 KiB: one workgroup per CU
-  gemm_bf16k_body<AKM, BKM>(p, (int)blockIdx.x, (int)gridDim.x, smem);
+  gemm_bf16k_body<AKM, BKM, NPIECE, F16>(p, (int)blockIdx.x, (int)gridDim.x, smem);
 }
 
+template <int NPIECE, bool F16>
 inline hipError_t gemm_bf16k_launch(hipStream_t st, const GemmP& p0, bool akm, bool bkm) {
   GemmP p = p0;
 #ifdef GANMF_PERSIST_DIAG_BUILD
@@ -207,9 +234,9 @@ inline hipError_t gemm_bf16k_launch(hipStream_t st, const GemmP& p0, bool akm, b
 #endif
   const int grid = p.tiles_m * p.tiles_n * p.nsplit * p.nbatch;
   if (grid <= 0) return hipSuccess;
-  if (!akm && !bkm) GANMF_LAUNCH((gemm_bf16k_mfma<false, false>), dim3(grid), dim3(1024), 0, st, p);
-  else if (!akm && bkm) GANMF_LAUNCH((gemm_bf16k_mfma<false, true>), dim3(grid), dim3(1024), 0, st, p);
-  else if (akm && bkm) GANMF_LAUNCH((gemm_bf16k_mfma<true, true>), dim3(grid), dim3(1024), 0, st, p);
+  if (!akm && !bkm) GANMF_LAUNCH((gemm_bf16k_mfma<false, false, NPIECE, F16>), dim3(grid), dim3(1024), 0, st, p);
+  else if (!akm && bkm) GANMF_LAUNCH((gemm_bf16k_mfma<false, true, NPIECE, F16>), dim3(grid), dim3(1024), 0, st, p);
+  else if (akm && bkm) GANMF_LAUNCH((gemm_bf16k_mfma<true, true, NPIECE, F16>), dim3(grid), dim3(1024), 0, st, p);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }

@@ -326,10 +326,15 @@ inline hipError_t gemm_bf16s_launch(hipStream_t st, const GemmP& p, bool akm, bo
   return hipGetLastError();
 }
 
+template <int NPIECE, bool F16>
 inline hipError_t gemm_bf16k_launch(hipStream_t st, const GemmP& p, bool akm, bool bkm);      // gemm_bf16k.hpp: the 16-wave form
 
 inline hipError_t gemm_dispatch_staged(hipStream_t st, const GemmP& p, bool akm, bool bkm, const GemmPlan& pl) {
-  if (pl.mode == MFMA_BF16X3 && pl.tile == 64 && pl.kg == 4) return gemm_bf16k_launch(st, p, akm, bkm);
+  if (pl.tile == 64 && pl.kg == 4) {
+    if (pl.mode == MFMA_BF16X3) return gemm_bf16k_launch<3, false>(st, p, akm, bkm);
+    if (pl.mode == MFMA_F16) return gemm_bf16k_launch<1, true>(st, p, akm, bkm);
+    if (pl.mode == MFMA_BF16) return gemm_bf16k_launch<1, false>(st, p, akm, bkm);
+  }
   if (pl.mode == MFMA_F16)
     return pl.tile == 128 ? gemm_bf16s_launch<128, 128, 32, 1, true>(st, p, akm, bkm) : gemm_bf16s_launch<64, 64, 64, 1, true>(st, p, akm, bkm);
   if (pl.mode == MFMA_BF16X3 && pl.tile == 64 && pl.bk == 32) return gemm_bf16s_launch<64, 64, 32, 3>(st, p, akm, bkm);
