@@ -90,12 +90,31 @@ struct SplitItemK {
 constexpr int BF16K_OPER = 3 * (64 * 64 / 2) * 2;      // dwords of one plane buffer: three pieces x (A + B) = 48 KiB
 constexpr int BF16K_PD = 4;                            // K-tiles in flight in registers (32 registers)
 
+// `s_waitcnt vmcnt(n)` (n wave-uniform, 0 .. 9) that hands out a token (always 0) every first use of the awaited registers is made to
+// depend on (SplitItemK::split folds it into the layout predicate of the pair selects), so that no consumer is scheduled above the wait.
+// (A wait tied to the registers themselves, "+v", made hipcc COPY them in front of it on some paths: a read of a register whose load is
+// still in flight.)
+__device__ __forceinline__ int bf16k_wait_vm(int n, const f32x4k& v0, const f32x4k& v1) {
+  int tok;
+#define GANMF_BF16K_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")\n\ts_mov_b32 %0, 0" : "=s"(tok) : "v"(v0), "v"(v1))
+  if (n >= 8) { if (n >= 9) GANMF_BF16K_WAIT(9); else GANMF_BF16K_WAIT(8); }
+  else if (n >= 4) { if (n >= 6) { if (n >= 7) GANMF_BF16K_WAIT(7); else GANMF_BF16K_WAIT(6); } else { if (n >= 5) GANMF_BF16K_WAIT(5); else GANMF_BF16K_WAIT(4); } }
+  else { if (n >= 2) { if (n >= 3) GANMF_BF16K_WAIT(3); else GANMF_BF16K_WAIT(2); } else { if (n >= 1) GANMF_BF16K_WAIT(1); else GANMF_BF16K_WAIT(0); } }
+#undef GANMF_BF16K_WAIT
+  return tok;
+}
+
+// K loop of one 64 x 64 tile (tm, tn), K slice sp, batch bz -> acc (this wave's 32 x 32 block, K group kg's share of the sum).
 // NPIECE = 3: the exact three-way split (fp32-accurate).  NPIECE = 1: every operand rounded to ONE bf16, or with F16 to one IEEE fp16
 // after its power-of-two scale (MFMA_BF16 / MFMA_F16, gemm_f32.hpp): one MFMA per wave and K-tile, same staging and pipeline.
-template <bool AKM, bool BKM, int NPIECE = 3, bool F16 = false>
-__device__ __forceinline__ void gemm_bf16k_body(const GemmP& p, const int bid, const int nblk, float* __restrict__ smem) {
+// at_entry(): called once, after the first PD K-tiles have been requested and have landed and before the first MFMA; it may issue
+// EXTRA vector-memory loads of its own (the weight-gradient kernel's theta / m / v fetch), which the counted waits then allow for.
+template <bool AKM, bool BKM, int NPIECE, bool F16, int EXTRA, class Entry>
+__device__ __forceinline__ void bf16k_mainloop(const GemmP& p, const int tm, const int tn, const int sp, const int bz, float* __restrict__ smem,
+                                               f32x16& acc_out, Entry&& at_entry) {
   static_assert(NPIECE == 3 || NPIECE == 1, "pieces per operand");
   static_assert(!F16 || NPIECE == 1, "fp16 pieces only in the single-piece mode");
+  static_assert(2 * 3 + EXTRA <= 9, "bf16k_wait_vm covers 0 .. 9");
   constexpr int BM = 64, BN = 64, BK = 64, PD = BF16K_PD;
   const float sa = (F16 && p.a_scale != 0.f) ? p.a_scale : 1.f, sb = (F16 && p.b_scale != 0.f) ? p.b_scale : 1.f;
   using FA = SplitStage<64, 64, AKM>;
@@ -108,17 +127,14 @@ __device__ __forceinline__ void gemm_bf16k_body(const GemmP& p, const int bid, c
   const int wr = (wave >> 1) & 1, wc = wave & 1;
   const int li = lane & 31, lh = lane >> 5;
   const bool stage_a = wave < 8;      // (wave-uniform)
-
-  int tm, tn, sp, bz;
-  tile_coords(p, bid, nblk, tm, tn, sp, bz);
   const int m0 = tm * BM, n0 = tn * BN;
   const int kbeg = sp * p.k_per_split;
   const int kend = min(p.K, kbeg + p.k_per_split);
   const int nt = (kend - kbeg + BK - 1) / BK;
 
-  f32x16 acc[1][1], accl;
+  f32x16 acc, accl;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { acc[0][0][r] = 0.f; accl[r] = 0.f; }
+  for (int r = 0; r < 16; ++r) { acc[r] = 0.f; accl[r] = 0.f; }
 
   SplitItemK it;
   if (stage_a) it.init(AKM, p.A + (size_t)bz * p.a_batch_stride, p.lda, m0, p.M, kbeg, p.zero_page, tid, AKM ? nullptr : p.a_gather);
@@ -143,18 +159,11 @@ __device__ __forceinline__ void gemm_bf16k_body(const GemmP& p, const int bid, c
     rg[s][0] = l0; rg[s][1] = l1;
     kleft -= BK;
   };
-  // `younger` = K-tiles requested after the one in slot s (two loads each; loads return in order)
-  auto store_tile = [&](auto ss, int b, int younger) {
+  // `nwait` = vector-memory loads issued after the two of the K-tile in slot s (loads return in order)
+  auto store_tile = [&](auto ss, int b, int nwait) {
     constexpr int s = decltype(ss)::value;
-    // The wait hands out a token (always 0) that every first use of the loaded registers depends on -- it is folded into the
-    // layout predicate of the pair selects -- so that no consumer can be scheduled above the wait.  (A wait tied to the registers
-    // themselves, "+v", made hipcc COPY them in front of it on some paths: a read of a register whose load is still in flight.)
     const f32x4k v[2] = {rg[s][0], rg[s][1]};
-    int tok;
-    if (younger >= 3) asm volatile("s_waitcnt vmcnt(6)\n\ts_mov_b32 %0, 0" : "=s"(tok) : "v"(v[0]), "v"(v[1]));
-    else if (younger == 2) asm volatile("s_waitcnt vmcnt(4)\n\ts_mov_b32 %0, 0" : "=s"(tok) : "v"(v[0]), "v"(v[1]));
-    else if (younger == 1) asm volatile("s_waitcnt vmcnt(2)\n\ts_mov_b32 %0, 0" : "=s"(tok) : "v"(v[0]), "v"(v[1]));
-    else asm volatile("s_waitcnt vmcnt(0)\n\ts_mov_b32 %0, 0" : "=s"(tok) : "v"(v[0]), "v"(v[1]));
+    const int tok = bf16k_wait_vm(nwait, v[0], v[1]);
     u32x4 pc[3];
     it.template split<NPIECE, F16>(v, pc, it.km != (tok != 0), my_scale);
     unsigned* o = my_planes + b * BF16K_OPER;
@@ -163,11 +172,12 @@ __device__ __forceinline__ void gemm_bf16k_body(const GemmP& p, const int bid, c
   };
   // prologue: K-tiles 0 .. PD-1 requested, tile 0 split into buffer 0
   static_for<0, PD>([&](auto ss) { if (decltype(ss)::value < nt) load_tile(ss); });
-  store_tile(std::integral_constant<int, 0>{}, 0, min(nt, PD) - 1);
+  store_tile(std::integral_constant<int, 0>{}, 0, 2 * (min(nt, PD) - 1));
   // everything requested so far lands before the loop is entered (the requests went out back to back with tile 0's, which the split
   // above has waited for): should hipcc move a prefetch register at the loop header, it moves a register that is complete
   asm volatile("s_waitcnt vmcnt(0)" :: "v"(rg[0][0]), "v"(rg[0][1]), "v"(rg[1][0]), "v"(rg[1][1]), "v"(rg[2][0]), "v"(rg[2][1]), "v"(rg[3][0]), "v"(rg[3][1]));
   static_assert(PD == 4, "the wait above names every prefetch register");
+  at_entry();
   __syncthreads();
 
   auto step = [&](auto ss, int t) {      // K-tile t, whose registers were slot s = t % PD (consumed in iteration t - 1)
@@ -194,30 +204,40 @@ __device__ __forceinline__ void gemm_bf16k_body(const GemmP& p, const int bid, c
           if (t6 < 5)
             accl = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pa[ta[t6]]), __builtin_bit_cast(bf16x8, pb[tb[t6]]), accl, 0, 0, 0);
           else
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pa[ta[t6]]), __builtin_bit_cast(bf16x8, pb[tb[t6]]), acc[0][0], 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pa[ta[t6]]), __builtin_bit_cast(bf16x8, pb[tb[t6]]), acc, 0, 0, 0);
         }
       } else if constexpr (F16) {
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, pa[0]), __builtin_bit_cast(f16x8, pb[0]), acc[0][0], 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, pa[0]), __builtin_bit_cast(f16x8, pb[0]), acc, 0, 0, 0);
       } else {
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pa[0]), __builtin_bit_cast(bf16x8, pb[0]), acc[0][0], 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pa[0]), __builtin_bit_cast(bf16x8, pb[0]), acc, 0, 0, 0);
       }
     }
 #ifdef GANMF_PERSIST_DIAG_BUILD
     if (!(p.diag & 2))             // timing only: no split / plane stores after the prologue
 #endif
-    // under the MFMAs: split K-tile t + 1 into the other buffer (requested after it: tiles t + 2 .. min(t + PD, nt - 1))
-    if (t + 1 < nt) store_tile(std::integral_constant<int, s1>{}, (t + 1) & 1, min(t + PD, nt - 1) - (t + 1));
+    // under the MFMAs: split K-tile t + 1 into the other buffer.  Issued after its two loads: those of tiles t + 2 .. min(t + PD, nt - 1),
+    // and the entry hook's EXTRA loads if tile t + 1 was requested in the prologue
+    if (t + 1 < nt) store_tile(std::integral_constant<int, s1>{}, (t + 1) & 1, 2 * (min(t + PD, nt - 1) - (t + 1)) + (t + 1 < PD ? EXTRA : 0));
     __syncthreads();
   };
   for (int t = 0; t < nt; t += PD)
     static_for<0, PD>([&](auto ss) { if (t + decltype(ss)::value < nt) step(ss, t + decltype(ss)::value); });
 
-  if constexpr (NPIECE == 3) acc[0][0] += accl;
+  if constexpr (NPIECE == 3) acc += accl;
   if constexpr (F16) {
-    if (sa != 1.f || sb != 1.f) acc[0][0] *= 1.f / (sa * sb);      // undo the operand scaling in fp32 (powers of two: exact)
+    if (sa != 1.f || sb != 1.f) acc *= 1.f / (sa * sb);      // undo the operand scaling in fp32 (powers of two: exact)
   }
-  static_assert(4 * BM * BN <= 2 * BF16K_OPER, "the plane buffers must hold the four staged partial tiles");
-  gemm_epilogue<BM, BN, 1, 1, 4>(p, acc, smem, TileCoord{tm, tn, sp, bz, m0, n0});
+  acc_out = acc;
+}
+
+template <bool AKM, bool BKM, int NPIECE = 3, bool F16 = false>
+__device__ __forceinline__ void gemm_bf16k_body(const GemmP& p, const int bid, const int nblk, float* __restrict__ smem) {
+  int tm, tn, sp, bz;
+  tile_coords(p, bid, nblk, tm, tn, sp, bz);
+  f32x16 acc[1][1];
+  bf16k_mainloop<AKM, BKM, NPIECE, F16, 0>(p, tm, tn, sp, bz, smem, acc[0][0], [] {});
+  static_assert(4 * 64 * 64 <= 2 * BF16K_OPER, "the plane buffers must hold the four staged partial tiles");
+  gemm_epilogue<64, 64, 1, 1, 4>(p, acc, smem, TileCoord{tm, tn, sp, bz, tm * 64, tn * 64});
 }
 
 template <bool AKM, bool BKM, int NPIECE = 3, bool F16 = false>
