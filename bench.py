@@ -25,8 +25,8 @@ replicated tensors are reduce-scattered over RCCL every step (Adam on the rank's
 all-gathered: DESIGN.md section 6); `value` counts the 128-row minibatch
 updates all ranks processed per second (= N x synchronous global steps/s).
 
-Extra objects on the JSON line: `roofline` (dominant kernel of the step = the 16-wave fp32 ring GEMM, on its largest
-class; `roofline_fused_adam` = the HBM-bound launch of the two fused-Adam weight-gradient GEMMs; HIP-event timed on the
+Extra objects on the JSON line: `roofline` (dominant kernel of the step = the 16-wave split-bf16 GEMM of gemm_bf16k.hpp -- fp32 in, fp32-accurate, priced
+against the fp32 MFMA peak -- on its largest class; `roofline_fused_adam` = the HBM-bound launch of the two fused-Adam weight-gradient GEMMs; HIP-event timed on the
 library's stream in a profiled repeat of the same steps (at least 96) right after the timed region — events
 stay out of the timed region so that `value` is not perturbed), `cpu_baseline` (the numpy fp32
 oracle = a port of the reference's per-step procedure, timed on this box's host cores on a
@@ -296,8 +296,8 @@ def main():
                 row["gbs"] = round(p["bytes"] / max(p["ms"], 1e-9) / 1e6, 1)
             kernels.append(row)
         # Dominant KERNEL of the step = the device function with the most time.  The library's profile rows are classes
-        # (one per GEMM of the step); the classes below all run the 16-wave fp32 ring GEMM (gemm_f32.hpp gemm_f32_body,
-        # also inside the generator / dE combined launches), the two weight-gradient products run the staged split-bf16
+        # (one per GEMM of the step); the classes below all run the 16-wave split-bf16 GEMM (gemm_bf16k.hpp bf16k_mainloop,
+        # also inside the generator / dE combined launches; GANMF_X3KG=0: the fp32 ring GEMM of gemm_f32.hpp), the two weight-gradient products run the staged split-bf16
         # kernel with the fused Adam epilogue (one launch: wgrad_pair_kernel).  `roofline` is the largest class of the
         # dominant kernel; the fused-Adam launch, HBM-bound, gets its own object (`roofline_fused_adam`).
         gemms = [p for p in prof if p["flops"] > 0]
