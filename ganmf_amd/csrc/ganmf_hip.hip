@@ -39,6 +39,9 @@
 #include "gemm_bf16p.hpp"
 #include "kernels.hpp"
 #include "gemm_multi.hpp"
+#ifdef GANMF_PERSIST_DIAG_BUILD
+#include "wgrad_stream.hpp"      // experiment (profiles/r04_wgrad_stream.md)
+#endif
 
 using namespace ganmf;
 
@@ -262,6 +265,14 @@ struct ganmf_handle {
                                        // before their next use on the main lane)
   bool merge_decode = true;            // GANMF_MERGE_DECODE: the discriminator step's two decode batches as one product (d_step)
   int red_elems = 0;                   // GANMF_RED_ELEMS: float4 outputs per thread of the stand-alone slab sum (0: the fixed 512-block grid)
+  // (experiment, make DIAG=1) bf16 x 3 planes of the discriminator step's activations (wgrad_stream.hpp): [2B][ld] per piece, piece stride ps_N / ps_e elements
+  bf16raw *pl_XF = nullptr, *pl_Dl = nullptr, *pl_Es = nullptr, *pl_dE = nullptr;
+  long long ps_N = 0, ps_e = 0;
+  float* wgs_dump = nullptr;           // 8 KiB the stream kernel's out-of-matrix lanes store to
+  int* wgs_table = nullptr;            // its tile schedule (wgs_build_schedule), rebuilt when the tile grid changes
+  int wgs_key[5] = {0, 0, 0, 0, 0}, wgs_rounds = 0;
+  size_t wgs_table_cap = 0;
+  bool wgrad_stream = false;           // GANMF_WGRAD_STREAM=1 (make DIAG=1 only): the two fused-Adam weight-gradient products as the persistent role-split launch
   int adam_nfast = 3;                  // GANMF_ADAM_NFAST: tile order of the fused-Adam weight-gradient launch (GemmP::n_fastest)
   bool fork_attach = true;             // GANMF_FORK_ATTACH: forks ride on the producing kernel's completion event (fork_arm / fork_wait)
   bool force_coll = false;             // GANMF_FORCE_COLLECTIVES=1: a one-rank communicator still issues its (in-place) reduce-scatter /
@@ -933,7 +944,117 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
     // applies TF-Adam to theta/m/v in place (after dE, which reads the old decoder).
     // Data-parallel: the gradients are stored, reduce-scattered, and each rank updates its slice (dp_update).
     bool wpair = false;
-    if (!dist && fused && (h->multi & 16) && dE_red.part) {
+#ifdef GANMF_PERSIST_DIAG_BUILD
+    if (!dist && fused && h->wgrad_stream && h->pl_XF && ft.mode == MFMA_BF16X3) {
+      // Both weight-gradient products with TF-Adam in place as ONE persistent launch fed from bf16 x 3 planes (wgrad_stream.hpp).
+      // In front of it, one launch: the slab sum of dE (+ its row scale; also files dE's planes) next to the planes of the three
+      // operands that are final by now.
+      const int K2 = 2 * nb;
+      PlaneJobs js{};
+      auto job = [&](const float* src, bf16raw* dst, long long ps, int rows, int ld) {
+        js.j[js.count++] = PlaneJob{src, PlaneRef{dst, ps}, (long long)rows * ld / 4};
+      };
+      if (h->sparse_d) job(h->XF + (size_t)nb * h->ldN, h->pl_XF + (size_t)nb * h->ldN, h->ps_N, nb, h->ldN);      // (the real rows stay CSR)
+      else job(h->XF, h->pl_XF, h->ps_N, K2, h->ldN);
+      job(h->Dl, h->pl_Dl, h->ps_N, K2, h->ldN);
+      job(h->Es, h->pl_Es, h->ps_e, K2, h->lde);
+      RedPlanes rp{};
+      RedP rr{};
+      int nred = 0;
+      long long n4 = 0;
+      if (dE_red.part) {
+        rr = dE_red; rp.pl = PlaneRef{h->pl_dE, h->ps_e}; rp.on = 1;
+        nred = h->red_elems > 0 ? red_grid(h, dE_red.M, dE_red.N, dE_red.nsplit) : GEMM_RED_GRID;
+        rr.epi.sq_stride = nred;
+      } else job(h->dE, h->pl_dE, h->ps_e, K2, h->lde);
+      for (int i = 0; i < js.count; ++i) n4 += js.j[i].n4;
+      const int nsp = (int)std::max<long long>(1, std::min<long long>(1024, (n4 + 1023) / 1024));
+      {
+        Scope s(h, T_RED_DE, 0, (dE_red.part ? 4.0 * (dE_red.nsplit + 1) * dE_red.M * dE_red.N : 0.0) + 10.0 * 4.0 * (double)n4);
+        GANMF_LAUNCH(presplit_red_kernel, dim3(nred + nsp), dim3(256), 0, h->st, rr, rp, nred, js);
+        HIP_TRY(hipGetLastError());
+      }
+      TRY(sparse_rows());
+      WgsP w{};
+      w.zero_page = h->zero_page;
+      w.dump = h->wgs_dump;
+      WgsProd& w0 = w.g[0];
+      w0.a_pl = h->pl_Es; w0.a_ps = h->ps_e; w0.lda = h->lde; w0.b_pl = h->pl_Dl; w0.b_ps = h->ps_N; w0.ldb = h->ldN; w0.ldc = h->ldN;
+      w0.M = e + 1; w0.N = N; w0.K = K2;
+      w0.epi.kind = EPI_ADAM; w0.epi.adam_theta = h->Wd.p; w0.epi.adam_m = h->Wd.m; w0.epi.adam_v = h->Wd.v;
+      w0.epi.adam_alpha = h->scal + aslot; w0.epi.adam_reg = h->cfg.d_reg; w0.epi.sq_partials = regD ? regWd : nullptr;
+      WgsProd& w1 = w.g[1];
+      const size_t r1 = h->sparse_d ? (size_t)nb : 0;      // sparse regime: the generated rows only, the real rows' share comes from the CSC matrix
+      w1.a_pl = h->pl_XF + r1 * h->ldN; w1.a_ps = h->ps_N; w1.lda = h->ldN; w1.b_pl = h->pl_dE + r1 * h->lde; w1.b_ps = h->ps_e; w1.ldb = h->lde;
+      w1.ldc = h->lde; w1.M = N + 1; w1.N = e; w1.K = h->sparse_d ? nb : K2;
+      w1.epi.kind = EPI_ADAM; w1.epi.adam_theta = h->We.p; w1.epi.adam_m = h->We.m; w1.epi.adam_v = h->We.v;
+      w1.epi.adam_alpha = h->scal + aslot; w1.epi.adam_reg = h->cfg.d_reg; w1.epi.sq_partials = regD ? regWe : nullptr;
+      if (h->sparse_d) { w1.epi.sp_rows = h->sp_rows; w1.epi.sp_ld = h->lde; w1.epi.sp_bias_row = N; w1.epi.sp_bias_parts = CSC_BIAS_PARTS; }
+      for (int i = 0; i < 2; ++i) { w.g[i].tiles_m = (w.g[i].M + WGS_BM - 1) / WGS_BM; w.g[i].tiles_n = (w.g[i].N + WGS_BN - 1) / WGS_BN; }
+      w.tiles0 = w0.tiles_m * w0.tiles_n;
+      w.tiles_total = w.tiles0 + w1.tiles_m * w1.tiles_n;
+      regn[1] = w.tiles0; regn[0] = w.tiles_total - w.tiles0;
+      const int grid = std::min(GEMM_CUS, round_up(w.tiles_total, 8));
+      {
+        const int key[5] = {w0.tiles_m, w0.tiles_n, w1.tiles_m, w1.tiles_n, grid};
+        if (memcmp(key, h->wgs_key, sizeof key) != 0) {
+          const int tms[2] = {w0.tiles_m, w1.tiles_m}, tns[2] = {w0.tiles_n, w1.tiles_n};
+          std::vector<int> tab;
+          const int rounds = wgs_build_schedule(tms, tns, 2, grid, tab);
+          HIP_TRY(hipStreamSynchronize(h->st));
+          if (tab.size() > h->wgs_table_cap) {
+            hipFree(h->wgs_table); h->wgs_table = nullptr;
+            HIP_TRY(hipMalloc((void**)&h->wgs_table, tab.size() * sizeof(int)));
+            h->wgs_table_cap = tab.size();
+          }
+          HIP_TRY(hipMemcpy(h->wgs_table, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
+          memcpy(h->wgs_key, key, sizeof key);
+          h->wgs_rounds = rounds;
+        }
+        w.table = h->wgs_table; w.rounds = h->wgs_rounds;
+      }
+      w.diag = env_int("GANMF_WGS_DIAG", 0);
+      static unsigned long long* wst = nullptr;
+      static int wst_n = 0;
+      const bool stamping = env_int("GANMF_WGS_STAMPS", 0) != 0 && wst_n < 40;
+      if (stamping) {
+        if (!wst) HIP_TRY(hipMalloc((void**)&wst, (size_t)GEMM_CUS * 64 * 8));
+        HIP_TRY(hipMemsetAsync(wst, 0, (size_t)GEMM_CUS * 64 * 8, h->st));
+        w.stamps = wst;
+      }
+      {
+        Scope s(h, T_WPAIR, gemm_flops(w0.M, w0.N, w0.K) + gemm_flops(w1.M, w1.N, w1.K),
+                // operands once (as planes: 6 bytes per element) + the six Adam streams; the gradients themselves never reach HBM
+                6.0 * ((double)w0.K * (w0.M + w0.N) + (double)w1.K * (w1.M + w1.N)) + 24.0 * ((double)w0.M * w0.N + (double)w1.M * w1.N));
+        GANMF_LAUNCH(wgrad_stream_kernel, dim3(grid), dim3(1024), 0, h->st, w);
+        HIP_TRY(hipGetLastError());
+      }
+      if (stamping && ++wst_n == 40) {      // (a warm launch)
+        HIP_TRY(hipStreamSynchronize(h->st));
+        std::vector<unsigned long long> hs((size_t)grid * 64);
+        HIP_TRY(hipMemcpy(hs.data(), wst, hs.size() * 8, hipMemcpyDeviceToHost));
+        unsigned long long t0 = ~0ull;
+        for (int b = 0; b < grid; ++b) if (hs[(size_t)b * 64]) t0 = std::min(t0, hs[(size_t)b * 64]);
+        auto med = [&](int role, int i) {
+          std::vector<double> v;
+          for (int b = 0; b < grid; ++b) { const unsigned long long x = hs[((size_t)b * 2 + role) * 32 + i]; if (x) v.push_back((double)(x - t0) * 0.01); }
+          if (v.empty()) return -1.0;
+          std::sort(v.begin(), v.end());
+          return v[v.size() / 2];
+        };
+        fprintf(stderr, "[wgs stamps] diag %d, %d workgroups, medians in us after the first GEMM-wave entry\n", w.diag, grid);
+        for (int role = 0; role < 2; ++role) {
+          fprintf(stderr, "  %s: start %.2f |", role ? "Adam" : "GEMM", med(role, 0));
+          for (int r = 0; r < 6; ++r) fprintf(stderr, " r%d: work done %.2f, past Y %.2f, past X %.2f |", r, med(role, 1 + 3 * r), med(role, 2 + 3 * r), med(role, 3 + 3 * r));
+          fprintf(stderr, "\n   detail:");
+          for (int i = 19; i < 32; ++i) fprintf(stderr, " %.2f", med(role, i));
+          fprintf(stderr, "\n");
+        }
+      }
+      wpair = true;
+    }
+#endif
+    if (!wpair && !dist && fused && (h->multi & 16) && dE_red.part) {
       // both weight-gradient products in ONE launch (wgrad_pair_kernel); the slab sum of dE, which gWe reads, gets its own
       // launch in front
       GemmP g0{}, g1{};
@@ -1715,6 +1836,17 @@ static int create_impl(const ganmf_cfg* cfg, ganmf_handle* h) {
     TRY(dalloc(&h->Dl, (size_t)2 * B * h->ldN));
     TRY(dalloc(&h->dE, (size_t)2 * B * h->lde));
     HIP_TRY(hipMemcpy2D(h->E + e, (size_t)h->lde * 4, ones.data(), 4, 4, (size_t)2 * B, hipMemcpyHostToDevice));
+#ifdef GANMF_PERSIST_DIAG_BUILD
+    h->wgrad_stream = env_int("GANMF_WGRAD_STREAM", 0) != 0;
+#endif
+    if (h->wgrad_stream) {      // three bf16 pieces per activation element (dalloc counts floats: two bf16 each)
+      h->ps_N = (long long)2 * B * h->ldN; h->ps_e = (long long)2 * B * h->lde;
+      TRY(dalloc((float**)&h->pl_XF, (size_t)(3 * h->ps_N + 1) / 2));
+      TRY(dalloc((float**)&h->pl_Dl, (size_t)(3 * h->ps_N + 1) / 2));
+      TRY(dalloc((float**)&h->pl_Es, (size_t)(3 * h->ps_e + 1) / 2));
+      TRY(dalloc((float**)&h->pl_dE, (size_t)(3 * h->ps_e + 1) / 2));
+      TRY(dalloc(&h->wgs_dump, 2048 + 64));
+    }
   } else {
     h->Al.resize(h->L, nullptr);
     for (int l = 0; l < h->L; ++l) {
@@ -1776,6 +1908,7 @@ int ganmf_destroy(ganmf_handle* h) {
   if (h->st2) hipStreamDestroy(h->st2);
   if (h->st) hipStreamDestroy(h->st);
   hipFree(h->slab2); hipFree(h->counters); hipFree(h->counters2);
+  hipFree(h->pl_XF); hipFree(h->pl_Dl); hipFree(h->pl_Es); hipFree(h->pl_dE); hipFree(h->wgs_dump); hipFree(h->wgs_table);
   delete h;
   return 0;
 }

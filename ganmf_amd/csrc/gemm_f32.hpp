@@ -209,6 +209,10 @@ struct EpiD {
   // sp_bias_row of the gradient.
   const float* sp_rows;    // S [sp_bias_row + sp_bias_parts, sp_ld]; nullptr: dense path
   int sp_ld, sp_bias_row, sp_bias_parts;
+  // the slab-sum kernel only (splitk_reduce_body): the finished values are ALSO filed as their three bf16 pieces, row-major with C's
+  // geometry, piece q at planes + q * plane_stride -- the operand form of wgrad_stream.hpp (nullptr: no planes)
+  unsigned short* planes;
+  long long plane_stride;
 };
 
 // X[batch row m, column col .. col + 3] of the CSR rows of the batch (EpiD::csr_*): lower bound on the sorted column indices
@@ -250,7 +254,11 @@ __device__ inline void adam_update(float g, float alpha, float reg, float& th, f
   const float gr = g + reg * x;
   m += (gr - m) * (1.f - ADAM_B1);
   v += (gr * gr - v) * (1.f - ADAM_B2);
+#if 0
+  th = x - (m * alpha) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v) + ADAM_EPS);
+#else
   th = x - (m * alpha) / (sqrtf(v) + ADAM_EPS);
+#endif
 }
 
 __device__ inline float epi_apply(const EpiD& e, float v, int row, int col, int ldc, const float* __restrict__ aux,
@@ -884,6 +892,33 @@ __global__ __launch_bounds__(256 * KG) void gemm_f32_mfma(const GemmP p) {
   gemm_f32_body<BM, BN, BK, NS, AKM, BKM, KG>(p, (int)blockIdx.x, (int)gridDim.x, smem);
 }
 
+typedef unsigned short bf16raw;
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+// ---- planes: x = hi + mid + lo exactly (split_bf16x3), three row-major bf16 matrices of the fp32 matrix's geometry -----------
+struct PlaneRef {
+  bf16raw* p;             // piece q at p + q * pstride
+  long long pstride;      // elements
+};
+
+__device__ inline void planes_store4(const PlaneRef& pl, size_t off, float x, float y, float z, float w) {
+  unsigned h0, m0, l0, h1, m1, l1;
+  split_bf16x3(x, y, h0, m0, l0);
+  split_bf16x3(z, w, h1, m1, l1);
+  *reinterpret_cast<uint2*>(pl.p + off) = make_uint2(h0, h1);
+  *reinterpret_cast<uint2*>(pl.p + pl.pstride + off) = make_uint2(m0, m1);
+  *reinterpret_cast<uint2*>(pl.p + 2 * pl.pstride + off) = make_uint2(l0, l1);
+}
+__device__ inline void planes_store1(const PlaneRef& pl, size_t off, float x) {
+  unsigned h, m, l;
+  split_bf16x3(x, 0.f, h, m, l);
+  pl.p[off] = (bf16raw)(h & 0xffffu);
+  pl.p[pl.pstride + off] = (bf16raw)(m & 0xffffu);
+  pl.p[2 * pl.pstride + off] = (bf16raw)(l & 0xffffu);
+}
+
+
 // Reduce split-K slabs and apply the deferred epilogue: out[m,n] = epi(sum_s part[s][m,n]).
 // grid = (gx, nbatch); columns >= N are never written (ones / pad columns keep their values).
 struct RedP {
@@ -926,8 +961,13 @@ __device__ __forceinline__ void splitk_reduce_body(const RedP& p, const int bx, 
 #pragma unroll
       for (int j = 0; j < 4; ++j) o[j] = epi_apply(e, o[j], m, c + j, p.ld, aux, sq);
       *reinterpret_cast<float4*>(out + off) = make_float4(o[0], o[1], o[2], o[3]);
+      if (e.planes) planes_store4(PlaneRef{e.planes, e.plane_stride}, off, o[0], o[1], o[2], o[3]);
     } else {
-      for (int j = 0; j < 4 && c + j < p.N; ++j) out[off + j] = epi_apply(e, o[j], m, c + j, p.ld, aux, sq);
+      for (int j = 0; j < 4 && c + j < p.N; ++j) {
+        const float r = epi_apply(e, o[j], m, c + j, p.ld, aux, sq);
+        out[off + j] = r;
+        if (e.planes) planes_store1(PlaneRef{e.planes, e.plane_stride}, off + j, r);
+      }
     }
   };
   const int G = reduce_groups(total, p.nsplit);
