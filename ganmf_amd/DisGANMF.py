@@ -36,6 +36,7 @@ class DisGANMF(GANMF):
                                         d_act=d_hidden_act, mfma=self.mfma, **hp)
         self.engine.set_urm(self._URM_fit)
         self.engine.set_seen(self._URM_eval)
+        self.engine.set_score_filter(None, mask_cold=True)      # MF contract (GANMF._compute_item_score)
         self.params = {'D': [_TensorRef(i, n) for i, n in enumerate(self._d_names())],
                        'G': [_TensorRef(t, n) for t, n in self._G_TENSORS]}
         from .GANMF import _SessionShim

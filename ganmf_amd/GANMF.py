@@ -98,6 +98,9 @@ class GANMF(BaseRecommender):
         self.filterTopPop_ItemsID = np.array([], dtype=int)
         self.mfma = None                # None | "f32" | "bf16" | "f16": arithmetic of the GEMM K loops (engine.Engine)
         self.initial_weights = None     # optional dict {We,be,Wd,bd,U,V}: explicit init (parity tests)
+        self.schedule_rng = None        # optional numpy RandomState for the per-epoch shuffle instead of numpy's GLOBAL stream (the
+                                        # reference's, GANMF.py:175): RandomState(s) draws what np.random.seed(s) would, and lets
+                                        # several fits run in threads of one process (tune.py: engines_per_worker)
         self.engine = None
         self.params = None
         self.sess = None
@@ -118,6 +121,7 @@ class GANMF(BaseRecommender):
         self.engine = self._make_engine(num_factors, emb_dim, batch_size, mfma=self.mfma, **hp)
         self.engine.set_urm(self._URM_fit)
         self.engine.set_seen(self._URM_eval)            # for device-side recommend()
+        self.engine.set_score_filter(None, mask_cold=True)      # MF contract: users without a training interaction score -inf
         self.params = {'D': [_TensorRef(t, n) for t, n in self._D_TENSORS],
                        'G': [_TensorRef(t, n) for t, n in self._G_TENSORS]}
         self.sess = _SessionShim(self)
@@ -130,7 +134,9 @@ class GANMF(BaseRecommender):
     def _make_engine(self, num_factors, width, batch_size, **kw):
         """One Engine on `device`, or the row-sharded group (same methods) when several devices / ranks were asked for."""
         if not self._sharded():
-            return Engine(self.num_users, self.num_items, num_factors, width, batch_size, device=self.device, **kw)
+            # a single entry in `devices` / GANMF_DEVICES names THE device (it used to be ignored in favour of `device`)
+            dev = self.devices[0] if (self.devices is not None and len(self.devices) == 1 and self.dist_backend != "local") else self.device
+            return Engine(self.num_users, self.num_items, num_factors, width, batch_size, device=dev, **kw)
         from .dist import ShardedEngine
         if self.dist_backend == "local":
             return ShardedEngine(self.num_users, self.num_items, num_factors, width, batch_size, world_size=self.world_size,
@@ -189,7 +195,7 @@ class GANMF(BaseRecommender):
         fit_t0 = window_t0 = time.time()
         stopped_at = None
         for epoch in range(1, epochs + 1):
-            np.random.shuffle(row_ids)
+            (self.schedule_rng if self.schedule_rng is not None else np.random).shuffle(row_ids)
             d_losses, g_losses = self.engine.train_epoch(row_ids, d_steps, g_steps)
             self.train_d_loss.append(np.mean(d_losses) if len(d_losses) else np.nan)
             self.train_g_loss.append(np.mean(g_losses) if len(g_losses) else np.nan)
@@ -246,14 +252,33 @@ class GANMF(BaseRecommender):
 
     # ---- scoring (GANMF.py:285-292) ---------------------------------------------------------------
     def _compute_item_score(self, user_id_array, items_to_compute=None):
+        """Scores in evaluation orientation with the MF contract's masks (BaseMatrixFactorizationRecommender.py:113-119,128-143):
+        `items_to_compute` given -> every other item is -inf (the reference's GANMF.py:285-292 takes the argument and ignores
+        it); users without a training interaction are -inf everywhere.  Both masks are applied on the device."""
         self._require_engine()
         ids = np.asarray(user_id_array).reshape(-1)
-        return self.engine.scores(ids, transposed=(self.mode == 'item'))
+        if items_to_compute is None:
+            return self.engine.scores(ids, transposed=(self.mode == 'item'))
+        with self._item_filter(items_to_compute):
+            return self.engine.scores(ids, transposed=(self.mode == 'item'))
+
+    def _item_filter(self, items_to_compute):
+        """context: scores / recommend / evaluate restricted to `items_to_compute`; the cold-user mask stays on"""
+        eng = self.engine
+
+        class _Ctx(object):
+            def __enter__(self_inner):
+                eng.set_score_filter(items_to_compute, mask_cold=True)
+
+            def __exit__(self_inner, *exc):
+                eng.set_score_filter(None, mask_cold=True)
+                return False
+        return _Ctx()
 
     # ---- recommend (Base/BaseRecommender.py:155-247) ---------------------------------------------
     _DEVICE_TOPK_MAX = 256   # above this the k-round device selection loses to numpy's argpartition
 
-    def recommend_topk(self, user_id_array, cutoff, remove_seen_flag=True):
+    def recommend_topk(self, user_id_array, cutoff, remove_seen_flag=True, items_to_compute=None):
         """Top-`cutoff` item ids per user as an [n, cutoff] int32 array, -1 padded where a user has fewer
         finite scores; scores, seen-item mask and selection all stay on the device (ganmf_recommend).
         Cut-offs the device selection does not take (above _DEVICE_TOPK_MAX or above the item count) are ranked by
@@ -261,9 +286,14 @@ class GANMF(BaseRecommender):
         self._require_engine()
         ids = np.atleast_1d(np.asarray(user_id_array)).reshape(-1)
         if 1 <= cutoff <= min(self._DEVICE_TOPK_MAX, self.n_items):
-            items, _ = self.engine.recommend(ids, cutoff, transposed=(self.mode == 'item'), remove_seen=remove_seen_flag)
+            if items_to_compute is None:
+                items, _ = self.engine.recommend(ids, cutoff, transposed=(self.mode == 'item'), remove_seen=remove_seen_flag)
+            else:
+                with self._item_filter(items_to_compute):
+                    items, _ = self.engine.recommend(ids, cutoff, transposed=(self.mode == 'item'), remove_seen=remove_seen_flag)
             return items
-        lists = self.recommend(ids, cutoff=cutoff, remove_seen_flag=remove_seen_flag, return_scores=True)[0]
+        lists = self.recommend(ids, cutoff=cutoff, remove_seen_flag=remove_seen_flag, items_to_compute=items_to_compute,
+                               return_scores=True)[0]
         items = np.full((len(ids), cutoff), -1, dtype=np.int32)
         for i, row in enumerate(lists):
             items[i, :len(row)] = row
@@ -292,7 +322,7 @@ class GANMF(BaseRecommender):
 
     def recommend(self, user_id_array, cutoff=None, remove_seen_flag=True, items_to_compute=None,
                   remove_top_pop_flag=False, remove_CustomItems_flag=False, return_scores=False):
-        device_ok = (not return_scores and items_to_compute is None and not remove_top_pop_flag
+        device_ok = (not return_scores and not remove_top_pop_flag
                      and not remove_CustomItems_flag and cutoff is not None and 1 <= cutoff <= self._DEVICE_TOPK_MAX
                      and cutoff <= self.n_items)
         if not device_ok:   # full score matrix needed on the host: the reference's own route
@@ -307,7 +337,7 @@ class GANMF(BaseRecommender):
             finally:
                 self.URM_train = saved
         single = np.isscalar(user_id_array)
-        items = self.recommend_topk(user_id_array, cutoff, remove_seen_flag)
+        items = self.recommend_topk(user_id_array, cutoff, remove_seen_flag, items_to_compute=items_to_compute)
         lists = [row[row >= 0].tolist() for row in items]
         return lists[0] if single else lists
 

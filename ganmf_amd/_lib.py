@@ -23,7 +23,7 @@ SYMBOLS = [
     "ganmf_create", "ganmf_destroy", "ganmf_comm_unique_id", "ganmf_comm_init", "ganmf_comm_init_local", "ganmf_set_urm_csr",
     "ganmf_set_tensor", "ganmf_get_tensor", "ganmf_tensor_shape", "ganmf_get_adam_powers",
     "ganmf_set_adam_powers", "ganmf_train_epoch", "ganmf_train_epoch_ragged", "ganmf_train_step", "ganmf_scores",
-    "ganmf_set_seen_csr", "ganmf_recommend", "ganmf_set_test_csr", "ganmf_evaluate", "ganmf_snapshot_best", "ganmf_restore_best", "ganmf_profile_enable", "ganmf_profile_read",
+    "ganmf_set_seen_csr", "ganmf_set_score_filter", "ganmf_recommend", "ganmf_set_test_csr", "ganmf_evaluate", "ganmf_snapshot_best", "ganmf_restore_best", "ganmf_profile_enable", "ganmf_profile_read", "ganmf_stream_timer",
     "ganmf_bench_scores", "ganmf_gemm_f32", "ganmf_crc32c", "ganmf_device_count", "ganmf_abi_version", "ganmf_last_error",
 ]
 
@@ -90,6 +90,7 @@ def load_library():
         "ganmf_train_step": (C.c_int, [vp, C.c_int, P(C.c_int32), i32, f32p]),
         "ganmf_scores": (C.c_int, [vp, P(C.c_int32), i64, C.c_int, f32p]),
         "ganmf_set_seen_csr": (C.c_int, [vp, P(C.c_int64), P(C.c_int32), i64, i64]),
+        "ganmf_set_score_filter": (C.c_int, [vp, P(C.c_int32), i64, C.c_int]),
         "ganmf_recommend": (C.c_int, [vp, P(C.c_int32), i64, C.c_int, i32, C.c_int, P(C.c_int32), f32p]),
         "ganmf_set_test_csr": (C.c_int, [vp, P(C.c_int64), P(C.c_int32), P(C.c_double), i64, i64]),
         "ganmf_evaluate": (C.c_int, [vp, P(C.c_int32), i64, C.c_int, C.c_int, P(C.c_int32), i32, P(C.c_double), P(C.c_double),
@@ -99,6 +100,7 @@ def load_library():
         "ganmf_restore_best": (C.c_int, [vp]),
         "ganmf_profile_enable": (C.c_int, [vp, C.c_int]),
         "ganmf_profile_read": (C.c_int, [vp, P(ProfEntry), i32, P(i32)]),
+        "ganmf_stream_timer": (C.c_int, [vp, C.c_int, P(C.c_double)]),
         "ganmf_bench_scores": (C.c_int, [vp, i64, C.c_int, i32, f32p]),
         "ganmf_gemm_f32": (C.c_int, [C.c_int, f32p, f32p, f32p, i64, i64, i64, C.c_int, C.c_int, C.c_int,
                                      C.c_int, C.c_int, f32p]),

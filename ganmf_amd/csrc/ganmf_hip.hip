@@ -164,6 +164,7 @@ struct ganmf_handle {
   hipStream_t st = nullptr;
   hipStream_t st2 = nullptr;             // side lane: independent kernels overlap the main lane
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_mid = nullptr;
+  hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;   // ganmf_stream_timer
   hipEvent_t ev_we = nullptr, ev_wd = nullptr;   // data-parallel: "the side lane has finished updating We / Wd" (dp_mark / dp_join)
   int U = 0, N = 0, k = 0, e = 0, B = 0;
   int ldN = 0, ldk = 0, lde = 0;
@@ -235,6 +236,11 @@ struct ganmf_handle {
   long long* seen_indptr = nullptr;
   int* seen_indices = nullptr;
   int64_t seen_rows = 0, seen_cols = 0;
+  // score filter (ganmf_set_score_filter): byte per score column (1 = computed), and whether cold rows are masked
+  unsigned char* item_mask = nullptr;
+  size_t item_mask_cap = 0;
+  int64_t item_mask_w = 0;             // 0: no item filter; else one past the largest listed item
+  bool mask_cold = false;
   int* topk_items = nullptr;
   float* topk_vals = nullptr;
   size_t topk_cap = 0;
@@ -274,6 +280,7 @@ struct ganmf_handle {
   size_t wgs_table_cap = 0;
   bool wgrad_stream = false;           // GANMF_WGRAD_STREAM=1 (make DIAG=1 only): the two fused-Adam weight-gradient products as the persistent role-split launch
   int adam_nfast = 3;                  // GANMF_ADAM_NFAST: tile order of the fused-Adam weight-gradient launch (GemmP::n_fastest)
+  long long fork_armed_at = 0;         // launch_count() when fork_arm() handed ev_fork to the next launch
   bool fork_attach = true;             // GANMF_FORK_ATTACH: forks ride on the producing kernel's completion event (fork_arm / fork_wait)
   bool force_coll = false;             // GANMF_FORCE_COLLECTIVES=1: a one-rank communicator still issues its (in-place) reduce-scatter /
                                        // all-gather calls, so that the RCCL call sites execute on a one-GPU box (tests, bench)
@@ -519,8 +526,10 @@ int run_gemm(ganmf_handle* h, int tag_gemm, int tag_red, GemmP g, bool akm, bool
   pl.persist = gemm_persist_eligible(g, akm, bkm, pl, tn.persist) ? (tn.persist >= 2 ? tn.persist : 1) : 0;
   // a plan for the 16-wave fp32 ring kernel (one 64 x 64 tile per CU) runs the 16-wave split-bf16 loop instead: same grid, same split,
   // same epilogue, 6 / 16 of the MFMA cycles (gemm_bf16k.hpp)
-  if (!force && pl.mode == MFMA_F32 && pl.tile == 64 && pl.kg == 4 && pl.ring == 3 && !pl.persist && !(akm && !bkm) && tag_gemm != T_GEMM_GUB && tag_gemm != T_GEMM_GV &&      // (gUb / gV: their other form is the fp32 pair_kernel)
-      ((h->x3kg & 1) && !akm && !bkm || (h->x3kg & 2) && bkm)) pl.mode = MFMA_BF16X3;      // bit 0: NT products, bit 1: products with a K-major B
+  // (only under MFMA_AUTO: a handle created with GANMF_FLAG_MFMA_F32 / mfma="f32" runs the fp32 MFMA everywhere, as documented)
+  if (!force && h->tune.mode == MFMA_AUTO && pl.mode == MFMA_F32 && pl.tile == 64 && pl.kg == 4 && pl.ring == 3 && !pl.persist && !(akm && !bkm) &&
+      tag_gemm != T_GEMM_GUB && tag_gemm != T_GEMM_GV &&      // (gUb / gV: their other form is the fp32 pair_kernel)
+      (((h->x3kg & 1) && !akm && !bkm) || ((h->x3kg & 2) && bkm))) pl.mode = MFMA_BF16X3;      // bit 0: NT products, bit 1: products with a K-major B
   // ... and a single-piece (bf16 / fp16) plan with a CU per workgroup takes the same 16-wave kernel in its one-piece form (bit 2)
   if (!force && (h->x3kg & 4) && (pl.mode == MFMA_F16 || pl.mode == MFMA_BF16) && pl.tile == 64 && pl.ring == 3 && pl.bk != 32 && !pl.persist &&
       !(akm && !bkm)) pl.kg = 4;
@@ -627,6 +636,10 @@ int run_gemm(ganmf_handle* h, int tag_gemm, int tag_red, GemmP g, bool akm, bool
   return 0;
 }
 
+// the combined launches (front_kernel, de_dcoef_kernel) carry the 16-wave split-bf16 loop where the stand-alone product would run it:
+// GANMF_X3KG bit 0, and only when the handle leaves the arithmetic to the planner (a forced fp32-MFMA handle keeps the fp32 MFMA)
+inline bool combined_x3(const ganmf_handle* h) { return (h->x3kg & 1) != 0 && h->tune.mode == MFMA_AUTO; }
+
 // fork: the side lane starts after everything enqueued so far on the main lane
 int lane_fork(ganmf_handle* h) {
   HIP_TRY(hipEventRecord(h->ev_fork, h->st));
@@ -636,14 +649,19 @@ int lane_fork(ganmf_handle* h) {
 // The same fork in two halves around the LAST main-lane launch the side lane has to wait for: fork_arm() before it (that launch
 // then carries ev_fork as its completion event: no marker packet on the main lane), fork_wait() after it.  While the library's
 // profiler is on (its scopes hand their own events to the launches) and with GANMF_FORK_ATTACH=0 the plain fork is used.
+// The attached event marks the FIRST launch after fork_arm(): the fork is only taken as attached when exactly one kernel was
+// launched in between (a plan that adds a stand-alone reduce or an attached slab sum falls back to the marker-packet fork, which
+// covers everything enqueued so far -- never a silent wait for the wrong kernel).
 bool fork_arm(ganmf_handle* h) {
   if (!h->fork_attach || h->prof) return false;
   launch_stop_event() = h->ev_fork;
+  h->fork_armed_at = launch_count();
   return true;
 }
 int fork_wait(ganmf_handle* h, bool armed) {
   if (!armed) return lane_fork(h);
-  if (launch_stop_event() != nullptr) {      // nothing was launched in between (a plan without a kernel): plain fork
+  const long long launched = launch_count() - h->fork_armed_at;
+  if (launch_stop_event() != nullptr || launched != 1) {      // nothing, or more than one kernel, was launched in between: plain fork
     launch_stop_event() = nullptr;
     return lane_fork(h);
   }
@@ -724,14 +742,14 @@ int rows_and_generator(ganmf_handle* h, const int* rows_dev, int nb, int which, 
       const long long key = ((long long)T_GEMM_GEN << 48) ^ ((long long)g.M << 32) ^ ((long long)g.N << 16) ^ g.K;
       if (std::find(h->seen_plans.begin(), h->seen_plans.end(), key) == h->seen_plans.end()) {
         h->seen_plans.push_back(key);
-        fprintf(stderr, "[ganmf plan] %-28s M=%d N=%d K=%d batch=1 -> tile 64 ring 3 kg 4 nsplit 1 (kps %d) mfma f32 wgs %d est %.1f us (one launch with the %d CSR rows)\n",
-                kTagName[T_GEMM_GEN], g.M, g.N, g.K, pl.kps, pl.tiles_m * pl.tiles_n, pl.est_us, nb);
+        fprintf(stderr, "[ganmf plan] %-28s M=%d N=%d K=%d batch=1 -> tile 64 ring 3 kg 4 nsplit 1 (kps %d) mfma %s wgs %d est %.1f us (one launch with the %d CSR rows)\n",
+                kTagName[T_GEMM_GEN], g.M, g.N, g.K, pl.kps, combined_x3(h) ? "bf16x3" : "f32", pl.tiles_m * pl.tiles_n, pl.est_us, nb);
       }
     }
     Scope s(h, T_FRONT, gemm_flops(g.M, g.N, g.K), gemm_bytes(g.M, g.N, g.K) + 4.0 * nb * (N + 2 * k));
     g.A = h->Ue.p; g.a_gather = rows_dev;        // A row r = U[rows[r]]: the lookup rides in the operand fetch
     fill_plan(g, pl);
-    if (h->x3kg & 1) GANMF_LAUNCH((front_kernel<4, true>), dim3(pl.tiles_m * pl.tiles_n + nb), dim3(1024), 0, h->st, g, d);
+    if (combined_x3(h)) GANMF_LAUNCH((front_kernel<4, true>), dim3(pl.tiles_m * pl.tiles_n + nb), dim3(1024), 0, h->st, g, d);
     else GANMF_LAUNCH(front_kernel<4>, dim3(pl.tiles_m * pl.tiles_n + nb), dim3(1024), 0, h->st, g, d);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -869,7 +887,7 @@ int d_step(ganmf_handle* h, const int* rows_dev, int nb, int b_global, float* pa
       q.C = h->slab; q.c_split_stride = (long long)gde.M * gde.ldc; q.c_batch_stride = (long long)gde.M * gde.ldc;
       const int ng = pde.tiles_m * pde.tiles_n * pde.nsplit;
       const int nd = h->dcoef_spread ? 0 : (int)std::max<long long>(1, std::min<long long>(32, (dc_total + 4095) / 4096));
-      if (h->x3kg & 1) GANMF_LAUNCH((de_dcoef_kernel<4, true>), dim3(ng + nd), dim3(1024), 0, h->st, q, dc, nd);
+      if (combined_x3(h)) GANMF_LAUNCH((de_dcoef_kernel<4, true>), dim3(ng + nd), dim3(1024), 0, h->st, q, dc, nd);
       else GANMF_LAUNCH(de_dcoef_kernel<4>, dim3(ng + nd), dim3(1024), 0, h->st, q, dc, nd);
       HIP_TRY(hipGetLastError());
       dcoef_done = true;
@@ -1765,7 +1783,11 @@ static int create_impl(const ganmf_cfg* cfg, ganmf_handle* h) {
   // lane events order two streams of THIS device only: no system-scope fence when they are recorded (the cache write-back /
   // invalidate a host-visible event performs showed as ~7 us of idle main lane per fork or join in the data-parallel step's
   // rocprofv3 timeline, profiles/r03_dp_timeline.md; kernel boundaries keep their device-scope release / acquire)
-  const unsigned lane_flags = env_int("GANMF_LANE_EVENT_FENCE", 0) ? hipEventDisableTiming : (hipEventDisableTiming | hipEventDisableSystemFence);
+  // With more than one rank the events also order RCCL's peer writes (all-gather results land in We / Wd / V from other GPUs)
+  // before the main-lane kernels that read them: the fence-free form has only ever run on one GPU, so world_size > 1 keeps the
+  // system-scope fence until a multi-GPU bitwise-replica run has passed without it (GANMF_LANE_EVENT_FENCE = 0 / 1 overrides).
+  const bool lane_fence = env_int("GANMF_LANE_EVENT_FENCE", cfg->world_size > 1 ? 1 : 0) != 0;
+  const unsigned lane_flags = lane_fence ? hipEventDisableTiming : (hipEventDisableTiming | hipEventDisableSystemFence);
   HIP_TRY(hipEventCreateWithFlags(&h->ev_fork, lane_flags));
   HIP_TRY(hipEventCreateWithFlags(&h->ev_join, lane_flags));
   HIP_TRY(hipEventCreateWithFlags(&h->ev_mid, lane_flags));
@@ -1896,13 +1918,15 @@ int ganmf_destroy(ganmf_handle* h) {
   hipFree(h->test_indptr); hipFree(h->test_indices); hipFree(h->test_gain); hipFree(h->eval_buf);
   hipFree(h->XF); hipFree(h->Ub); hipFree(h->E); hipFree(h->Dl); hipFree(h->dE); hipFree(h->dF); hipFree(h->gUb);
   hipFree(h->slab); hipFree(h->rs); hipFree(h->scal); hipFree(h->sqp);
-  hipFree(h->seen_indptr); hipFree(h->seen_indices); hipFree(h->topk_items); hipFree(h->topk_vals); hipFree(h->sc_ids);
+  hipFree(h->seen_indptr); hipFree(h->seen_indices); hipFree(h->item_mask); hipFree(h->topk_items); hipFree(h->topk_vals); hipFree(h->sc_ids);
   hipFree(h->colbuf); hipFree(h->parts_all); hipFree(h->sc_rows); hipFree(h->sc_out); hipFree(h->sc_pa); hipFree(h->sc_pb);
   for (auto& r : h->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
   if (h->st2) hipStreamSynchronize(h->st2);
   if (h->ev_fork) hipEventDestroy(h->ev_fork);
   if (h->ev_join) hipEventDestroy(h->ev_join);
   if (h->ev_mid) hipEventDestroy(h->ev_mid);
+  if (h->ev_t0) hipEventDestroy(h->ev_t0);
+  if (h->ev_t1) hipEventDestroy(h->ev_t1);
   if (h->ev_we) hipEventDestroy(h->ev_we);
   if (h->ev_wd) hipEventDestroy(h->ev_wd);
   if (h->st2) hipStreamDestroy(h->st2);
@@ -2303,6 +2327,56 @@ static int upload_ids(ganmf_handle* h, const int32_t* ids, int64_t n, int** out)
   return 0;
 }
 
+// The filter of ganmf_set_score_filter as the two kernel arguments (item mask, indptr of the rows whose emptiness means "cold"),
+// checked against the orientation in use: score width W, `limit` scored rows.
+static int score_filter_args(ganmf_handle* h, const char* who, int W, int limit, const unsigned char** mask, const long long** cold) {
+  *mask = nullptr; *cold = nullptr;
+  if (h->item_mask_w > 0) {
+    if (h->item_mask_w > W) return fail(-1, "%s: the score filter lists item %lld but the score rows have %d columns", who, (long long)h->item_mask_w - 1, W);
+    *mask = h->item_mask;
+  }
+  if (h->mask_cold) {
+    if (!h->seen_indptr || h->seen_rows != limit || h->seen_cols != W)
+      return fail(-1, "%s: masking cold rows needs ganmf_set_seen_csr with a %d x %d matrix", who, limit, W);
+    *cold = h->seen_indptr;
+  }
+  return 0;
+}
+static int apply_score_filter(ganmf_handle* h, const char* who, float* scores, int ld, int W, const int* ids_dev, int64_t n, int limit) {
+  const unsigned char* mask; const long long* cold;
+  TRY(score_filter_args(h, who, W, limit, &mask, &cold));
+  if (!mask && !cold) return 0;
+  GANMF_LAUNCH(score_filter_kernel, dim3((int)n), dim3(256), 0, h->st, scores, ld, W, ids_dev, mask, cold);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int ganmf_set_score_filter(ganmf_handle* h, const int32_t* items, int64_t n_items, int mask_cold_rows) {
+  if (!h) return fail(-1, "null handle");
+  if (n_items < 0 || (n_items > 0 && !items)) return fail(-1, "ganmf_set_score_filter: bad item list");
+  const int64_t wmax = std::max(h->U, h->N);
+  int64_t top = 0;
+  for (int64_t i = 0; i < n_items; ++i) {
+    if (items[i] < 0 || items[i] >= wmax) return fail(-1, "ganmf_set_score_filter: item %d out of range [0,%lld)", items[i], (long long)wmax);
+    top = std::max<int64_t>(top, (int64_t)items[i] + 1);
+  }
+  HIP_TRY(hipSetDevice(h->dev));
+  HIP_TRY(hipStreamSynchronize(h->st));
+  if (n_items > 0) {
+    if ((size_t)wmax > h->item_mask_cap) {
+      hipFree(h->item_mask); h->item_mask = nullptr; h->item_mask_cap = 0;
+      HIP_TRY(hipMalloc((void**)&h->item_mask, (size_t)wmax));
+      h->item_mask_cap = (size_t)wmax;
+    }
+    std::vector<unsigned char> m((size_t)wmax, 0);
+    for (int64_t i = 0; i < n_items; ++i) m[(size_t)items[i]] = 1;
+    HIP_TRY(hipMemcpy(h->item_mask, m.data(), m.size(), hipMemcpyHostToDevice));
+  }
+  h->item_mask_w = n_items > 0 ? top : 0;
+  h->mask_cold = mask_cold_rows != 0;
+  return 0;
+}
+
 int ganmf_scores(ganmf_handle* h, const int32_t* ids, int64_t n, int transposed, float* out) {
   if (!h || !ids || !out) return fail(-1, "ganmf_scores: null argument");
   if (n < 1 || n > (1 << 30)) return fail(-1, "ganmf_scores: n out of range");
@@ -2314,6 +2388,7 @@ int ganmf_scores(ganmf_handle* h, const int32_t* ids, int64_t n, int transposed,
   TRY(upload_ids(h, ids, n, &ids_dev));
   float* od = nullptr; int W = 0, ldw = 0;
   int rc = scores_device(h, ids_dev, n, transposed, &od, &W, &ldw);
+  if (rc == 0) rc = apply_score_filter(h, "ganmf_scores", od, ldw, W, ids_dev, n, limit);
   if (rc == 0) {
     hipError_t e = hipMemcpy2DAsync(out, (size_t)W * 4, od, (size_t)ldw * 4, (size_t)W * 4, n, hipMemcpyDeviceToHost, h->st);
     if (e == hipSuccess) e = hipStreamSynchronize(h->st);
@@ -2366,6 +2441,8 @@ static int recommend_device(ganmf_handle* h, const char* who, const int32_t* ids
     HIP_TRY(hipMalloc((void**)&h->topk_vals, need * sizeof(float)));
     h->topk_cap = need;
   }
+  const unsigned char* fmask; const long long* fcold;
+  TRY(score_filter_args(h, who, W, limit, &fmask, &fcold));
   float* od = nullptr; int Wd = 0, ldw = 0;
   TRY(scores_device(h, ids_dev, n, transposed, &od, &Wd, &ldw));
   const int lds_cap = 32768;   // floats: 128 KiB of the CU's 160 KiB
@@ -2374,7 +2451,7 @@ static int recommend_device(ganmf_handle* h, const char* who, const int32_t* ids
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mask_topk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
   GANMF_LAUNCH(mask_topk_kernel, dim3((int)n), dim3(256), shmem, h->st, od, ldw, Wd, ids_dev,
                      remove_seen ? h->seen_indptr : (const long long*)nullptr, h->seen_indices, (int)cutoff, lds_cap,
-                     h->topk_items, h->topk_vals);
+                     h->topk_items, h->topk_vals, fmask, fcold);
   HIP_TRY(hipGetLastError());
   if (ids_dev_out) *ids_dev_out = ids_dev;
   return 0;
@@ -2522,6 +2599,20 @@ int ganmf_restore_best(ganmf_handle* h) {
   for (Tensor* t : all_tensors(h))
     HIP_TRY(hipMemcpyAsync(t->p, t->best, t->padded() * sizeof(float), hipMemcpyDeviceToDevice, h->st));
   HIP_TRY(hipStreamSynchronize(h->st));
+  return 0;
+}
+
+int ganmf_stream_timer(ganmf_handle* h, int stop, double* ms) {
+  if (!h) return fail(-1, "null handle");
+  HIP_TRY(hipSetDevice(h->dev));
+  if (!h->ev_t0) { HIP_TRY(hipEventCreate(&h->ev_t0)); HIP_TRY(hipEventCreate(&h->ev_t1)); }
+  if (!stop) { HIP_TRY(hipEventRecord(h->ev_t0, h->st)); return 0; }
+  if (!ms) return fail(-1, "ganmf_stream_timer: null result pointer");
+  HIP_TRY(hipEventRecord(h->ev_t1, h->st));
+  HIP_TRY(hipEventSynchronize(h->ev_t1));
+  float f = 0.f;
+  HIP_TRY(hipEventElapsedTime(&f, h->ev_t0, h->ev_t1));
+  *ms = (double)f;
   return 0;
 }
 

@@ -53,11 +53,13 @@ inline LaunchProf& launch_prof() { static thread_local LaunchProf lp; return lp;
 // can wait for exactly that kernel; recording an event behind the kernel instead puts a marker packet into the producing
 // stream, which showed as ~5 us of idle lane per fork in the data-parallel step's timeline (profiles/r03_dp_timeline.md).
 inline hipEvent_t& launch_stop_event() { static thread_local hipEvent_t ev = nullptr; return ev; }
+inline long long& launch_count() { static thread_local long long n = 0; return n; }      // launches of this host thread (fork_arm / fork_wait)
 
 template <class F, class... Args>
 inline void launch_kernel(F kernel, const dim3& grid, const dim3& block, unsigned shmem, hipStream_t st, Args... args) {
   LaunchProf& lp = launch_prof();
   hipEvent_t& stop = launch_stop_event();
+  ++launch_count();
   if (lp.start && lp.count++ == 0) hipExtLaunchKernelGGL(kernel, grid, block, shmem, st, lp.start, lp.stop, 0, args...);
   else if (stop) { hipExtLaunchKernelGGL(kernel, grid, block, shmem, st, nullptr, stop, 0, args...); stop = nullptr; }
   else hipLaunchKernelGGL(kernel, grid, block, shmem, st, args...);

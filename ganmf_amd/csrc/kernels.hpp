@@ -645,7 +645,9 @@ __global__ __launch_bounds__(256) void mask_topk_kernel(float* __restrict__ scor
                                                         const int* __restrict__ row_ids,
                                                         const long long* __restrict__ seen_indptr,
                                                         const int* __restrict__ seen_indices, int k, int lds_cap,
-                                                        int* __restrict__ out_items, float* __restrict__ out_vals) {
+                                                        int* __restrict__ out_items, float* __restrict__ out_vals,
+                                                        const unsigned char* __restrict__ item_mask,
+                                                        const long long* __restrict__ cold_indptr) {
   extern __shared__ __attribute__((aligned(16))) float srow[];
   __shared__ float wv[4];
   __shared__ int wi[4];
@@ -656,6 +658,12 @@ __global__ __launch_bounds__(256) void mask_topk_kernel(float* __restrict__ scor
   if (in_lds)
     for (int i = tid; i < W; i += 256) srow[i] = g[i];
   __syncthreads();
+  // MF contract (Base/BaseMatrixFactorizationRecommender.py:113-119,128-143): items outside items_to_compute score -inf; a row
+  // without a training interaction (cold) scores -inf everywhere
+  const bool cold = cold_indptr != nullptr && cold_indptr[row_ids[r] + 1] == cold_indptr[row_ids[r]];
+  if (item_mask != nullptr || cold)
+    for (int i = tid; i < W; i += 256)
+      if (cold || !item_mask[i]) row[i] = -INFINITY;
   if (seen_indptr) {
     const int u = row_ids[r];
     const long long s = seen_indptr[u], e = seen_indptr[u + 1];
@@ -688,6 +696,17 @@ __global__ __launch_bounds__(256) void mask_topk_kernel(float* __restrict__ scor
     }
     __syncthreads();
   }
+}
+
+// ganmf_scores under a score filter (ganmf_set_score_filter): one workgroup per score row, same rule as mask_topk_kernel
+__global__ __launch_bounds__(256) void score_filter_kernel(float* __restrict__ scores, int ld, int W, const int* __restrict__ row_ids,
+                                                           const unsigned char* __restrict__ item_mask,
+                                                           const long long* __restrict__ cold_indptr) {
+  float* row = scores + (size_t)blockIdx.x * ld;
+  const bool cold = cold_indptr != nullptr && cold_indptr[row_ids[blockIdx.x] + 1] == cold_indptr[row_ids[blockIdx.x]];
+  if (item_mask == nullptr && !cold) return;
+  for (int i = threadIdx.x; i < W; i += 256)
+    if (cold || !item_mask[i]) row[i] = -INFINITY;
 }
 
 __global__ void fill_kernel(float* __restrict__ p, float v, long long n) {

@@ -28,6 +28,7 @@ or persistence are asked for (GANMF.py:285-292: `_compute_item_score` needs all 
 """
 import multiprocessing as mp
 import threading
+import time
 
 import numpy as np
 
@@ -132,6 +133,22 @@ class _ProcessRank(object):
     def submit(self, name, *args, **kw):
         self.conn.send((name, args, kw))
 
+    def ready(self, timeout):
+        """an answer (or the end of the pipe: the process died) is waiting"""
+        return self.conn.poll(timeout)
+
+    def kill(self):
+        """end the process now (a peer failed: this rank may sit in a collective that will never complete)"""
+        try:
+            self.conn.close()
+        except Exception:
+            pass
+        if self.proc.is_alive():
+            self.proc.terminate()
+            self.proc.join(timeout=10)
+            if self.proc.is_alive():
+                self.proc.kill()
+
     def result(self, timeout=600.0):
         if not self.conn.poll(timeout):
             raise L.GanmfError("sharded fit: a rank process did not answer within %.0f s" % timeout)
@@ -174,6 +191,13 @@ class _ThreadRank(object):
                 self._out = ("err", ex)
         self._t = threading.Thread(target=run)
         self._t.start()
+
+    def ready(self, timeout):
+        self._t.join(timeout)
+        return not self._t.is_alive()
+
+    def kill(self):      # (threads cannot be ended; the loopback group is marked failed when an engine closes, which wakes its peers)
+        self.close()
 
     def result(self, timeout=600.0):
         self._t.join(timeout)
@@ -246,17 +270,30 @@ class ShardedEngine(object):
             raise
 
     # ---- plumbing -------------------------------------------------------------------------------------
-    def _collect(self):
-        """results of the request every rank was just handed; a failed rank ends the whole group (its peers would wait
-        for it in the next collective for ever)"""
-        outs, first = [], None
-        for rk in self.ranks:
-            try:
-                outs.append(rk.result())
-            except BaseException as ex:
-                outs.append(None)
-                first = first or ex
+    def _collect(self, timeout=600.0):
+        """results of the request every rank was just handed.  All ranks are polled together; the FIRST failure (an error
+        reply, a dead process, the deadline) ends the whole group at once -- the survivors sit in a collective that can no
+        longer complete, and waiting for them one after the other would stall the caller for world x timeout."""
+        n = len(self.ranks)
+        outs, first, pending = [None] * n, None, list(range(n))
+        deadline = time.monotonic() + timeout
+        while pending and first is None:
+            for i in list(pending):
+                if self.ranks[i].ready(0.02):
+                    try:
+                        outs[i] = self.ranks[i].result(timeout=5.0)
+                    except BaseException as ex:
+                        first = ex
+                        break
+                    pending.remove(i)
+            if pending and first is None and time.monotonic() > deadline:
+                first = L.GanmfError("sharded fit: rank(s) %s did not answer within %.0f s" % (pending, timeout))
         if first is not None:
+            for rk in self.ranks:
+                try:
+                    rk.kill()
+                except Exception:
+                    pass
             self.close()
             raise first
         return outs
@@ -363,6 +400,9 @@ class ShardedEngine(object):
 
     def set_seen(self, urm_eval_csr):
         self.master.set_seen(urm_eval_csr)
+
+    def set_score_filter(self, items_to_compute=None, mask_cold=False):
+        self.master.set_score_filter(items_to_compute, mask_cold)
 
     def recommend(self, ids, cutoff, transposed=False, remove_seen=True):
         self._sync_master()

@@ -133,6 +133,16 @@ class Engine:
         L.check(self.lib.ganmf_set_seen_csr(self.h, indptr.ctypes.data_as(C.POINTER(C.c_int64)), _i32p(indices),
                                             urm.shape[0], urm.shape[1]), "ganmf_set_seen_csr")
 
+    def set_score_filter(self, items_to_compute=None, mask_cold=False):
+        """MF contract (BaseMatrixFactorizationRecommender.py:113-119,128-143) for every later scores / recommend / evaluate
+        call: only `items_to_compute` keep their scores (the others -inf); rows that are empty in the set_seen() matrix score
+        -inf everywhere."""
+        if items_to_compute is None or len(items_to_compute) == 0:
+            L.check(self.lib.ganmf_set_score_filter(self.h, None, 0, int(bool(mask_cold))), "ganmf_set_score_filter")
+            return
+        items = np.ascontiguousarray(np.asarray(items_to_compute).reshape(-1), dtype=np.int32)
+        L.check(self.lib.ganmf_set_score_filter(self.h, _i32p(items), len(items), int(bool(mask_cold))), "ganmf_set_score_filter")
+
     def recommend(self, ids, cutoff, transposed=False, remove_seen=True):
         """device top-k: returns (items [n, cutoff] int32 with -1 padding, scores [n, cutoff])"""
         ids = np.ascontiguousarray(ids, dtype=np.int32).ravel()
@@ -180,6 +190,16 @@ class Engine:
         L.check(self.lib.ganmf_restore_best(self.h), "ganmf_restore_best")
 
     # -- measurement ------------------------------------------------------------------------
+    def timer_start(self):
+        """hipEvent on the library's stream in front of whatever is enqueued next (bench.py's timed region)."""
+        L.check(self.lib.ganmf_stream_timer(self.h, 0, None), "ganmf_stream_timer")
+
+    def timer_stop(self):
+        """milliseconds the stream spent since timer_start (waits for the stream)."""
+        ms = C.c_double(0.0)
+        L.check(self.lib.ganmf_stream_timer(self.h, 1, C.byref(ms)), "ganmf_stream_timer")
+        return float(ms.value)
+
     def profile(self, on):
         L.check(self.lib.ganmf_profile_enable(self.h, int(on)), "ganmf_profile_enable")
 

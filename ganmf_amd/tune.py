@@ -70,13 +70,17 @@ def search_space(model_name, n_users, n_items):
 
 
 # ---- one trial (RecSysExp.obj_func) -----------------------------------------------------------------
-def run_trial(spec, params, device):
-    """-> dict(fitness, fit_params, results_string, seconds).  `spec` is the picklable experiment description."""
+def run_trial(spec, params, device, schedule_rng=None):
+    """-> dict(fitness, fit_params, results_string, seconds).  `spec` is the picklable experiment description.
+    schedule_rng: a numpy RandomState for the fit's per-epoch shuffles (default: numpy's global stream, as the reference);
+    trials that run in threads of one process each bring their own."""
     t0 = time.time()
     cls = spec["recommender_class"]
     model = cls(spec["URM_train_small"], mode=spec["mode"], seed=spec["seed"], is_experiment=True, **spec["model_kwargs"])
     if hasattr(model, "device"):
         model.device = device
+    if schedule_rng is not None:
+        model.schedule_rng = schedule_rng
     fit_params = dict(params)
     fit_kwargs = dict(fit_params)
     fit_kwargs.update(EARLY_STOPPING)
@@ -94,25 +98,42 @@ def run_trial(spec, params, device):
             "seconds": time.time() - t0}
 
 
-def _worker(spec, device, tasks, results, worker_id=0):
+def _worker(spec, device, tasks, results, worker_id=0, engines=1):
+    """One worker PROCESS per GPU slot running `engines` trial threads: every thread owns an engine (its own HIP stream) and
+    runs whole trials; ctypes releases the GIL inside the library, so one trial's launch gaps and host-side evaluation are
+    filled by another trial's kernels -- unlike several PROCESSES on one GPU, which time-slice it (20 ML-1M trials: 47.8 s
+    with one process, 56.4 s with two).  Thread t announces its trials as worker (worker_id, t)."""
     try:
         if spec.get("visible_devices") is not None:      # one physical GPU per worker, seen as device 0
             os.environ["HIP_VISIBLE_DEVICES"] = str(spec["visible_devices"][device])
             device = 0
-        while True:
-            item = tasks.get()
-            if item is None:
-                return
-            idx, params = item
-            results.put(("start", worker_id, idx))        # lets the driver attribute a hard crash to this trial
-            try:
-                out = run_trial(spec, params, device)
-            except MemoryError as e:                      # the reference maps OOM to fitness 0 (RecSysExp.py:290-291)
-                out = {"fitness": 0.0, "fit_params": dict(params), "results_string": "out of memory: %s\n" % e, "seconds": 0.0}
-            except Exception as e:                        # a failed trial must not take the search down
-                out = {"fitness": 0.0, "fit_params": dict(params), "results_string": "trial failed: %r\n" % (e,), "seconds": 0.0,
-                       "error": repr(e)}
-            results.put(("done", worker_id, idx, params, out))
+
+        def loop(t):
+            while True:
+                item = tasks.get()
+                if item is None:
+                    return
+                idx, params = item
+                results.put(("start", (worker_id, t), idx))        # lets the driver attribute a hard crash to this trial
+                try:
+                    # threads share numpy's global stream: each trial shuffles from its own (seeded by trial, reproducible)
+                    rng = np.random.RandomState((spec["seed"] * 1000003 + idx) % (1 << 31)) if engines > 1 else None
+                    out = run_trial(spec, params, device, schedule_rng=rng)
+                except MemoryError as e:                      # the reference maps OOM to fitness 0 (RecSysExp.py:290-291)
+                    out = {"fitness": 0.0, "fit_params": dict(params), "results_string": "out of memory: %s\n" % e, "seconds": 0.0}
+                except Exception as e:                        # a failed trial must not take the search down
+                    out = {"fitness": 0.0, "fit_params": dict(params), "results_string": "trial failed: %r\n" % (e,), "seconds": 0.0,
+                           "error": repr(e)}
+                results.put(("done", (worker_id, t), idx, params, out))
+
+        if engines <= 1:
+            return loop(0)
+        import threading
+        threads = [threading.Thread(target=loop, args=(t,), daemon=True) for t in range(engines)]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
     except KeyboardInterrupt:
         return
 
@@ -121,10 +142,11 @@ def _worker(spec, device, tasks, results, worker_id=0):
 class TrialParallelTuner(object):
     def __init__(self, recommender_class, URM_train_small, URM_early_stop, URM_validation, logsdir, mode="user",
                  metric="MAP", at=5, seed=1337, method="random", n_workers=None, devices=None, evaluator_class=None,
-                 model_kwargs=None, isolate_devices=False):
+                 model_kwargs=None, isolate_devices=False, engines_per_worker=1):
         """devices: device ordinals to use (default: every visible HIP device); n_workers: worker processes (default:
         one per device; more than one per device is allowed); isolate_devices: give each worker only its GPU via
-        HIP_VISIBLE_DEVICES."""
+        HIP_VISIBLE_DEVICES; engines_per_worker: trial threads (each with its own engine and stream) inside every worker
+        process -- the way to put more than one trial on a GPU at a time (_worker)."""
         if method not in ("random", "bayesian"):
             raise ValueError("method must be 'random' or 'bayesian'")
         if evaluator_class is None:
@@ -134,6 +156,7 @@ class TrialParallelTuner(object):
             devices = list(range(max(1, L.load_library().ganmf_device_count())))
         self.devices = list(devices)
         self.n_workers = n_workers or len(self.devices)
+        self.engines = max(1, int(engines_per_worker))
         self.method, self.seed, self.logsdir = method, seed, logsdir
         self.metric, self.at = metric, at
         os.makedirs(logsdir, exist_ok=True)
@@ -207,8 +230,12 @@ class TrialParallelTuner(object):
         ctx = mp.get_context("spawn")             # never fork a process that has touched the GPU
         # results travel on a SimpleQueue: its put() writes to the pipe before returning (a Queue hands the item to a
         # feeder thread, and a worker that dies right after announcing a trial would take the announcement with it)
-        tasks, results = ctx.Queue(), ctx.SimpleQueue()
-        workers, reaped, running = {}, set(), {}      # worker id -> process; ids of dead workers; worker id -> trial index
+        # Tasks travel on ONE queue PER worker process (the driver places every trial): a shared task queue is read under a
+        # cross-process lock, and a worker that dies hard while one of its threads sits in get() would take that lock with it.
+        results = ctx.SimpleQueue()
+        workers, queues, assigned = {}, {}, {}        # worker id -> process / its task queue / trial indices it holds
+        reaped, running = set(), {}                   # ids of dead workers; (worker id, thread) -> announced trial index
+        backlog = []                                  # trials to place (new ones and those a dead worker never announced)
         next_wid = [0]
 
         def spawn():
@@ -216,18 +243,18 @@ class TrialParallelTuner(object):
             next_wid[0] += 1
             slot = wid % len(self.devices)
             dev = slot if self.spec["visible_devices"] is not None else self.devices[slot]
-            workers[wid] = ctx.Process(target=_worker, args=(self.spec, dev, tasks, results, wid), daemon=True)
+            queues[wid], assigned[wid] = ctx.Queue(), set()
+            workers[wid] = ctx.Process(target=_worker, args=(self.spec, dev, queues[wid], results, wid, self.engines), daemon=True)
             workers[wid].start()
 
         for _ in range(self.n_workers):
             spawn()
         pending, issued, done = {}, len(self.func_vals), len(self.func_vals)
-        idle_polls = 0
 
         def finish(idx, params, out):
             nonlocal done
             if pending.pop(idx, None) is None:
-                return                            # already recorded (a re-issued trial can report twice)
+                return                            # already recorded
             self._record(params, out)
             done += 1
             if verbose:
@@ -242,6 +269,17 @@ class TrialParallelTuner(object):
                                      "results_string": "worker %d died (exit code %s)\n" % (wid, exitcode),
                                      "error": "worker died, exit code %s" % exitcode})
 
+        def place():
+            """hand backlog trials to the live workers with a free trial thread, least loaded first"""
+            while backlog:
+                live = [w for w in workers if len(assigned[w]) < self.engines]
+                if not live:
+                    return
+                wid = min(live, key=lambda w: len(assigned[w]))
+                idx = backlog.pop(0)
+                assigned[wid].add(idx)
+                queues[wid].put((idx, pending[idx]))
+
         def next_message():
             deadline = time.time() + self.poll_seconds
             while results.empty():
@@ -252,58 +290,56 @@ class TrialParallelTuner(object):
 
         try:
             while done < evals:
-                while issued < evals and len(pending) < self.n_workers:
-                    params = self._propose(rng, list(pending.values()))
-                    pending[issued] = params
-                    tasks.put((issued, params))
+                while issued < evals and len(pending) < self.n_workers * self.engines:
+                    pending[issued] = self._propose(rng, list(pending.values()))
+                    backlog.append(issued)
                     issued += 1
+                place()
                 msg = next_message()
                 if msg is not None and msg[0] == "start":
-                    _, wid, idx = msg
-                    if wid in reaped:             # announced, died and was replaced before the announcement was read
-                        crashed(idx, wid, "unknown")
+                    _, wid, idx = msg             # wid = (process, thread)
+                    if wid[0] in reaped:          # announced, died and was replaced before the announcement was read
+                        crashed(idx, wid[0], "unknown")
                     else:
                         running[wid] = idx
-                    idle_polls = 0
                     continue
                 if msg is not None:
                     _, wid, idx, params, out = msg
                     if running.get(wid) == idx:
                         del running[wid]
+                    if wid[0] in assigned:
+                        assigned[wid[0]].discard(idx)
                     finish(idx, params, out)
-                    idle_polls = 0
                     continue
                 # Nothing arrived for poll_seconds.  A worker that died hard (HIP abort, GPU fault, OOM kill) never
-                # reports: the trial it announced is recorded as failed with fitness 0 (what the reference does for an
-                # out-of-memory trial, RecSysExp.py:290-291) and a fresh child process takes its place.
+                # reports: every trial one of its threads had announced is recorded as failed with fitness 0 (what the
+                # reference does for an out-of-memory trial, RecSysExp.py:290-291), the trials it held without announcing
+                # them go back to the backlog, and a fresh child process takes its place.
                 for wid, w in list(workers.items()):
                     if w.is_alive():
                         continue
                     del workers[wid]
                     reaped.add(wid)
-                    if wid in running:
-                        crashed(running.pop(wid), wid, w.exitcode)
+                    announced = set()
+                    for key in [k for k in running if k[0] == wid]:
+                        announced.add(running[key])
+                        crashed(running.pop(key), wid, w.exitcode)
+                    backlog.extend(sorted(i for i in assigned.pop(wid) if i not in announced and i in pending))
+                    queues.pop(wid)
                     if len(reaped) > self.max_respawns:
                         raise RuntimeError("TrialParallelTuner: %d worker processes died; giving up" % len(reaped))
                     spawn()
-                # safety net: a trial nobody announced and nobody holds (its worker died between taking the task and
-                # announcing it) is issued again; a duplicate result is ignored by finish()
-                orphans = [i for i in pending if i not in running.values()]
-                idle_polls = idle_polls + 1 if (orphans and tasks.empty()) else 0
-                if idle_polls >= 3:
-                    for i in orphans:
-                        tasks.put((i, pending[i]))
-                    idle_polls = 0
         finally:
-            for _ in workers:
-                tasks.put(None)
+            for wid in workers:
+                for _ in range(self.engines):
+                    queues[wid].put(None)
             for w in workers.values():
                 w.join(timeout=30)
                 if w.is_alive():
                     w.terminate()
         elapsed = time.time() - t_start
         with open(os.path.join(self.logsdir, "results.txt"), "a") as f:
-            f.write("Experiment ran for {:.1f} s with {} workers on devices {}\n".format(elapsed, self.n_workers, self.devices))
+            f.write("Experiment ran for {:.1f} s with {} workers x {} engines on devices {}\n".format(elapsed, self.n_workers, self.engines, self.devices))
             f.write("Best {} score: {}. Best result found at: {}\n".format(self.metric, self.best_res, self.best_params))
         if self.best_params is not None:
             with open(os.path.join(self.logsdir, "best_params.txt"), "w") as f:

@@ -169,6 +169,14 @@ int ganmf_set_seen_csr(ganmf_handle* h, const int64_t* indptr, const int32_t* in
 int ganmf_recommend(ganmf_handle* h, const int32_t* ids, int64_t n, int transposed, int32_t cutoff, int remove_seen,
                     int32_t* out_items, float* out_scores);
 
+/* The MF contract's two masking rules for everything scored afterwards -- ganmf_scores, ganmf_recommend, ganmf_evaluate
+ * (Base/BaseMatrixFactorizationRecommender.py:113-119: `items_to_compute` given -> every OTHER item scores -inf; :128-143: a user
+ * without a training interaction ("cold") scores -inf for ALL items; the reference's GANMF._compute_item_score, GANMF.py:285-292,
+ * accepts items_to_compute and ignores it).  items == NULL / n_items == 0: no item restriction.  mask_cold_rows != 0: rows that are
+ * empty in the matrix of ganmf_set_seen_csr (URM_train, evaluation orientation) are cold; it must be set when the scoring call is
+ * made.  The filter stays until it is set again. */
+int ganmf_set_score_filter(ganmf_handle* h, const int32_t* items, int64_t n_items, int mask_cold_rows);
+
 /* Replaces save_current_model / load_model (GANMF.py:249-255, Utils_.py:292-294): device-side
  * copies of all trainable tensors to / from their `best` twins. */
 int ganmf_snapshot_best(ganmf_handle* h);
@@ -186,6 +194,11 @@ typedef struct ganmf_prof_entry {
   double bytes;   /* algorithmic HBM bytes */
 } ganmf_prof_entry;
 int ganmf_profile_enable(ganmf_handle* h, int on);
+/* Device time of a region of calls (bench.py's timed K steps; SURVEY 8(d): hipEvent timing): stop = 0 records a start event on
+ * the handle's stream, stop = 1 records the stop event, waits for it and returns the milliseconds between the two -- the time the
+ * stream spent on everything enqueued in between, host gaps between blocking calls included, launch latency of the first call
+ * excluded.  Nothing in the reference corresponds to it (GANMF.py:172-203 times nothing). */
+int ganmf_stream_timer(ganmf_handle* h, int stop, double* ms);
 int ganmf_profile_read(ganmf_handle* h, ganmf_prof_entry* out, int32_t cap, int32_t* n_out);
 
 /* Hold-out evaluation on the device (replaces the per-user metric loop of

@@ -264,12 +264,55 @@ def trial_logs():
               open(os.path.join(OUT, "trial_logs_ml1m.json"), "w"), indent=0)
 
 
+def mf_contract_golden():
+    """MF-contract corners of _compute_item_score / recommend (Base/BaseMatrixFactorizationRecommender.py:113-119,
+    128-143): items_to_compute -> every other item scores -inf; users without a training interaction ("cold") score -inf
+    everywhere.  Expected outputs come from the reference's own class on seeded random factors; the fixture holds inputs and
+    outputs only."""
+    sys.path.insert(0, REF)
+    from Base.BaseMatrixFactorizationRecommender import BaseMatrixFactorizationRecommender
+    rng = np.random.RandomState(20251004)
+    n_users, n_items, k = 61, 83, 7
+    dense = (rng.rand(n_users, n_items) < 0.12).astype(np.float32)
+    cold = np.array([3, 17, 40])
+    dense[cold] = 0.0
+    dense[np.setdiff1d(np.arange(n_users), cold), rng.randint(0, n_items, n_users - len(cold))] = 1.0      # everybody else is warm
+    urm = sps.csr_matrix(dense)
+    U = rng.randn(n_users, k).astype(np.float32)
+    V = rng.randn(n_items, k).astype(np.float32)
+
+    class RefMF(BaseMatrixFactorizationRecommender):
+        RECOMMENDER_NAME = "mf_contract"
+
+    rec = RefMF(urm)
+    rec.USER_factors, rec.ITEM_factors = U, V
+    users = np.array([0, 3, 5, 17, 18, 40, 41, 60], dtype=np.int64)
+    items = np.sort(rng.choice(n_items, 29, replace=False)).astype(np.int64)
+    out = {"users": users, "items_to_compute": items, "cold_users": cold, "U": U, "V": V,
+           "urm_indptr": urm.indptr.astype(np.int64), "urm_indices": urm.indices.astype(np.int32), "urm_shape": np.array(urm.shape)}
+    out["scores_all"] = rec._compute_item_score(users)
+    out["scores_subset"] = rec._compute_item_score(users, items_to_compute=items)
+    for name, kw in (("rank_all_seen", dict(remove_seen_flag=True)), ("rank_subset_seen", dict(remove_seen_flag=True, items_to_compute=items)),
+                     ("rank_subset_unseen", dict(remove_seen_flag=False, items_to_compute=items))):
+        lists = rec.recommend(users, cutoff=10, **kw)
+        pad = np.full((len(users), 10), -1, dtype=np.int32)
+        for i, l in enumerate(lists):
+            pad[i, :len(l)] = l
+        out[name] = pad
+    np.savez_compressed(os.path.join(OUT, "mf_contract.npz"), **out)
+    print("MF contract fixture: %d users (%d cold), %d of %d items to compute" % (len(users), len(cold), len(items), n_items))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     BR, EH = _import_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == "mf_contract":      # one fixture only
+        mf_contract_golden()
+        raise SystemExit(0)
     kat1(BR, EH)
     bundle_golden()
     evaluator_golden(BR, EH)
     tiny_trajectories()
     statistical_fixture()
     trial_logs()
+    mf_contract_golden()

@@ -68,6 +68,9 @@ class RecordingEngine(object):
     def set_seen(self, urm):
         self.seen = urm.shape
 
+    def set_score_filter(self, items_to_compute=None, mask_cold=False):
+        self.score_filter = (None if items_to_compute is None else list(items_to_compute), bool(mask_cold))
+
     def snapshot_best(self):
         self.best = {k: v.copy() for k, v in self.t.items()}
 

@@ -226,3 +226,79 @@ def test_device_metrics_reject_bad_input():
     out = eng.evaluate(np.arange(4), [5], disc, ideal, remove_seen=False)
     assert out.shape == (1, 9) and np.all(np.isfinite(out))
     eng.close()
+
+
+@pytest.mark.parametrize("mode", ["user", "item"])
+def test_mf_contract_items_to_compute_and_cold_users(mode, golden_dir):
+    """Base/BaseMatrixFactorizationRecommender.py:113-119,128-143 through the HIP path: the expected scores and rankings were
+    produced by the reference's own class (oracle/make_golden.py::mf_contract_golden).  Item mode scores the same evaluation
+    matrix from the transposed model (generator rows = items)."""
+    from ganmf_amd.GANMF import GANMF
+    g = np.load(os.path.join(golden_dir, "mf_contract.npz"))
+    n_users, n_items = (int(x) for x in g["urm_shape"])
+    urm = sps.csr_matrix((np.ones(len(g["urm_indices"]), np.float32), g["urm_indices"], g["urm_indptr"]), shape=(n_users, n_items))
+    k = g["U"].shape[1]
+    model = GANMF(urm, mode=mode, is_experiment=True)
+    model._build(k, 16, 32)
+    # the evaluation-orientation factors of the fixture: in item mode the generator's "users" are the catalogue items
+    model.engine.set_tensor(100, g["U"] if mode == "user" else g["V"])
+    model.engine.set_tensor(101, g["V"] if mode == "user" else g["U"])
+    model.URM_train = model._URM_eval
+    users, items = g["users"], g["items_to_compute"]
+
+    def same(got, want):
+        assert np.array_equal(np.isneginf(got), np.isneginf(want))
+        fin = np.isfinite(want)
+        assert np.abs(got[fin] - want[fin]).max() <= 2e-6 * np.abs(want[fin]).max()
+
+    same(model._compute_item_score(users), g["scores_all"])                                   # cold users: -inf everywhere
+    same(model._compute_item_score(users, items_to_compute=items), g["scores_subset"])        # other items: -inf
+    assert np.all(np.isneginf(model._compute_item_score(g["cold_users"])))
+    pad = lambda lists: np.array([l + [-1] * (10 - len(l)) for l in lists], dtype=np.int32)
+    # device top-k route (scores never leave the GPU) and the host route (return_scores) agree with the reference's lists
+    assert np.array_equal(pad(model.recommend(users, cutoff=10, remove_seen_flag=True)), g["rank_all_seen"])
+    assert np.array_equal(pad(model.recommend(users, cutoff=10, remove_seen_flag=True, items_to_compute=items)), g["rank_subset_seen"])
+    assert np.array_equal(pad(model.recommend(users, cutoff=10, remove_seen_flag=False, items_to_compute=items)), g["rank_subset_unseen"])
+    host_lists, _ = model.recommend(users, cutoff=10, remove_seen_flag=True, items_to_compute=items, return_scores=True)
+    assert np.array_equal(pad(host_lists), g["rank_subset_seen"])
+    # the filter does not leak into later calls
+    same(model._compute_item_score(users), g["scores_all"])
+    # engine-level errors: an item beyond the score width, cold masking without the seen matrix
+    from ganmf_amd import _lib as L
+    with pytest.raises(L.GanmfError):
+        model.engine.set_score_filter([10 ** 6], mask_cold=True)
+
+
+def test_concurrent_engines_bit_identical(golden_dir):
+    """Two fits in two threads of one process (two engines, two HIP streams: the tuner's engines_per_worker) leave exactly the
+    tensors and losses each leaves when it runs alone -- GANMF and DisGANMF side by side."""
+    import threading
+    from GANRec.DisGANMF import DisGANMF
+    from GANRec.GANMF import GANMF
+    urm = sps.load_npz(os.path.join(golden_dir, "tiny_urm.npz")).tocsr()
+
+    def fit(kind, out, key):
+        if kind == "ganmf":
+            m = GANMF(urm, mode="user", seed=3, is_experiment=True)
+            m.schedule_rng = np.random.RandomState(11)
+            m.fit(num_factors=9, emb_dim=24, epochs=6, batch_size=16, d_lr=1e-3, g_lr=1e-3, d_reg=1e-4, m=3, recon_coefficient=0.05)
+        else:
+            m = DisGANMF(urm, mode="item", seed=4, is_experiment=True)
+            m.schedule_rng = np.random.RandomState(12)
+            m.fit(num_factors=7, d_nodes=20, d_layers=2, d_hidden_act="tanh", epochs=6, batch_size=16, d_lr=1e-3, g_lr=1e-3)
+        out[key] = (m.user_factors().copy(), m.item_factors().copy(), list(m.train_d_loss), list(m.train_g_loss))
+        m.engine.close()
+
+    solo, both = {}, {}
+    for kind in ("ganmf", "dis"):
+        fit(kind, solo, kind)
+    for _ in range(3):      # several rounds: an interleaving-dependent result would not survive them
+        threads = [threading.Thread(target=fit, args=(kind, both, kind)) for kind in ("ganmf", "dis")]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        for kind in ("ganmf", "dis"):
+            for a, b in zip(solo[kind][:2], both[kind][:2]):
+                assert np.array_equal(a, b), kind
+            assert solo[kind][2] == both[kind][2] and solo[kind][3] == both[kind][3], kind

@@ -117,3 +117,26 @@ def test_search_survives_hard_worker_death(tmp_path, monkeypatch):
         assert (f == 0.0) == (x["num_factors"] % 5 == 0 or x["num_factors"] == 13), (x, f)
     assert open(os.path.join(logs, "results.txt")).read().count("died (exit code 134)") == len(crashed)
     assert best < 0
+
+
+@pytest.mark.parametrize("crashing", [False, True])
+def test_trial_threads_inside_one_worker(tmp_path, monkeypatch, crashing):
+    """engines_per_worker: one worker process, three trial threads (each announces as (worker, thread)).  The search finishes
+    with the same bookkeeping; a hard death of the process fails every trial its threads had announced, and a fresh process
+    takes over."""
+    monkeypatch.setenv("PYTHONPATH", HERE + os.pathsep + os.path.dirname(HERE) + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    sys.path.insert(0, HERE)
+    from helpers_tune import CrashingGAN, StubGAN
+    from ganmf_amd.evaluation import EvaluatorHoldoutFast
+    train, early, val = _data(3)
+    t = tune.TrialParallelTuner(CrashingGAN if crashing else StubGAN, train, early, val, str(tmp_path / "thr"), seed=13,
+                                method="random", n_workers=1, devices=[0], evaluator_class=EvaluatorHoldoutFast,
+                                engines_per_worker=3)
+    t.poll_seconds = 0.2
+    t.max_respawns = 64
+    best, params = t.tune(evals=12, verbose=False)
+    assert len(t.func_vals) == 12 and best == min(t.func_vals)
+    if crashing:
+        assert any(v == 0.0 for v in t.func_vals) and best < 0      # some trials died with their process, the rest scored
+    text = open(os.path.join(str(tmp_path / "thr"), "results.txt")).read()
+    assert "1 workers x 3 engines" in text

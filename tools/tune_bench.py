@@ -1,5 +1,5 @@
 """Trial-parallel search on ML-1M (the regime the paper ran: 50 trials x <= 300 epochs took 2 h 18 m on its GPU,
-SURVEY §6).  Usage: python tools/tune_bench.py [evals] [workers]"""
+SURVEY §6).  Usage: python tools/tune_bench.py [evals] [worker processes] [trial threads per process]"""
 import os
 import sys
 import tempfile
@@ -25,10 +25,11 @@ def main():
     small, early, val = mk(r < 0.8), mk((r >= 0.8) & (r < 0.9)), mk(r >= 0.9)
     evals = int(sys.argv[1]) if len(sys.argv) > 1 else 8
     workers = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+    engines = int(sys.argv[3]) if len(sys.argv) > 3 else 1
     t0 = time.time()
-    t = tune.TrialParallelTuner(GANMF, small, early, val, tempfile.mkdtemp(), seed=1337, n_workers=workers)
+    t = tune.TrialParallelTuner(GANMF, small, early, val, tempfile.mkdtemp(), seed=1337, n_workers=workers, engines_per_worker=engines)
     best, params = t.tune(evals=evals)
-    print("%d trials, %d workers on %d device(s): %.1f s wall; best MAP@5 %.4f at %s" % (evals, workers, len(t.devices), time.time() - t0, -best, params))
+    print("%d trials, %d workers x %d engines on %d device(s): %.1f s wall; best MAP@5 %.4f at %s" % (evals, workers, engines, len(t.devices), time.time() - t0, -best, params))
 
 
 if __name__ == "__main__":      # worker processes are spawned: they re-import this module
