@@ -339,8 +339,12 @@ inline hipError_t gemm_bf16p_launch(hipStream_t st, const unsigned* a_planes, in
   if (q.tiles_m * BF16P_TILE > a_rows_pad || q.tiles_n * BF16P_TILE > b_rows_pad || kp2 % (BF16P_BK / 2)) return hipErrorInvalidValue;
   const PersistPlan pp = persist_plan(M, N, 2 * kp2, BF16P_TILE, GEMM_CUS);
   q.xb_m = pp.xb_m; q.xb_n = pp.xb_n; q.wgs_per_xcd = pp.grid / 8;
+#ifdef GANMF_PERSIST_DIAG_BUILD      // experiment switches (make DIAG=1): the 4-wave form and the per-wave phase order were measured and not kept
   static const int waves = [] { const char* e = getenv("GANMF_BF16P_WAVES"); return e ? atoi(e) : 8; }();
   static const int late_mask = [] { const char* e = getenv("GANMF_BF16P_LATE"); return e ? (int)strtol(e, nullptr, 0) : 0; }();
+#else
+  constexpr int waves = 8, late_mask = 0;
+#endif
   q.late_mask = late_mask;
 #ifdef GANMF_PERSIST_DIAG_BUILD
   static unsigned long long* dbg = nullptr;

@@ -215,6 +215,12 @@ class Engine:
         L.check(self.lib.ganmf_bench_scores(self.h, n, int(transposed), iters, C.byref(ms)), "ganmf_bench_scores")
         return ms.value
 
+    def comm_info(self):
+        """(ranks in the communicator as RCCL reports them, this handle's rank); (0, -1) without a communicator"""
+        w, r = C.c_int32(0), C.c_int32(-1)
+        L.check(self.lib.ganmf_comm_info(self.h, C.byref(w), C.byref(r)), "ganmf_comm_info")
+        return int(w.value), int(r.value)
+
     def comm_init_local(self, group_id):
         """join the in-process loopback communicator `group_id` (all world_size engines of this process must)"""
         L.check(self.lib.ganmf_comm_init_local(self.h, int(group_id)), "ganmf_comm_init_local")

@@ -95,6 +95,9 @@ int ganmf_destroy(ganmf_handle* h);
  * ganmf_comm_unique_id, the host broadcasts the 128 bytes, every rank calls ganmf_comm_init. */
 int ganmf_comm_unique_id(uint8_t out128[128]);
 int ganmf_comm_init(ganmf_handle* h, const uint8_t id128[128]);
+/* What the communicator itself reports (bench.py's `parallelism` object): ranks in the RCCL communicator (ncclCommCount) and this
+ * handle's rank in it (ncclCommUserRank); the loopback communicator reports its group.  0 / -1 without a communicator. */
+int ganmf_comm_info(ganmf_handle* h, int32_t* world_size, int32_t* rank);
 /* In-process alternative to the RCCL communicator: the world_size handles that call this with the same group_id
  * (same process, same device, one host thread each) all-reduce among themselves by rendezvous; sums run in rank
  * order.  For exercising the data-parallel path with world_size > 1 on one GPU (tests/test_gpu_dist_local.py). */

@@ -65,3 +65,25 @@ def test_launcher_fails_and_ends_the_peers_when_a_rank_dies(tmp_path):
         b.launch_ranks(2, [], script=str(script))
     assert ex.value.code == 1
     assert time.time() - t0 < 60
+
+
+def test_parallelism_object_shape():
+    """bench.py --gpus N > 1 adds a `parallelism` object built from the library's profile classes: per replicated tensor the
+    collective time and the exposed (join-wait) time per step, what RCCL reports as its world size, rows/s."""
+    b = _bench()
+
+    class Eng(object):
+        def comm_info(self):
+            return 8, 0
+    prof = [{"name": "collective_We (reduce-scatter + all-gather)", "ms": 9.6, "launches": 96, "flops": 0, "bytes": 1},
+            {"name": "collective_Wd (reduce-scatter + all-gather)", "ms": 4.8, "launches": 96, "flops": 0, "bytes": 1},
+            {"name": "collective_V (reduce-scatter + all-gather)", "ms": 0.96, "launches": 96, "flops": 0, "bytes": 1},
+            {"name": "join_wait_We (main lane)", "ms": 0.48, "launches": 48, "flops": 0, "bytes": 0},
+            {"name": "adam_dense_D", "ms": 1.92, "launches": 96, "flops": 0, "bytes": 1}]
+    p = b.parallelism_object(Eng(), prof, 8, 96, 1.0e6)
+    assert p["rccl_world_size"] == 8 and p["launcher_world_size"] == 8 and p["rows_per_s"] == 1.0e6
+    assert set(p["per_tensor"]) == {"We", "Wd", "V"}
+    assert p["per_tensor"]["We"] == {"collective_us_per_step": 100.0, "exposed_us_per_step": 5.0}
+    assert p["per_tensor"]["Wd"]["exposed_us_per_step"] == 0.0
+    assert p["collective_us_per_step"] == 160.0 and p["exposed_collective_us_per_step"] == 5.0 and p["adam_slice_us_per_step"] == 20.0
+    json.dumps(p)

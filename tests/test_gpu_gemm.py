@@ -68,8 +68,7 @@ def test_gemm_deterministic():
 
 @pytest.mark.parametrize("shape", [(128, 128, 32), (1, 1, 1), (700, 900, 250), (1300, 1500, 70), (3000, 260, 33),
                                    (129, 4100, 250), (5000, 131, 8)])
-@pytest.mark.parametrize("waves", ["1", "2", "3"])  # GANMF_PERSIST: 1 = two 4-wave workgroups per CU (default), 2 / 3 = one 4- / 8-wave workgroup
-def test_gemm_persistent_tile_walk(shape, waves, monkeypatch):
+def test_gemm_persistent_tile_walk(shape, monkeypatch):
     """gemm_persist.hpp (one workgroup per CU walks a list of output tiles, stores deferred under the next tile's
     K loop) against fp64 and, bit for bit, against the one-tile-per-workgroup kernel: same K order, same MFMA chain."""
     from ganmf_amd.engine import gemm_f32
@@ -77,11 +76,11 @@ def test_gemm_persistent_tile_walk(shape, waves, monkeypatch):
     rng = np.random.RandomState(M + 3 * N + 7 * K)
     A, B, ref, bound = _mk(rng, M, N, K, False, False)
     monkeypatch.setenv("GANMF_MFMA", "f32")
-    monkeypatch.setenv("GANMF_PERSIST", waves)
+    monkeypatch.setenv("GANMF_TUNE", "persist=1")      # two 4-wave workgroups per CU (the one-workgroup forms are experiment builds)
     out, _ = gemm_f32(A, B, False, False, tile=128)
     err = np.abs(out - ref)
     assert np.all(err <= 4e-7 * bound * np.sqrt(K) + 1e-30), float((err / (bound + 1e-30)).max())
-    monkeypatch.setenv("GANMF_PERSIST", "0")
+    monkeypatch.setenv("GANMF_TUNE", "persist=0")
     plain, _ = gemm_f32(A, B, False, False, tile=128)
     np.testing.assert_array_equal(out, plain)
 
@@ -92,7 +91,7 @@ def test_gemm_persistent_tile_walk(shape, waves, monkeypatch):
 @pytest.mark.parametrize("shape,nsplit", [((256, 992, 3707), 4), ((128, 250, 3706), 0), ((65, 70, 130), 1), ((1, 1, 1), 1),
                                            ((200, 3706, 96), 1), ((130, 129, 64), 1)])
 def test_gemm_k_groups(akm, bkm, kg, ring, shape, nsplit, monkeypatch):
-    """64 x 64 fp32 ring kernel with KG groups of four waves per workgroup (GANMF_KG; the groups split the 8-wide chunks of
+    """64 x 64 fp32 ring kernel with KG groups of four waves per workgroup (GANMF_TUNE kg=; the groups split the 8-wide chunks of
     every K-tile and their partial tiles meet through LDS in the epilogue): every layout, both ring depths, ragged edges,
     K shorter than one K-tile, split-K on top.  Same error bound as the one-group kernel, and run-to-run identical."""
     from ganmf_amd.engine import gemm_f32
@@ -100,8 +99,7 @@ def test_gemm_k_groups(akm, bkm, kg, ring, shape, nsplit, monkeypatch):
     rng = np.random.RandomState(M + 3 * N + 7 * K)
     A, B, ref, bound = _mk(rng, M, N, K, akm, bkm)
     monkeypatch.setenv("GANMF_MFMA", "f32")
-    monkeypatch.setenv("GANMF_KG", kg)
-    monkeypatch.setenv("GANMF_RING", ring)
+    monkeypatch.setenv("GANMF_TUNE", "kg=%s,ring=%s" % (kg, ring))
     out, _ = gemm_f32(A, B, akm, bkm, tile=64, nsplit=nsplit)
     err = np.abs(out - ref)
     assert np.all(err <= 4e-7 * bound * np.sqrt(K) + 1e-30), float((err / (bound + 1e-30)).max())
@@ -113,7 +111,7 @@ def test_gemm_k_groups(akm, bkm, kg, ring, shape, nsplit, monkeypatch):
 @pytest.mark.parametrize("tile", [64, 128])
 @pytest.mark.parametrize("shape", [(1, 1, 1), (700, 900, 250), (129, 4100, 40), (5000, 131, 8), (1300, 1500, 70), (64 * 9, 64 * 7, 3000)])
 def test_gemm_blocked_tile_order(mfma, tile, shape, monkeypatch):
-    """GANMF_TILE_ORDER=2 forces the XCD-blocked block -> tile map (gemm_f32.hpp tile_coords: eight rectangles of the tile
+    """GANMF_TUNE tile_order=2 forces the XCD-blocked block -> tile map (gemm_f32.hpp tile_coords: eight rectangles of the tile
     grid, banded, M-innermost) on every unsplit product; the map must be a bijection for ragged tile grids (fewer than 8 tiles,
     rectangles of unequal size, bands taller than a rectangle), so the result equals the list-order launch bit for bit."""
     from ganmf_amd.engine import gemm_f32
@@ -121,10 +119,9 @@ def test_gemm_blocked_tile_order(mfma, tile, shape, monkeypatch):
     rng = np.random.RandomState(M + 3 * N + 7 * K)
     A, B, ref, bound = _mk(rng, M, N, K, False, False)
     monkeypatch.setenv("GANMF_MFMA", mfma)
-    monkeypatch.setenv("GANMF_PERSIST", "0")
-    monkeypatch.setenv("GANMF_TILE_ORDER", "0")
+    monkeypatch.setenv("GANMF_TUNE", "persist=0,tile_order=0")
     plain, _ = gemm_f32(A, B, False, False, tile=tile, nsplit=1)
-    monkeypatch.setenv("GANMF_TILE_ORDER", "2")
+    monkeypatch.setenv("GANMF_TUNE", "persist=0,tile_order=2")
     out, _ = gemm_f32(A, B, False, False, tile=tile, nsplit=1)
     np.testing.assert_array_equal(out, plain)
     err = np.abs(out - ref)
@@ -162,8 +159,7 @@ def test_gemm_split_bf16_k_groups(akm, bkm, shape, nsplit, monkeypatch):
     rng = np.random.RandomState(M + 3 * N + 7 * K)
     A, B, ref, bound = _mk(rng, M, N, K, akm, bkm)
     monkeypatch.setenv("GANMF_MFMA", "f32")
-    monkeypatch.setenv("GANMF_KG", "4")
-    monkeypatch.setenv("GANMF_RING", "3")
+    monkeypatch.setenv("GANMF_TUNE", "kg=4,ring=3")
     monkeypatch.setenv("GANMF_X3KG", "3")
     out, _ = gemm_f32(A, B, akm, bkm, tile=64, nsplit=nsplit)
     err = np.abs(out - ref)

@@ -235,3 +235,40 @@ def test_ganmf_f16_step_vs_oracle():
         print("   GANMF f16 first moment %-3s error %.2e of its scale" % (n, err))
         assert err <= 1e-2, (n, err)
     eng.close()
+
+
+def test_forced_f32_plans_stay_f32(monkeypatch, capfd):
+    """A handle created with mfma="f32" (GANMF_FLAG_MFMA_F32) runs the fp32 MFMA EVERYWHERE: the 16-wave split-bf16 kernel
+    (GANMF_X3KG, default on) must not take over its plans, neither the stand-alone products nor the GEMM halves of the combined
+    launches.  GANMF_DEBUG_PLAN prints the arithmetic actually launched; the results equal a forced-fp32 handle with the
+    16-wave kernel switched off, bit for bit -- and differ from the default arithmetic."""
+    from ganmf_amd.engine import Engine
+    from ganmf_amd.synthetic import glorot_params, synthetic_urm
+    U, N, k, e, B = 300, 3706, 250, 992, 128
+    hp = dict(d_lr=1e-4, g_lr=2e-4, d_reg=1e-4, g_reg=0.0, m=10.0, recon_coefficient=0.05)
+    urm = synthetic_urm(U, N, 0.04, seed=3)
+    w = glorot_params(U, N, k, e, seed=4)
+    ids = {"We": 0, "be": 1, "Wd": 2, "bd": 3, "U": 100, "V": 101}
+    perm = np.random.RandomState(1).permutation(U)
+
+    def run(mfma, x3kg):
+        monkeypatch.setenv("GANMF_DEBUG_PLAN", "1")
+        monkeypatch.setenv("GANMF_X3KG", x3kg)
+        eng = Engine(U, N, k, e, B, mfma=mfma, **hp)
+        eng.set_urm(urm)
+        for n, tid in ids.items():
+            eng.set_tensor(tid, w[n])
+        eng.train_epoch(perm, 1, 1)
+        out = {n: eng.get_tensor(tid).copy() for n, tid in ids.items()}
+        eng.close()
+        plans = [l for l in capfd.readouterr().err.splitlines() if l.startswith("[ganmf plan]")]
+        return out, plans
+
+    forced, plans = run("f32", "7")
+    assert plans and all("mfma f32" in l for l in plans), [l for l in plans if "mfma f32" not in l]
+    ring_only, _ = run("f32", "0")
+    for n in ids:
+        np.testing.assert_array_equal(forced[n], ring_only[n])
+    auto, plans_auto = run(None, "7")
+    assert any("mfma bf16x3" in l for l in plans_auto)
+    assert any(not np.array_equal(forced[n], auto[n]) for n in ids)

@@ -3,7 +3,7 @@
 A combined launch runs the bodies of the ordinary kernels as block ranges of one grid (generator GEMM + CSR row expansion;
 gUb + gV with the update of V written to a second buffer; the slab sum of dE inside the gWd launch; d_coef inside the dE
 launch; gWd + gWe as block ranges of one grid; the gUb slabs summed by adam_rows_kernel), so it must reproduce the separate launches BIT FOR BIT: same arithmetic, same summation order.  GANMF_MULTI
-/ GANMF_DEFER_GUB are read when a handle is created."""
+(bits 0-4 the combined launches, bit 5 = 32 the gUb slabs summed by adam_rows_kernel) is read when a handle is created."""
 import numpy as np
 import pytest
 
@@ -17,8 +17,7 @@ IDS = {"We": 0, "be": 1, "Wd": 2, "bd": 3, "U": 100, "V": 101}
 def _run(monkeypatch, multi, defer, U, N, k, e, B, hp, epochs, d_steps=1, g_steps=1):
     from ganmf_amd import _lib as L
     from ganmf_amd.engine import Engine
-    monkeypatch.setenv("GANMF_MULTI", str(multi))
-    monkeypatch.setenv("GANMF_DEFER_GUB", str(defer))
+    monkeypatch.setenv("GANMF_MULTI", str(multi + 32 * defer + 64))
     urm = synthetic_urm(U, N, 0.04, seed=21)
     w = glorot_params(U, N, k, e, seed=9)
     eng = Engine(U, N, k, e, B, **hp)
@@ -53,7 +52,7 @@ def test_combined_launches_bit_identical(shape, g_reg, monkeypatch):
             np.testing.assert_array_equal(dl, dr, err_msg="D losses, GANMF_MULTI=%d" % multi)
             np.testing.assert_array_equal(gl, gr, err_msg="G losses, GANMF_MULTI=%d" % multi)
         for n in ref:
-            np.testing.assert_array_equal(got[n], ref[n], err_msg="%s, GANMF_MULTI=%d GANMF_DEFER_GUB=%d" % (n, multi, defer))
+            np.testing.assert_array_equal(got[n], ref[n], err_msg="%s, GANMF_MULTI=%d" % (n, multi + 32 * defer + 64))
 
 
 def test_second_item_buffer_survives_snapshot_and_restore(monkeypatch):

@@ -220,17 +220,22 @@ def test_snapshot_restore_and_errors():
     eng.close()
 
 
-@pytest.mark.parametrize("shape", ["small", "c2"])
+@pytest.mark.parametrize("shape,lane_fence", [("small", None), ("c2", "0"), ("c2", "1")])
 @pytest.mark.parametrize("force_collectives", [False, True])
-def test_rccl_path_single_rank_matches_plain(monkeypatch, force_collectives, shape):
+def test_rccl_path_single_rank_matches_plain(monkeypatch, force_collectives, shape, lane_fence):
     """The data-parallel code path (RCCL all-reduce of the hinge sums, reduce-scatter of the D gradients and of gV, Adam on
     the rank's slice, all-gather of the parameters, presummed d_coef, per-epoch loss all-reduce) with a 1-rank communicator
     must reproduce the plain single-GPU path bit for bit.  force_collectives: GANMF_FORCE_COLLECTIVES=1 makes the one-rank
     communicator ISSUE its in-place ncclReduceScatter / ncclAllGather calls (they are skipped at world_size 1 otherwise),
     so the RCCL call sites of ganmf_hip.hip reduce_scatter() / all_gather() execute on this one-GPU box.  shape "c2": the
     BASELINE configs[1] shape, where the data-parallel step takes the combined launches (de_dcoef_kernel, gWd + slab sum of
-    dE, gUb + gV)."""
+    dE, gUb + gV).  lane_fence: GANMF_LANE_EVENT_FENCE -- the lane events with (1: what world_size > 1 runs with) and without (0)
+    the system-scope fence."""
     from ganmf_amd.engine import Engine, comm_unique_id
+    if lane_fence is None:
+        monkeypatch.delenv("GANMF_LANE_EVENT_FENCE", raising=False)
+    else:
+        monkeypatch.setenv("GANMF_LANE_EVENT_FENCE", lane_fence)
     if force_collectives:
         monkeypatch.setenv("GANMF_FORCE_COLLECTIVES", "1")
     else:

@@ -34,6 +34,9 @@ EXPECT = {
 }
 
 
+CONCURRENCY = 3
+
+
 def _in_band(got, logged):
     return abs(got - logged) <= max(0.01, 0.15 * logged)
 
@@ -43,7 +46,9 @@ def test_logged_trials_replay(experiment):
     import replay_trials as R
     rho_min, band_min, never_max, mean_tol = EXPECT[experiment]
     logs, splits = R.load_fixture()
-    rows = R.replay(experiment, range(50), seed=1337, logs=logs, splits=splits, verbose=False)
+    # three trials at a time in threads of this process (own engine, own stream and own RandomState(seed) each): every trial
+    # computes exactly what it computes alone (test_concurrent_engines_bit_identical), the 50 take ~30 % less wall time
+    rows = R.replay(experiment, range(50), seed=1337, logs=logs, splits=splits, verbose=False, concurrency=CONCURRENCY)
     logged = np.array([r["logged_map"] for r in rows])
     got = np.array([r["map"] for r in rows])
     rho = R.spearman(logged, got)
@@ -67,8 +72,11 @@ def test_logged_trials_replay(experiment):
         assert abs(got[deep].mean() - logged[deep].mean()) <= max(0.01, 0.2 * logged[deep].mean())
     # second chances: a trial outside the band is re-run with two other seeds; few may stay outside
     never = 0
-    for i in np.where(~ok)[0]:
-        again = [R.replay(experiment, [int(i)], seed=s, logs=logs, splits=splits, verbose=False)[0]["map"] for s in (1, 2)]
+    out = [int(i) for i in np.where(~ok)[0]]
+    second = {s: {r["trial"]: r["map"] for r in R.replay(experiment, out, seed=s, logs=logs, splits=splits, verbose=False,
+                                                         concurrency=CONCURRENCY)} for s in (1, 2)} if out else {}
+    for i in out:
+        again = [second[s][i] for s in (1, 2)]
         lo, hi = min(again + [got[i]]), max(again + [got[i]])
         band = max(0.01, 0.15 * logged[i])
         if not (lo - band <= logged[i] <= hi + band):

@@ -42,7 +42,7 @@ IDS = {"U": 100, "V": 101, "Wo": 2, "bo": 3, "W0": 0, "b0": 1}
 
 
 def make(fuse):
-    os.environ["GANMF_DIS_FUSE_HIDDEN"] = fuse
+    os.environ["GANMF_MULTI"] = str(63 + 64 * int(fuse))      # bit 6: hidden layers' Adam fused
     eng = Engine(U, N, k, e, B, model=L.MODEL_DISGANMF, d_layers=1, d_act="linear", m=0.0, **hp)
     eng.set_urm(urm)
     for n, tid in IDS.items():

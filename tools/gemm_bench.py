@@ -39,4 +39,4 @@ if __name__ == "__main__":
             for ns in splits:
                 ms, tf = run(layout, M, N, K, tile, ns)
                 print("%s %5dx%5dx%5d tile=%3d nsplit=%2d ring=%s : %8.2f us  %6.1f TF/s (%4.1f%%)" % (
-                    layout, M, N, K, tile, ns, os.environ.get("GANMF_RING", "auto"), ms * 1e3, tf, 100 * tf / PEAK), flush=True)
+                    layout, M, N, K, tile, ns, os.environ.get("GANMF_TUNE", "auto"), ms * 1e3, tf, 100 * tf / PEAK), flush=True)

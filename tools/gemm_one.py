@@ -1,5 +1,5 @@
 """One GEMM through ganmf_gemm_f32 for profiling: python tools/gemm_one.py LAYOUT M N K [tile] [nsplit] [iters]
-(kernel variant / arithmetic from the environment: GANMF_MFMA, GANMF_PERSIST, GANMF_RING)."""
+(kernel variant / arithmetic from the environment: GANMF_MFMA, GANMF_TUNE=persist=..,ring=..)."""
 import os
 import sys
 

@@ -24,10 +24,9 @@ def run(M, N, K, env, iters=30):
 
 if __name__ == "__main__":
     for (M, N, K) in [(6040, 3706, 250), (4096, 4096, 4096), (25000, 50000 // 8, 250)]:
-        for name, env in [("f32 one-tile", {"GANMF_MFMA": "f32", "GANMF_PERSIST": "0"}),
-                          ("f32 persistent 2x4w", {"GANMF_MFMA": "f32", "GANMF_PERSIST": "1"}),
-                          ("f32 persistent 8w", {"GANMF_MFMA": "f32", "GANMF_PERSIST": "3"}),
-                          ("bf16x3 one-tile", {"GANMF_MFMA": "bf16x3", "GANMF_PERSIST": "0"})]:
+        for name, env in [("f32 one-tile", {"GANMF_MFMA": "f32", "GANMF_TUNE": "persist=0"}),
+                          ("f32 persistent 2x4w", {"GANMF_MFMA": "f32", "GANMF_TUNE": "persist=1"}),
+                          ("bf16x3 one-tile", {"GANMF_MFMA": "bf16x3", "GANMF_TUNE": "persist=0"})]:
             ms = run(M, N, K, env)
             tf = 2.0 * M * N * K / ms / 1e9
             print("%6d x %6d x %5d  %-18s %8.1f us  %6.1f TF/s  %.3f of 157.3" % (M, N, K, name, ms * 1e3, tf, tf / 157.3), flush=True)
