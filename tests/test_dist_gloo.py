@@ -71,7 +71,7 @@ def _worker(rank, world, port, out, sliced=False):
                 g[n] = t.numpy() + hp["d_reg"] * loc.p[n]
                 loc.opt_d.apply_dense(n, loc.p[n], g[n])
                 continue
-            # the library's form (ganmf_hip.hip dp_update): the summed gradient is only needed on the owner of each slice
+            # the library's form (csrc/lib/dataparallel.inc dp_update): the summed gradient is only needed on the owner of each slice
             # (reduce-scatter; gloo has none, an all-reduce of which the rank keeps its slice stands in), TF-Adam on that
             # slice of the flattened, zero-padded parameter with moments that exist on the owner alone, then an
             # all-gather of the parameter slices
@@ -92,7 +92,7 @@ def _worker(rank, world, port, out, sliced=False):
         full.d_step(union, X[union])
     for n in loc.D_NAMES:
         np.testing.assert_allclose(loc.p[n], full.p[n], rtol=1e-9, atol=1e-12)
-    # ---- the generator pass over the SAME slices (GANMF.py:191-203; ganmf_hip.hip g_step / gen_update): every rank forms
+    # ---- the generator pass over the SAME slices (GANMF.py:191-203; csrc/lib/step_ganmf.inc g_step / gen_update): every rank forms
     # dF for its own rows with the GLOBAL batch size in both scales; gV is summed over ranks (all-reduce, or reduce-scatter
     # -> Adam on the rank's slice of V -> all-gather); the rows of U belong to their rank and are never communicated -- the
     # all-rows TF update (App. B.5: non-batch rows decay their moments and still move) runs on the local rows only.

@@ -227,7 +227,7 @@ def test_rccl_path_single_rank_matches_plain(monkeypatch, force_collectives, sha
     the rank's slice, all-gather of the parameters, presummed d_coef, per-epoch loss all-reduce) with a 1-rank communicator
     must reproduce the plain single-GPU path bit for bit.  force_collectives: GANMF_FORCE_COLLECTIVES=1 makes the one-rank
     communicator ISSUE its in-place ncclReduceScatter / ncclAllGather calls (they are skipped at world_size 1 otherwise),
-    so the RCCL call sites of ganmf_hip.hip reduce_scatter() / all_gather() execute on this one-GPU box.  shape "c2": the
+    so the RCCL call sites of csrc/lib/dataparallel.inc reduce_scatter() / all_gather() execute on this one-GPU box.  shape "c2": the
     BASELINE configs[1] shape, where the data-parallel step takes the combined launches (de_dcoef_kernel, gWd + slab sum of
     dE, gUb + gV).  lane_fence: GANMF_LANE_EVENT_FENCE -- the lane events with (1: what world_size > 1 runs with) and without (0)
     the system-scope fence."""
