@@ -506,6 +506,65 @@ __global__ __launch_bounds__(256) void dis_head_kernel(const float* __restrict__
   }
 }
 
+// The head inside the slab sum of the last hidden layer (round 4): when that layer's forward GEMM is split along K, its reduce launch
+// is this kernel -- one workgroup per ROW sums the row's slabs (same order as splitk_reduce_body), applies the activation epilogue,
+// stores the layer output, and forms the row's logit [a | 1] . wo_ext, cross-entropy and dlogit on the way: dis_head_kernel's launch
+// (5-6 us at the launch floor, twice per D + G pair) disappears.  Rows outside [row0, row0 + nrows) only get their layer output
+// (generator step: the real half is needed for feature matching, not for the loss).
+struct HeadP {
+  const float* wo;       // [e + 1] output kernel then output bias
+  int row0, nrows, n_real;
+  float inv_b;
+  float* dlogit;
+  float* loss_real;      // may be nullptr (generator step)
+  float* loss_fake;
+};
+__global__ __launch_bounds__(256) void reduce_rows_head_kernel(const RedP p, const HeadP hd) {
+  __shared__ float red[4];
+  const int r = blockIdx.x;
+  const int n4 = (p.N + 3) >> 2;
+  const EpiD& e = p.epi;
+  const float* __restrict__ part = p.part;
+  float* __restrict__ out = p.out;
+  float dot = 0.f, sq = 0.f;
+  for (int c4 = threadIdx.x; c4 < n4; c4 += 256) {
+    const int c = 4 * c4;
+    const size_t off = (size_t)r * p.ld + c;
+    float4 s = *reinterpret_cast<const float4*>(part + off);
+#pragma unroll 8
+    for (int k = 1; k < p.nsplit; ++k) {
+      const float4 q = *reinterpret_cast<const float4*>(part + (size_t)k * p.split_stride + off);
+      s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
+    }
+    float o[4] = {s.x, s.y, s.z, s.w};
+    if (c + 3 < p.N) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = epi_apply(e, o[j], r, c + j, p.ld, nullptr, sq);
+      *reinterpret_cast<float4*>(out + off) = make_float4(o[0], o[1], o[2], o[3]);
+      const float4 w = *reinterpret_cast<const float4*>(hd.wo + c);
+      dot += o[0] * w.x; dot += o[1] * w.y; dot += o[2] * w.z; dot += o[3] * w.w;
+    } else {
+      for (int j = 0; j < 4 && c + j < p.N; ++j) {
+        const float v = epi_apply(e, o[j], r, c + j, p.ld, nullptr, sq);
+        out[off + j] = v;
+        dot += v * hd.wo[c + j];
+      }
+    }
+  }
+  if (r < hd.row0 || r >= hd.row0 + hd.nrows) return;      // (uniform per workgroup)
+  dot = wave_sum(dot);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dot;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float sl = ((red[0] + red[1]) + (red[2] + red[3])) + hd.wo[p.N];      // + the ones column's weight (the output bias)
+    const float z = r < hd.n_real ? 1.f : 0.f;
+    const float l = fmaxf(sl, 0.f) - sl * z + log1pf(expf(-fabsf(sl)));          // tf.nn.sigmoid_cross_entropy_with_logits
+    if (r < hd.n_real) { if (hd.loss_real) hd.loss_real[r] = l; }
+    else hd.loss_fake[r - hd.n_real] = l;
+    hd.dlogit[r] = (1.f / (1.f + expf(-sl)) - z) * hd.inv_b;
+  }
+}
+
 // Top of the backward pass, rows [row0, row0+nrows), columns [0, e1):
 //   dh = dlogit[r] * wo[j] + fmc * (feat[r, j] - feat[r - pair_off, j])      (fmc != 0: G-step)
 //   dz[r, j] = dh * act'(feat[r, j])                 (columns < e only)
