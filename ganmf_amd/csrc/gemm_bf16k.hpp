@@ -165,6 +165,12 @@ __device__ __forceinline__ void bf16k_mainloop(const GemmP& p, const int tm, con
     const f32x4k v[2] = {rg[s][0], rg[s][1]};
     const int tok = bf16k_wait_vm(nwait, v[0], v[1]);
     u32x4 pc[3];
+#ifdef GANMF_PERSIST_DIAG_BUILD
+    if ((p.diag & 32) && stage_a) {      // timing only: the A-staging waves store unsplit bits (what pre-split activation planes would save)
+      pc[0] = __builtin_bit_cast(u32x4, v[0]); pc[1] = __builtin_bit_cast(u32x4, v[1]); pc[2] = pc[0];
+      pc[0][0] += (unsigned)tok;
+    } else
+#endif
     it.template split<NPIECE, F16>(v, pc, it.km != (tok != 0), my_scale);
     unsigned* o = my_planes + b * BF16K_OPER;
 #pragma unroll
