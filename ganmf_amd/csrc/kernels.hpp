@@ -518,39 +518,72 @@ struct HeadP {
   float* dlogit;
   float* loss_real;      // may be nullptr (generator step)
   float* loss_fake;
+  // generator step (pair_off > 0): the workgroup of generated row r also forms the top of the backward pass for its row --
+  // dz = (dlogit . wo + fmc (a_f - a_r)) act'(a_f) and the feature-matching partial sum (a_f - a_r)^2 -> fm_partials[r - pair_off],
+  // with a_r = the output of the paired real row r - pair_off -- which is row-local once the row's logit exists: dis_dz_top_kernel's
+  // launch disappears from the generator step too.  (The discriminator step's top also sums feat^T . dlogit over ALL rows for the
+  // output layer's gradient: it keeps its kernel.)
+  int pair_off;
+  float fmc;
+  int act;
+  float* dz;             // [.., ld] top-of-backward output (generated rows)
+  float* fm_partials;
 };
-__global__ __launch_bounds__(256) void reduce_rows_head_kernel(const RedP p, const HeadP hd) {
-  __shared__ float red[4];
-  const int r = blockIdx.x;
+
+// one row's slab sum + epilogue; returns the row's partial dot with wo over this thread's columns
+__device__ __forceinline__ float reduce_row_dot(const RedP& p, const float* __restrict__ wo, int r) {
   const int n4 = (p.N + 3) >> 2;
   const EpiD& e = p.epi;
-  const float* __restrict__ part = p.part;
-  float* __restrict__ out = p.out;
   float dot = 0.f, sq = 0.f;
   for (int c4 = threadIdx.x; c4 < n4; c4 += 256) {
     const int c = 4 * c4;
     const size_t off = (size_t)r * p.ld + c;
-    float4 s = *reinterpret_cast<const float4*>(part + off);
+    float4 s = *reinterpret_cast<const float4*>(p.part + off);
 #pragma unroll 8
     for (int k = 1; k < p.nsplit; ++k) {
-      const float4 q = *reinterpret_cast<const float4*>(part + (size_t)k * p.split_stride + off);
+      const float4 q = *reinterpret_cast<const float4*>(p.part + (size_t)k * p.split_stride + off);
       s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
     }
     float o[4] = {s.x, s.y, s.z, s.w};
     if (c + 3 < p.N) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) o[j] = epi_apply(e, o[j], r, c + j, p.ld, nullptr, sq);
-      *reinterpret_cast<float4*>(out + off) = make_float4(o[0], o[1], o[2], o[3]);
-      const float4 w = *reinterpret_cast<const float4*>(hd.wo + c);
+      *reinterpret_cast<float4*>(p.out + off) = make_float4(o[0], o[1], o[2], o[3]);
+      const float4 w = *reinterpret_cast<const float4*>(wo + c);
       dot += o[0] * w.x; dot += o[1] * w.y; dot += o[2] * w.z; dot += o[3] * w.w;
     } else {
       for (int j = 0; j < 4 && c + j < p.N; ++j) {
         const float v = epi_apply(e, o[j], r, c + j, p.ld, nullptr, sq);
-        out[off + j] = v;
-        dot += v * hd.wo[c + j];
+        p.out[off + j] = v;
+        dot += v * wo[c + j];
       }
     }
   }
+  return dot;
+}
+
+// the finished values of four columns of row r (slab sum + epilogue), nothing stored
+__device__ __forceinline__ float4 reduce_row_quad(const RedP& p, int r, int c) {
+  const size_t off = (size_t)r * p.ld + c;
+  float4 s = *reinterpret_cast<const float4*>(p.part + off);
+#pragma unroll 8
+  for (int k = 1; k < p.nsplit; ++k) {
+    const float4 q = *reinterpret_cast<const float4*>(p.part + (size_t)k * p.split_stride + off);
+    s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
+  }
+  float sq = 0.f;
+  s.x = epi_apply(p.epi, s.x, r, c, p.ld, nullptr, sq);
+  s.y = c + 1 < p.N ? epi_apply(p.epi, s.y, r, c + 1, p.ld, nullptr, sq) : 0.f;
+  s.z = c + 2 < p.N ? epi_apply(p.epi, s.z, r, c + 2, p.ld, nullptr, sq) : 0.f;
+  s.w = c + 3 < p.N ? epi_apply(p.epi, s.w, r, c + 3, p.ld, nullptr, sq) : 0.f;
+  return s;
+}
+
+// grid = the M rows of the layer output, one workgroup each
+__global__ __launch_bounds__(256) void reduce_rows_head_kernel(const RedP p, const HeadP hd) {
+  __shared__ float red[8];
+  const int r = (int)blockIdx.x;
+  float dot = reduce_row_dot(p, hd.wo, r);
   if (r < hd.row0 || r >= hd.row0 + hd.nrows) return;      // (uniform per workgroup)
   dot = wave_sum(dot);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dot;
@@ -561,8 +594,36 @@ __global__ __launch_bounds__(256) void reduce_rows_head_kernel(const RedP p, con
     const float l = fmaxf(sl, 0.f) - sl * z + log1pf(expf(-fabsf(sl)));          // tf.nn.sigmoid_cross_entropy_with_logits
     if (r < hd.n_real) { if (hd.loss_real) hd.loss_real[r] = l; }
     else hd.loss_fake[r - hd.n_real] = l;
-    hd.dlogit[r] = (1.f / (1.f + expf(-sl)) - z) * hd.inv_b;
+    const float dl = (1.f / (1.f + expf(-sl)) - z) * hd.inv_b;
+    hd.dlogit[r] = dl;
+    red[4] = dl;
   }
+  if (hd.pair_off <= 0) return;
+  // generator step: the top of the backward pass for this (generated) row.  Its paired real row's output belongs to ANOTHER
+  // workgroup of this launch: its values are formed again here from the slabs (the same sums, the same epilogue: the same bits),
+  // four more slab loads per float4 instead of a dependency between workgroups.
+  __syncthreads();      // red[4]; and this workgroup's stores of its own row are behind its barrier
+  const float dl = red[4];
+  float fm = 0.f;
+  for (int c = 4 * threadIdx.x; c < p.N; c += 4 * 256) {
+    const float4 ar = reduce_row_quad(p, r - hd.pair_off, c);
+    const float4 af = reduce_row_quad(p, r, c);
+    const float a_f[4] = {af.x, af.y, af.z, af.w}, a_r[4] = {ar.x, ar.y, ar.z, ar.w};
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float d = a_f[j] - a_r[j];
+      if (c + j < p.N) fm += d * d;
+      o[j] = c + j < p.N ? (dl * hd.wo[c + j] + hd.fmc * d) * act_grad_out(hd.act, a_f[j]) : 0.f;
+    }
+    if (c + 3 < p.N) *reinterpret_cast<float4*>(hd.dz + (size_t)r * p.ld + c) = make_float4(o[0], o[1], o[2], o[3]);
+    else for (int j = 0; j < 4 && c + j < p.N; ++j) hd.dz[(size_t)r * p.ld + c + j] = o[j];
+  }
+  fm = wave_sum(fm);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = fm;
+  __syncthreads();
+  if (threadIdx.x == 0) hd.fm_partials[r - hd.pair_off] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 // Top of the backward pass, rows [row0, row0+nrows), columns [0, e1):

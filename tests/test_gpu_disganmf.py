@@ -118,3 +118,38 @@ def test_disganmf_golden_trajectory_and_class(golden_dir):
     _close(model._compute_item_score(ids), ref, 2e-4, "scores")
     assert [r.name for r in model.params['D']][:2] == ['discriminator/layer_0/kernel', 'discriminator/layer_0/bias']
     assert model.sess.run(model.params['D'][0]).shape == (urm.shape[1] + 1, c["e"])
+
+
+@pytest.mark.parametrize("layers,act", [(1, "linear"), (2, "tanh")])
+def test_head_inside_the_slab_sum_launch_matches_the_separate_head(layers, act, monkeypatch):
+    """configs[4]-sized DisGANMF: the last hidden layer's forward GEMM is split along K, so its slab sum runs as
+    reduce_rows_head_kernel (logit, cross-entropy and dlogit of a row formed by the workgroup that sums the row).  Against the
+    separate dis_head_kernel (GANMF_TUNE=dis_head_fuse=0): the layer outputs are the same numbers, only the order of the 1 025
+    products of a row's logit differs -- every tensor and loss after an epoch agrees to fp32 rounding, and both agree with the
+    fp64 oracle as test_disganmf_epochs demands."""
+    U, N, k, e, B = 520, 3706, 250, 1024, 128
+    rng = np.random.RandomState(17)
+    urm = _rand_urm(rng, U, N, 0.04)
+    hp = dict(d_lr=1e-4, g_lr=5e-4, d_reg=3e-5, g_reg=0.0, recon_coefficient=0.5)
+    o = DisGANMFOracle(U, N, k, d_layers=layers, d_nodes=e, d_hidden_act=act, dtype=np.float64, seed=5, **hp)
+    o.p["W0"][0, :] *= 1.0 / U
+    perm = rng.permutation(U)
+    outs = {}
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("GANMF_TUNE", "dis_head_fuse=" + fuse)
+        eng = _engine(o, urm, B, hp, layers, e, act)
+        dl, gl = eng.train_epoch(perm, 1, 1)
+        outs[fuse] = ({n: eng.get_tensor(tid).copy() for n, tid in _ids(layers).items()}, np.array(dl), np.array(gl))
+        eng.close()
+    # both forms against the fp64 oracle at the per-epoch bound of this file; against each other within twice that (TF-Adam turns the
+    # last bit of a logit into a visible change of a bias that has barely left zero: b1 differs by 8e-5 of its own 4e-4 scale)
+    dl_ref, gl_ref = o.train_epoch(urm, perm, B)
+    for fuse in ("1", "0"):
+        for n in outs[fuse][0]:
+            _close(outs[fuse][0][n], o.p[n], 1e-4, "head fused=%s vs fp64 oracle: %s" % (fuse, n))
+        np.testing.assert_allclose(outs[fuse][1], dl_ref, rtol=2e-4)
+        np.testing.assert_allclose(outs[fuse][2], gl_ref, rtol=2e-4)
+    for n in outs["1"][0]:
+        _close(outs["1"][0][n], outs["0"][0][n], 2e-4, "fused vs separate head: " + n)
+    np.testing.assert_allclose(outs["1"][1], outs["0"][1], rtol=2e-5)
+    np.testing.assert_allclose(outs["1"][2], outs["0"][2], rtol=2e-5)
