@@ -183,14 +183,30 @@ def extra_workload(w, e, world, rank, local_rank, steps, warmup, sync, torch, di
     headline (REPEATS event-timed repeats of `steps` steps, MAX over ranks, median)."""
     from ganmf_amd.engine import Engine, comm_unique_id
     from ganmf_amd.synthetic import glorot_params, synthetic_urm
-    urm = synthetic_urm(w["U"], w["N"], w["density"], seed=4242 + rank)
-    params = glorot_params(w["U"], w["N"], w["k"], e, seed=4242)
-    if rank:
-        params["U"] = glorot_params(w["U"], 8, w["k"], 8, seed=4242 + rank)["U"]
-    eng = Engine(w["U"], w["N"], w["k"], e, w["B"], device=local_rank, world_size=world, rank=rank, row_offset=rank * w["U"], **w["hp"])
-    eng.set_urm(urm)
-    for name, tid in (("We", 0), ("be", 1), ("Wd", 2), ("bd", 3), ("U", 100), ("V", 101)):
-        eng.set_tensor(tid, params[name])
+    # Phase 1 -- everything that can fail on ONE rank alone (host memory, device memory, bad shapes) -- ends with an agreement over
+    # gloo: either every rank goes on to the collectives or none does (a rank that skipped ahead would leave its peers inside an
+    # RCCL call for ever, and the headline line of this run with them).
+    eng, err = None, None
+    try:
+        urm = synthetic_urm(w["U"], w["N"], w["density"], seed=4242 + rank)
+        params = glorot_params(w["U"], w["N"], w["k"], e, seed=4242)
+        if rank:
+            params["U"] = glorot_params(w["U"], 8, w["k"], 8, seed=4242 + rank)["U"]
+        eng = Engine(w["U"], w["N"], w["k"], e, w["B"], device=local_rank, world_size=world, rank=rank, row_offset=rank * w["U"], **w["hp"])
+        eng.set_urm(urm)
+        for name, tid in (("We", 0), ("be", 1), ("Wd", 2), ("bd", 3), ("U", 100), ("V", 101)):
+            eng.set_tensor(tid, params[name])
+    except BaseException as ex:      # (MemoryError included)
+        err = "%s: %s" % (type(ex).__name__, ex)
+    ok = 0 if err else 1
+    if world > 1:
+        t = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        ok = int(t.item())
+    if not ok:
+        if eng is not None:
+            eng.close()
+        raise RuntimeError(err or "another rank could not set this workload up")
     ids = [comm_unique_id() if rank == 0 else None]
     if world > 1:
         dist.broadcast_object_list(ids, src=0)
