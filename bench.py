@@ -25,6 +25,13 @@ replicated tensors are reduce-scattered over RCCL every step (Adam on the rank's
 all-gathered: DESIGN.md section 6); `value` counts the 128-row minibatch
 updates all ranks processed per second (= N x synchronous global steps/s).
 
+Protocol: W untimed warm-up steps, then the K-step region FIVE times; every repeat is exactly K steps between a
+barrier + synchronize on both sides and is timed by hipEvents on the library's own stream (ganmf_stream_timer) and by the host's
+wall clock.  `value` = N * K / the MEDIAN event time (MAX over ranks per repeat); `timing` carries all five samples, their spread,
+the wall-clock median and the per-call overhead.  With --gpus N > 1 (or GANMF_BENCH_FORCE_COMM=1 on one GPU) the line also carries
+`parallelism` (per replicated tensor: collective time and exposed join-wait time per step; RCCL's own world size; rows/s) and
+`configs3_sharded` (BASELINE.json configs[3]: one 25 000 x 50 000 shard per rank at emb_dim 32 and 1024, same protocol).
+
 Extra objects on the JSON line: `roofline` (dominant kernel of the step = the 16-wave split-bf16 GEMM of gemm_bf16k.hpp -- fp32 in, fp32-accurate, priced
 against the fp32 MFMA peak -- on its largest class; `roofline_fused_adam` = the HBM-bound launch of the two fused-Adam weight-gradient GEMMs; HIP-event timed on the
 library's stream in a profiled repeat of the same steps (at least 96) right after the timed region — events
