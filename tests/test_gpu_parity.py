@@ -267,3 +267,39 @@ def test_rccl_path_single_rank_matches_plain(monkeypatch, force_collectives, sha
     assert len(dl2) == steps + 1 and np.isfinite(dl2).all() and np.isfinite(gl2).all()
     np.testing.assert_allclose(dp.adam_powers()[0], before[0] * 0.9 ** (steps + 1), rtol=1e-5)
     plain.close(); dp.close()
+
+
+def test_stream_timer_and_comm_info():
+    """ganmf_stream_timer (bench.py's clock) and ganmf_comm_info (its `parallelism` object): the timer brackets what is enqueued
+    between its two calls on the library's stream; comm_info reports (0, -1) without a communicator, RCCL's own (1, 0) for a
+    one-rank communicator and the loopback group's size."""
+    import time
+    from ganmf_amd.engine import Engine, comm_unique_id
+    rng = np.random.RandomState(3)
+    U, N, k, e, B = 400, 600, 16, 40, 64
+    urm = _rand_urm(rng, U, N, 0.05)
+    eng = Engine(U, N, k, e, B, **HP)
+    eng.set_urm(urm)
+    assert eng.comm_info() == (0, -1)
+    perm = rng.permutation(U)
+    eng.train_epoch(perm, 1, 1)
+    eng.timer_start()
+    empty = eng.timer_stop()
+    eng.timer_start()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        eng.train_epoch(perm, 1, 1)
+    ms = eng.timer_stop()
+    wall = (time.perf_counter() - t0) * 1e3
+    assert 0.0 <= empty < 0.5 and ms > 5 * empty and 0.2 * wall < ms <= wall + 0.5, (empty, ms, wall)
+    eng.close()
+    dp = Engine(U, N, k, e, B, world_size=1, rank=0, **HP)
+    dp.comm_init(comm_unique_id())
+    assert dp.comm_info() == (1, 0)
+    dp.close()
+    a = Engine(U, N, k, e, B, world_size=2, rank=0, **HP)
+    b = Engine(U, N, k, e, B, world_size=2, rank=1, **HP)
+    a.comm_init_local(4242)
+    b.comm_init_local(4242)
+    assert a.comm_info() == (2, 0) and b.comm_info() == (2, 1)
+    a.close(); b.close()
