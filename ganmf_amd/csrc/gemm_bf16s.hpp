@@ -329,8 +329,13 @@ inline hipError_t gemm_bf16s_launch(hipStream_t st, const GemmP& p, bool akm, bo
 template <int NPIECE, bool F16>
 inline hipError_t gemm_bf16k_launch(hipStream_t st, const GemmP& p, bool akm, bool bkm);      // gemm_bf16k.hpp: the 16-wave form
 
+inline hipError_t gemm_planes_launch(hipStream_t st, const GemmP& p, bool bkm);      // gemm_planes.hpp: the same plan on pre-split operands
+
 inline hipError_t gemm_dispatch_staged(hipStream_t st, const GemmP& p, bool akm, bool bkm, const GemmPlan& pl) {
   if (pl.tile == 64 && pl.kg == 4) {
+#ifdef GANMF_PERSIST_DIAG_BUILD      // experiment (profiles/r04_wgrad_stream.md): measured level with the in-loop split, not used by the step
+    if (pl.mode == MFMA_BF16X3 && p.a_planes && p.b_planes && !akm && !p.a_gather) return gemm_planes_launch(st, p, bkm);
+#endif
     if (pl.mode == MFMA_BF16X3) return gemm_bf16k_launch<3, false>(st, p, akm, bkm);
     if (pl.mode == MFMA_F16) return gemm_bf16k_launch<1, true>(st, p, akm, bkm);
     if (pl.mode == MFMA_BF16) return gemm_bf16k_launch<1, false>(st, p, akm, bkm);

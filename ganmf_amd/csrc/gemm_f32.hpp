@@ -324,6 +324,12 @@ struct GemmP {
   int xb_m, xb_n, xb_band;
   int diag;                     // diagnostic builds only (make DIAG=1): timing experiments of the staged kernel's K loop
   unsigned long long* stamps;   // diagnostic builds only: four s_memrealtime stamps per workgroup (entry, first K-tile landed, K loop done, exit)
+  // Operands split ahead of the launch (gemm_planes.hpp): the three bf16 pieces of A / B as row-major matrices of the fp32 operand's
+  // geometry (same lda / ldb, in elements), piece q at base + q * stride.  Both set (and A K-contiguous, no a_gather): the 16-wave
+  // split-bf16 plan runs its DMA form -- no split in the K loop, bit-identical results.  nullptr: the fp32 operand is split in the loop.
+  const unsigned short* a_planes;
+  const unsigned short* b_planes;
+  long long a_pstride, b_pstride;
   int n_fastest;                // list order with the tile COLUMN fastest (default: tile row fastest).  For the fused-Adam weight-gradient
                                 // products: workgroups that run at the same time then update neighbouring 256-byte segments of the same
                                 // parameter rows, i.e. whole DRAM pages of theta / m / v instead of one segment per 4-15 KiB row

@@ -22,6 +22,9 @@
 #pragma once
 #include "gemm_bf16s.hpp"
 #include "gemm_bf16k.hpp"
+#ifdef GANMF_PERSIST_DIAG_BUILD
+#include "gemm_planes.hpp"      // experiment: the 16-wave plan on pre-split operand planes
+#endif
 #include "gemm_f32.hpp"
 #include "kernels.hpp"
 
