@@ -137,7 +137,8 @@ __device__ __forceinline__ void bf16k_mainloop(const GemmP& p, const int tm, con
   for (int r = 0; r < 16; ++r) { acc[r] = 0.f; accl[r] = 0.f; }
 
   SplitItemK it;
-  if (stage_a) it.init(AKM, p.A + (size_t)bz * p.a_batch_stride, p.lda, m0, p.M, kbeg, p.zero_page, tid, AKM ? nullptr : p.a_gather);
+  if (stage_a) it.init(AKM, p.A + (size_t)bz * p.a_batch_stride, p.lda, m0, p.M, kbeg, p.zero_page, tid,
+                       (AKM || !p.a_gather) ? nullptr : p.a_gather + (size_t)bz * p.a_gather_batch);
   else it.init(BKM, p.B, p.ldb, n0, p.N, kbeg, p.zero_page, tid - 512);
   unsigned* const my_planes = buf + (stage_a ? 0 : 3 * FA::PLANE) + it.dst;      // this thread's 16 bytes of piece 0, buffer 0
   const float my_scale = stage_a ? sa : sb;

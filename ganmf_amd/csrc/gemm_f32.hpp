@@ -316,6 +316,7 @@ struct GemmP {
   int c_pad_writable;           // columns N .. ldc-1 of C hold nothing the caller needs (gemm_persist.hpp writes zeros there)
   const int* a_gather;          // K-contiguous A only: row r of A is A + a_gather[r] * lda (embedding lookup folded into the
                                 // operand fetch, GANMF.py:82); nullptr: row r is A + r * lda
+  int a_gather_batch;           // batch bz reads its row list at a_gather + bz * a_gather_batch (one product per minibatch of a staged pass)
   float a_scale, b_scale;       // MFMA_F16: powers of two applied to the operands at conversion (0 = 1); acc *= 1 / (a_scale * b_scale)
   // Blocked tile order of the one-tile-per-workgroup kernels (0 = tm-fastest list order).  Plain products with many more
   // tiles than CUs (the scoring GEMM): the tile grid is cut into xb_m x xb_n = 8 rectangles, one per XCD, and a rectangle
@@ -780,7 +781,8 @@ __device__ __forceinline__ void gemm_f32_body(const GemmP& p, const int bid, con
 
   SA la;
   SB lb;
-  la.init(p.A + (size_t)bz * p.a_batch_stride, p.lda, m0, p.M, kbeg, p.zero_page, tid, AKM ? nullptr : p.a_gather);
+  la.init(p.A + (size_t)bz * p.a_batch_stride, p.lda, m0, p.M, kbeg, p.zero_page, tid,
+          (AKM || !p.a_gather) ? nullptr : p.a_gather + (size_t)bz * p.a_gather_batch);
   lb.init(p.B, p.ldb, n0, p.N, kbeg, p.zero_page, tid);
 
   constexpr int NC = BK / 8 / KG;   // 8-wide k chunks per tile and K group (even: local chunk c uses fragment set c & 1)

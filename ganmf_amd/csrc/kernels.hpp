@@ -16,7 +16,8 @@ enum Scal : int {
   S_ALPHA_D_ALT = 6,                                   // lr_t of odd discriminator steps (data-parallel: step i's encoder update still
                                                        // reads its lr_t on the side lane while step i+1 opens on the main lane)
   S_SUM_REAL = 8, S_SUM_FAKE = 9, S_SUM_FM = 10,        // sum of squares (local, then all-reduced)
-  S_COUNT = 16
+  S_COUNT = 16,
+  S_TAB = 16                                           // from here: lr_t of every discriminator step of a staged pass (open_steps_kernel), one slot per step
 };
 
 
@@ -57,13 +58,16 @@ struct DensP {
   float lr;
   int uid_col, row_offset;
   int nseg;                      // > 1 (stand-alone launch on wide rows): nseg workgroups per row, one column segment each
+  int stage_b;                   // > 0: the rows of a whole pass (stage_pass): list row b belongs to minibatch b / stage_b and lands in that
+                                 // minibatch's [real ; generated] block of 2 * stage_b rows; no embedding copy, no optimizer step opened
 };
 
 // (block b of the row expansion, any block size: also runs as extra workgroups of the generator GEMM's launch, gemm_multi.hpp)
 __device__ __forceinline__ void densify_row_body(const DensP& d, const int bid) {
   const int nseg = d.nseg > 1 ? d.nseg : 1;
   const int b = bid / nseg, seg = bid % nseg;
-  if (bid == 0 && threadIdx.x == 0) {
+  const bool staged = d.stage_b > 0;
+  if (!staged && bid == 0 && threadIdx.x == 0) {
     const int o = d.which ? S_B1P_G : S_B1P_D;
     const float b1p = d.scal[o], b2p = d.scal[o + 1];
     d.scal[d.alpha_idx] = d.lr * sqrtf(1.f - b2p) / (1.f - b1p);
@@ -71,13 +75,15 @@ __device__ __forceinline__ void densify_row_body(const DensP& d, const int bid) 
     d.scal[o + 1] = b2p * ADAM_B2;
   }
   const int r = d.rows[b];
+  const size_t xrow = staged ? (size_t)b + (size_t)(b / d.stage_b) * d.stage_b : (size_t)b;      // row of X that receives list row b
+  const size_t frow = staged ? xrow + d.stage_b : (size_t)d.nb + b;                                // ... and its generated twin
   // this workgroup's columns [c0, c1) of the row (a multiple of four floats; the whole padded row when nseg == 1)
   const int segw = ((d.ldx / 4 + nseg - 1) / nseg) * 4;
   const int c0 = seg * segw, c1 = min(d.ldx, c0 + segw);
-  float* x = d.X + (size_t)b * d.ldx;
+  float* x = d.X + xrow * d.ldx;
   float4* xr = reinterpret_cast<float4*>(x + c0);
   for (int c = threadIdx.x; c < (c1 - c0) / 4; c += blockDim.x) xr[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (seg == 0) {
+  if (seg == 0 && d.Ub) {
     const float4* us = reinterpret_cast<const float4*>(d.Uemb + (size_t)r * d.ldk);
     float4* ud = reinterpret_cast<float4*>(d.Ub + (size_t)b * d.ldk);
     for (int c = threadIdx.x; c < d.ldk / 4; c += blockDim.x) ud[c] = us[c];
@@ -90,10 +96,10 @@ __device__ __forceinline__ void densify_row_body(const DensP& d, const int bid) 
   }
   if (threadIdx.x == 0) {
     if (d.ncols >= c0 && d.ncols < c1) x[d.ncols] = 1.0f;
-    if (seg == 0) d.X[(size_t)(d.nb + b) * d.ldx + d.ncols] = 1.0f;
+    if (seg == 0) d.X[frow * d.ldx + d.ncols] = 1.0f;
     if (d.uid_col >= 0) {   // DisGANMF conditions D on float(uid) (DisGANMF.py:59,110-111)
       if (d.uid_col >= c0 && d.uid_col < c1) x[d.uid_col] = (float)(d.row_offset + r);
-      if (seg == 0) d.X[(size_t)(d.nb + b) * d.ldx + d.uid_col] = (float)(d.row_offset + r);
+      if (seg == 0) d.X[frow * d.ldx + d.uid_col] = (float)(d.row_offset + r);
     }
   }
 }
@@ -229,6 +235,23 @@ __global__ void open_step_kernel(float* __restrict__ scal, int which, int alpha_
     scal[alpha_idx] = lr * sqrtf(1.f - b2p) / (1.f - b1p);
     scal[o] = b1p * ADAM_B1;
     scal[o + 1] = b2p * ADAM_B2;
+  }
+}
+
+// Opens `count` consecutive optimizer steps at once: lr_t of step i -> scal[first_slot + i], the beta powers advanced `count` times
+// -- the same float operations, in the same order, as `count` single openings (staged discriminator pass: no step of it has a
+// row-expansion launch to open it).
+__global__ void open_steps_kernel(float* __restrict__ scal, int which, int first_slot, int count, float lr) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const int o = which ? S_B1P_G : S_B1P_D;
+    float b1p = scal[o], b2p = scal[o + 1];
+    for (int i = 0; i < count; ++i) {
+      scal[first_slot + i] = lr * sqrtf(1.f - b2p) / (1.f - b1p);
+      b1p = b1p * ADAM_B1;
+      b2p = b2p * ADAM_B2;
+    }
+    scal[o] = b1p;
+    scal[o + 1] = b2p;
   }
 }
 

@@ -83,3 +83,60 @@ def test_second_item_buffer_survives_snapshot_and_restore(monkeypatch):
     eng.train_epoch(perm)                        # and the next update starts from it
     assert np.max(np.abs(eng.get_tensor(101) - w["V"])) <= 3 * 2.1 * hp["g_lr"]      # |delta| <= ~lr per Adam step
     eng.close()
+
+
+def _run_staged(monkeypatch, stage, model, U, N, k, e, B, hp, epochs, d_steps):
+    """Epochs (and D passes) with / without the staged discriminator pass (GANMF_TUNE=pass_stage=0|1)."""
+    from ganmf_amd import _lib as L
+    from ganmf_amd.engine import Engine
+    monkeypatch.setenv("GANMF_TUNE", "pass_stage=%d" % stage)
+    urm = synthetic_urm(U, N, 0.04, seed=21)
+    rng = np.random.RandomState(11)
+    if model == "ganmf":
+        ids = dict(IDS)
+        w = glorot_params(U, N, k, e, seed=9)
+        eng = Engine(U, N, k, e, B, **hp)
+    else:
+        layers = 2
+        ids = {"W0": 0, "b0": 1, "W1": 2, "b1": 3, "Wo": 4, "bo": 5, "U": 100, "V": 101}
+        w = {"W0": rng.randn(N + 1, e) * 0.03, "b0": rng.randn(e) * 0.01, "W1": rng.randn(e, e) * 0.05, "b1": rng.randn(e) * 0.01,
+             "Wo": rng.randn(e, 1) * 0.1, "bo": np.zeros(1), "U": rng.randn(U, k) * 0.1, "V": rng.randn(N, k) * 0.1}
+        w["W0"][0, :] *= 1.0 / U      # the float(uid) row
+        w = {n: v.astype(np.float32) for n, v in w.items()}
+        eng = Engine(U, N, k, e, B, model=L.MODEL_DISGANMF, d_layers=layers, d_act="tanh", m=0.0, **hp)
+    eng.set_urm(urm)
+    for n, tid in ids.items():
+        eng.set_tensor(tid, w[n])
+    prng = np.random.RandomState(5)
+    losses = []
+    for _ in range(epochs):
+        dl, gl = eng.train_epoch(prng.permutation(U), d_steps, 1)
+        losses.append((np.array(dl), np.array(gl)))
+    out = {n: eng.get_tensor(tid).copy() for n, tid in ids.items()}
+    out.update({n + ".m": eng.get_tensor(tid, slot=L.SLOT_ADAM_M).copy() for n, tid in ids.items()})
+    out.update({n + ".v": eng.get_tensor(tid, slot=L.SLOT_ADAM_V).copy() for n, tid in ids.items()})
+    out["scores"] = eng.scores(np.arange(min(U, 64)))
+    eng.close()
+    return out, losses
+
+
+@pytest.mark.parametrize("case", [
+    ("ganmf", 1500, 3706, 250, 992, 128, 1),       # the row expansion rides in the generator launch (front_kernel); ragged last minibatch
+    ("ganmf", 700, 1100, 20, 64, 32, 2),           # stand-alone row expansion + generator product; two discriminator passes per call
+    ("disganmf", 900, 1100, 64, 128, 64, 1),       # float(uid) column in the staged rows
+])
+def test_staged_discriminator_pass_is_bit_identical(case, monkeypatch):
+    """stage_pass (lib/step_ganmf.inc): the CSR rows and the generated rows of every full minibatch of a discriminator pass formed once in
+    front of it -- same tiles, same K order, lr_t from open_steps_kernel -- against every step expanding its own rows."""
+    model, U, N, k, e, B, d_steps = case
+    hp = dict(d_lr=1e-4, g_lr=2e-4, d_reg=1e-4, g_reg=1e-3, recon_coefficient=0.05)
+    if model == "ganmf":
+        hp.update(m=10.0)
+    ref, ref_l = _run_staged(monkeypatch, 0, model, U, N, k, e, B, hp, 2, d_steps)
+    got, got_l = _run_staged(monkeypatch, 1, model, U, N, k, e, B, hp, 2, d_steps)
+    for (dl, gl), (dr, gr) in zip(got_l, ref_l):
+        np.testing.assert_array_equal(dl, dr, err_msg="D losses")
+        np.testing.assert_array_equal(gl, gr, err_msg="G losses")
+    assert set(ref) == set(got)
+    for n in ref:
+        np.testing.assert_array_equal(got[n], ref[n], err_msg=str(n))

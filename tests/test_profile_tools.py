@@ -65,6 +65,26 @@ def test_labels_follow_dispatch_order(tmp_path):
     assert out.returncode == 0 and "| D:encode |" in out.stdout and "D+G pair" in out.stdout
 
 
+def test_staged_pass_labels(tmp_path):
+    """A staged discriminator pass (stage_pass): three launches in front of it, then steps WITHOUT a front launch, delimited by their last
+    weight-gradient launch; a ragged last minibatch keeps its own front launch."""
+    from step_classes import COUNTS, label, load
+    p = tmp_path / "trace.csv"
+    head = ["ganmf::densify_rows_kernel(ganmf::DensP)", "void ganmf::gemm_bf16k_mfma<false, false, 3, false>(ganmf::GemmP)",
+            "ganmf::open_steps_kernel(float*, int, int, int, float)"]
+    _write(p, [head, WPAIR_D_STEP[1:], NEW_D_STEP[1:], WPAIR_D_STEP, G_STEP])
+    COUNTS["D"] = COUNTS["G"] = 0
+    lab = [k for k, _ in label(load(str(p)))]
+    assert lab[:3] == ["P:CSR rows of the whole pass", "P:generated rows of the whole pass (batched)", "P:lr_t of the pass's steps"]
+    assert lab[3:9] == ["D:encode", "D:reduce(encode)", "D:decode", "D:dE+d_coef", "D:reduce(dE)", "D:gWd+gWe+adam"]
+    assert lab[9:15] == ["D:encode", "D:reduce(encode)", "D:decode", "D:dE+d_coef", "D:gWd+adam+reduce(dE)", "D:gWe+adam"]
+    assert lab[15:22] == ["D:gen+rows", "D:encode", "D:reduce(encode)", "D:decode", "D:dE+d_coef", "D:reduce(dE)", "D:gWd+gWe+adam"]
+    assert lab[22] == "G:gen+rows" and len(lab) == 3 + 6 + 6 + 7 + 11
+    assert COUNTS == {"D": 3, "G": 1}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "step_classes.py"), str(p)], capture_output=True, text=True)
+    assert out.returncode == 0 and "in front of the pass" in out.stdout, out.stdout + out.stderr
+
+
 def test_traffic_per_class(tmp_path):
     for name, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
         os.makedirs(tmp_path / name / "run")

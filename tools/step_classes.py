@@ -42,20 +42,58 @@ def _gemm_like(n):
     return "gemm_" in n or "front_kernel" in n or "pair_kernel" in n or "de_dcoef_kernel" in n      # ("wgrad_pair_kernel" contains "pair_kernel")
 
 
+COUNTS = {"D": 0, "G": 0}      # complete steps labelled (label())
+
+
 def label(disp):
     """[(class label, dispatch)] for every dispatch that belongs to a complete training step."""
     steps, cur = [], None
-    for d in disp:
+    out_pass = []
+    staged = False          # inside a staged discriminator pass (stage_pass: no front launch per step; open_steps_kernel starts it)
+    after_dcoef = None      # staged pass: GEMM-like launches seen since the step's d_coef launch
+    need = 2
+    expect_pass_gemm = False
+    for i, d in enumerate(disp):
         n = d["name"]
+        if "open_steps_kernel" in n:
+            staged, cur, after_dcoef = True, None, None
+            out_pass.append(("P:lr_t of the pass's steps", d))
+            continue
+        if "densify_rows_kernel" in n and any("open_steps_kernel" in x["name"] for x in disp[i + 1:i + 4]):
+            out_pass.append(("P:CSR rows of the whole pass", d))      # (stage_pass: row expansion, generated rows, then the pass's lr_t table)
+            cur, expect_pass_gemm = None, True
+            continue
+        if expect_pass_gemm and "gemm_" in n:
+            out_pass.append(("P:generated rows of the whole pass (batched)", d))
+            expect_pass_gemm = False
+            continue
         if "densify_rows_kernel" in n or "sparse_front_kernel" in n or "front_kernel" in n:
+            staged = False
             cur = [d]
             steps.append(cur)
+        elif staged:
+            if cur is None:
+                if "persist" in n or "finish_parts" in n or "rocclr" in n or "mask_topk" in n:
+                    staged = False
+                    continue
+                cur = [d]
+                steps.append(cur)
+                after_dcoef = None
+            else:
+                cur.append(d)
+            if "d_coef_kernel" in n or "de_dcoef_kernel" in n:
+                after_dcoef = 0
+                need = 2 if "de_dcoef_kernel" in n else 3
+            elif after_dcoef is not None and _gemm_like(n):
+                after_dcoef += 2 if "wgrad_pair_kernel" in n else 1
+                if after_dcoef >= need:
+                    cur, after_dcoef = None, None      # the step's last launch
         elif cur is not None:
             if "persist" in n or "mask_topk" in n or "gather_rows" in n or "finish_parts" in n or "rocclr" in n:
                 cur = None      # scoring / epoch end: not part of a step
             else:
                 cur.append(d)
-    out = []
+    out = list(out_pass)
     for d in disp:      # the scoring GEMM of the bench (ganmf_bench_scores): its own classes, outside the steps
         n = d["name"]
         if "gemm_f32_persist" in n:
@@ -71,10 +109,13 @@ def label(disp):
         paired = any("pair_kernel" in d["name"] and "wgrad" not in d["name"] for d in st)
         wpaired = any("wgrad_pair_kernel" in d["name"] for d in st)
         names = list(D_GEMMS if is_d else G_GEMMS)
+        has_front = any("front_kernel" in d["name"] or "densify_rows" in d["name"] or "sparse_front" in d["name"] for d in st)
         if paired:
             names = names[:5] + ["gUb+gV+adam"]
         if wpaired:
             names = names[:4] + ["gWd+gWe+adam"]
+        if not has_front:
+            names = names[1:]      # a step of a staged pass: rows and generated rows were formed in front of the pass
         gi, last = 0, None
         kind = "D" if is_d else "G"
         if sum(1 for d in st if _gemm_like(d["name"])) != len(names):
@@ -102,6 +143,7 @@ def label(disp):
             else:
                 lab = n.split("(")[0][-30:]
             out.append((kind + ":" + lab, d))
+        COUNTS[kind] += 1
     return out
 
 
@@ -122,7 +164,7 @@ def main():
     # SQ_VALU_MFMA_BUSY_CYCLES over the 1024 SIMDs (256 CUs x 4): clock = busy cycles per SE / duration, MFMA utilisation
     # = MFMA-busy cycles per SIMD / busy cycles per SE
     derived = "SQ_BUSY_CYCLES" in cnames and "SQ_VALU_MFMA_BUSY_CYCLES" in cnames
-    per = {"D": 0.0, "G": 0.0}
+    per = {"D": 0.0, "G": 0.0, "P": 0.0}      # total us per kind (P: launches in front of a staged discriminator pass)
     print("| step:class | kernel | workgroups | launches | avg us |" + "".join(" %s |" % c for c in cnames) +
           (" clock GHz | MFMA busy % |" if derived else ""))
     print("|---|---|---|---|---|" + "---|" * (len(cnames) + (2 if derived else 0)))
@@ -135,14 +177,17 @@ def main():
             pass
         avg = a["us"] / a["n"]
         if k[0] in per:
-            per[k[0]] += avg
+            per[k[0]] += a["us"]
         extra = ""
         if derived:
             busy_se = a["c"]["SQ_BUSY_CYCLES"] / a["n"] / 32.0
             extra = " %.2f | %.1f |" % (busy_se / max(avg, 1e-9) / 1e3, 100.0 * a["c"]["SQ_VALU_MFMA_BUSY_CYCLES"] / a["n"] / 1024.0 / max(busy_se, 1.0))
         print("| %s | `%s` | %s | %d | %.2f |" % (k, kern, wg, a["n"], avg) + "".join(" %.4g |" % (a["c"][c] / a["n"]) for c in cnames) + extra)
-    print("\nD-step %.1f us, G-step %.1f us, D+G pair %.1f us (sum of the class averages; %d labelled dispatches)" % (
-        per["D"], per["G"], per["D"] + per["G"], len(lab)))
+    nd, ng = max(COUNTS["D"], 1), max(COUNTS["G"], 1)
+    dstep = (per["D"] + per["P"]) / nd      # the launches in front of a staged pass belong to its discriminator steps
+    print("\nD-step %.1f us%s, G-step %.1f us, D+G pair %.1f us (kernel time of the labelled dispatches / steps: %d D, %d G; %d labelled dispatches)" % (
+        dstep, " (of which %.1f us per step in front of the pass)" % (per["P"] / nd) if per["P"] else "", per["G"] / ng, dstep + per["G"] / ng,
+        COUNTS["D"], COUNTS["G"], len(lab)))
 
 
 if __name__ == "__main__":
