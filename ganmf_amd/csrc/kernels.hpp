@@ -67,7 +67,7 @@ __device__ __forceinline__ void densify_row_body(const DensP& d, const int bid) 
   const int nseg = d.nseg > 1 ? d.nseg : 1;
   const int b = bid / nseg, seg = bid % nseg;
   const bool staged = d.stage_b > 0;
-  if (!staged && bid == 0 && threadIdx.x == 0) {
+  if (!staged && d.alpha_idx >= 0 && bid == 0 && threadIdx.x == 0) {      // (alpha_idx < 0: the pass opened its steps at once, open_steps_kernel)
     const int o = d.which ? S_B1P_G : S_B1P_D;
     const float b1p = d.scal[o], b2p = d.scal[o + 1];
     d.scal[d.alpha_idx] = d.lr * sqrtf(1.f - b2p) / (1.f - b1p);
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void sparse_front_kernel(const long long* __re
                                                            int e, float* __restrict__ E) {
   __shared__ float4 part[256];
   const int b = blockIdx.x, tid = threadIdx.x;
-  if (b == 0 && tid == 0) {
+  if (alpha_idx >= 0 && b == 0 && tid == 0) {
     const int o = which ? S_B1P_G : S_B1P_D;
     const float b1p = scal[o], b2p = scal[o + 1];
     scal[alpha_idx] = lr * sqrtf(1.f - b2p) / (1.f - b1p);
@@ -133,8 +133,10 @@ __global__ __launch_bounds__(256) void sparse_front_kernel(const long long* __re
   }
   const int r = rows[b];
   const float4* us = reinterpret_cast<const float4*>(Uemb + (size_t)r * ldk);
-  float4* ud = reinterpret_cast<float4*>(Ub + (size_t)b * ldk);
-  for (int c = tid; c < ldk / 4; c += 256) ud[c] = us[c];
+  if (Ub) {      // (nullptr: the embeddings of the pass were staged in schedule order, adam_rows_advance_kernel)
+    float4* ud = reinterpret_cast<float4*>(Ub + (size_t)b * ldk);
+    for (int c = tid; c < ldk / 4; c += 256) ud[c] = us[c];
+  }
   if (tid == 0) XF[(size_t)(nb + b) * ldx + ncols] = 1.0f;
   const long long s = indptr[r], en = indptr[r + 1];
   const int c4n = (e + 3) / 4;                       // float4 columns that hold encodings (We rows are zero-padded to lde)
@@ -449,6 +451,16 @@ __global__ __launch_bounds__(256) void adam_dense_kernel(float* __restrict__ th,
   }
 }
 
+// one element of the all-rows update below (shared with the per-pass forms, adam_rows_advance_kernel / adam_rows_flush_kernel)
+__device__ __forceinline__ void adam_row_elem(float g, float reg, float alpha, float& th, float& m, float& v, float& sq) {
+  const float x = th;
+  sq += x * x;
+  const float gr = g + reg * x;
+  m = m * ADAM_B1 + gr * (1.f - ADAM_B1);
+  v = v * ADAM_B2 + (gr * gr) * (1.f - ADAM_B2);
+  th = x - alpha * m / (sqrtf(v) + ADAM_EPS);
+}
+
 // AdamOptimizer._apply_sparse_shared over ALL rows of user_embeddings (TF-1 Adam is not lazy,
 // SURVEY Appendix B.5): rows of the current batch take their gradient from gUb, others g = 0.
 //   m = m*b1 + g'(1-b1) ; v = v*b2 + g'^2(1-b2) ; theta -= alpha*m/(sqrt(v)+eps)
@@ -486,14 +498,7 @@ __global__ __launch_bounds__(256) void adam_rows_kernel(float* __restrict__ th, 
     float4 v = reinterpret_cast<float4*>(vo)[i];
     float* tp = &t.x; float* mp = &m.x; float* vp = &v.x; const float* gp = &gg.x;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float x = tp[j];
-      sq += x * x;
-      const float gr = gp[j] + reg * x;
-      mp[j] = mp[j] * ADAM_B1 + gr * (1.f - ADAM_B1);
-      vp[j] = vp[j] * ADAM_B2 + (gr * gr) * (1.f - ADAM_B2);
-      tp[j] = x - alpha * mp[j] / (sqrtf(vp[j]) + ADAM_EPS);
-    }
+    for (int j = 0; j < 4; ++j) adam_row_elem(gp[j], reg, alpha, tp[j], mp[j], vp[j], sq);
     reinterpret_cast<float4*>(th)[i] = t;
     reinterpret_cast<float4*>(mo)[i] = m;
     reinterpret_cast<float4*>(vo)[i] = v;
@@ -501,6 +506,84 @@ __global__ __launch_bounds__(256) void adam_rows_kernel(float* __restrict__ th, 
   if (sq_partials) {
     const float s = block_sum_256(sq, red);
     if (threadIdx.x == 0) sq_partials[blockIdx.x] = s;
+  }
+}
+
+// ---- the all-rows update of user_embeddings, once per generator PASS instead of once per step (g_reg == 0) ---------------------
+// During a generator pass a row of U is read exactly once -- by the step whose minibatch holds it -- and (with g_reg = 0) receives
+// a non-zero gradient exactly once, at that step; every other step only decays its moments and moves it by lr_t * m / (sqrt(v) + eps).
+// Those T updates per element depend on nothing but the element's own state, so they need not be T passes over 6 x U x k floats:
+//   adam_rows_advance_kernel (front of the pass): row at schedule position a, used by step s = pos_step[a], advanced by s
+//       zero-gradient steps -> Ub_sched[a] = the embedding that step will read (the parameter itself is not touched);
+//   adam_rows_flush_kernel (end of the pass): every row of U through all T steps, the gradient of ITS step summed from that step's
+//       gUb slabs in split order -- theta, m, v read and written once per pass.
+// Same float operations in the same order per element as T launches of adam_rows_kernel (adam_row_elem): bit-identical.
+struct LazyStep {
+  const float* g;          // gUb of the step: nsplit slabs [nb, ld] (slab q at g + q * gstride)
+  long long gstride;
+  int nsplit, start, nb;   // the step's minibatch = schedule positions [start, start + nb)
+};
+
+__global__ __launch_bounds__(256) void adam_rows_advance_kernel(const float* __restrict__ th, const float* __restrict__ mo,
+                                                                const float* __restrict__ vo, const int* __restrict__ perm,
+                                                                const int* __restrict__ pos_step, int n, int ld,
+                                                                const float* __restrict__ scal, int tab, float reg,
+                                                                float* __restrict__ out) {
+  const int c4 = ld / 4;
+  const long long total = (long long)n * c4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int a = (int)(i / c4), c = (int)(i % c4);
+    const size_t src = (size_t)perm[a] * c4 + c;
+    const int s = pos_step[a];
+    float4 t = reinterpret_cast<const float4*>(th)[src];
+    float4 m = reinterpret_cast<const float4*>(mo)[src];
+    float4 v = reinterpret_cast<const float4*>(vo)[src];
+    float* tp = &t.x; float* mp = &m.x; float* vp = &v.x;
+    float sq = 0.f;
+    for (int tt = 0; tt < s; ++tt) {
+      const float alpha = scal[tab + tt];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) adam_row_elem(0.f, reg, alpha, tp[j], mp[j], vp[j], sq);
+    }
+    reinterpret_cast<float4*>(out)[i] = t;
+  }
+}
+
+__global__ __launch_bounds__(256) void adam_rows_flush_kernel(float* __restrict__ th, float* __restrict__ mo, float* __restrict__ vo,
+                                                              const int* __restrict__ pos, const int* __restrict__ pos_step,
+                                                              const LazyStep* __restrict__ steps, int T, int nrows, int ld,
+                                                              const float* __restrict__ scal, int tab, float reg) {
+  const int c4 = ld / 4;
+  const long long total = (long long)nrows * c4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / c4), c = (int)(i % c4);
+    const int a = pos[r];
+    const int s = a >= 0 ? pos_step[a] : -1;
+    float4 gg = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (s >= 0) {
+      const LazyStep st = steps[s];
+      const float* gp0 = st.g + (size_t)(a - st.start) * ld + 4 * c;
+      gg = *reinterpret_cast<const float4*>(gp0);
+#pragma unroll 8
+      for (int sp = 1; sp < st.nsplit; ++sp) {
+        const float4 q = *reinterpret_cast<const float4*>(gp0 + (size_t)sp * st.gstride);
+        gg.x += q.x; gg.y += q.y; gg.z += q.z; gg.w += q.w;
+      }
+    }
+    float4 t = reinterpret_cast<float4*>(th)[i];
+    float4 m = reinterpret_cast<float4*>(mo)[i];
+    float4 v = reinterpret_cast<float4*>(vo)[i];
+    float* tp = &t.x; float* mp = &m.x; float* vp = &v.x; const float* gp = &gg.x;
+    float sq = 0.f;
+    for (int tt = 0; tt < T; ++tt) {
+      const float alpha = scal[tab + tt];
+      const bool mine = tt == s;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) adam_row_elem(mine ? gp[j] : 0.f, reg, alpha, tp[j], mp[j], vp[j], sq);
+    }
+    reinterpret_cast<float4*>(th)[i] = t;
+    reinterpret_cast<float4*>(mo)[i] = m;
+    reinterpret_cast<float4*>(vo)[i] = v;
   }
 }
 

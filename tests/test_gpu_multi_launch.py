@@ -85,11 +85,11 @@ def test_second_item_buffer_survives_snapshot_and_restore(monkeypatch):
     eng.close()
 
 
-def _run_staged(monkeypatch, stage, model, U, N, k, e, B, hp, epochs, d_steps):
-    """Epochs (and D passes) with / without the staged discriminator pass (GANMF_TUNE=pass_stage=0|1)."""
+def _run_staged(monkeypatch, tune, model, U, N, k, e, B, hp, epochs, d_steps, g_steps=1):
+    """Epochs with / without the per-pass forms (GANMF_TUNE=pass_stage=0|1,lazy_rows=0|1)."""
     from ganmf_amd import _lib as L
     from ganmf_amd.engine import Engine
-    monkeypatch.setenv("GANMF_TUNE", "pass_stage=%d" % stage)
+    monkeypatch.setenv("GANMF_TUNE", tune)
     urm = synthetic_urm(U, N, 0.04, seed=21)
     rng = np.random.RandomState(11)
     if model == "ganmf":
@@ -110,7 +110,7 @@ def _run_staged(monkeypatch, stage, model, U, N, k, e, B, hp, epochs, d_steps):
     prng = np.random.RandomState(5)
     losses = []
     for _ in range(epochs):
-        dl, gl = eng.train_epoch(prng.permutation(U), d_steps, 1)
+        dl, gl = eng.train_epoch(prng.permutation(U), d_steps, g_steps)
         losses.append((np.array(dl), np.array(gl)))
     out = {n: eng.get_tensor(tid).copy() for n, tid in ids.items()}
     out.update({n + ".m": eng.get_tensor(tid, slot=L.SLOT_ADAM_M).copy() for n, tid in ids.items()})
@@ -121,22 +121,28 @@ def _run_staged(monkeypatch, stage, model, U, N, k, e, B, hp, epochs, d_steps):
 
 
 @pytest.mark.parametrize("case", [
-    ("ganmf", 1500, 3706, 250, 992, 128, 1),       # the row expansion rides in the generator launch (front_kernel); ragged last minibatch
-    ("ganmf", 700, 1100, 20, 64, 32, 2),           # stand-alone row expansion + generator product; two discriminator passes per call
-    ("disganmf", 900, 1100, 64, 128, 64, 1),       # float(uid) column in the staged rows
+    ("ganmf", 1500, 3706, 250, 992, 128, 1, 1, 0.0),     # the row expansion rides in the generator launch (front_kernel); ragged last minibatch; gUb + gV paired
+    ("ganmf", 700, 1100, 20, 64, 32, 2, 3, 0.0),         # stand-alone row expansion, generator product, gUb, gV; two D and three G passes per call
+    ("ganmf", 700, 1100, 20, 64, 32, 1, 1, 1e-3),        # g_reg != 0: the all-rows update stays per step (every row has a gradient every step)
+    ("disganmf", 900, 1100, 64, 128, 64, 1, 2, 0.0),     # float(uid) column in the staged rows
 ])
-def test_staged_discriminator_pass_is_bit_identical(case, monkeypatch):
-    """stage_pass (lib/step_ganmf.inc): the CSR rows and the generated rows of every full minibatch of a discriminator pass formed once in
-    front of it -- same tiles, same K order, lr_t from open_steps_kernel -- against every step expanding its own rows."""
-    model, U, N, k, e, B, d_steps = case
-    hp = dict(d_lr=1e-4, g_lr=2e-4, d_reg=1e-4, g_reg=1e-3, recon_coefficient=0.05)
+def test_per_pass_forms_are_bit_identical(case, monkeypatch):
+    """Work that a pass's frozen half of the model makes independent of the steps before it, done once per pass:
+    * stage_pass (lib/step_ganmf.inc): the CSR rows and the generated rows of every full minibatch of a DISCRIMINATOR pass (U, V frozen)
+      formed in front of it -- same tiles, same K order, lr_t from open_steps_kernel;
+    * lazy_pass_begin / lazy_pass_end: the all-rows Adam over user_embeddings of a GENERATOR pass (g_reg == 0: a row is read once and has
+      a gradient once per pass) as one advance launch in front of the pass and one flush launch behind it;
+    against every step doing its own (GANMF_TUNE=pass_stage=0,lazy_rows=0)."""
+    model, U, N, k, e, B, d_steps, g_steps, g_reg = case
+    hp = dict(d_lr=1e-4, g_lr=2e-4, d_reg=1e-4, g_reg=g_reg, recon_coefficient=0.05)
     if model == "ganmf":
         hp.update(m=10.0)
-    ref, ref_l = _run_staged(monkeypatch, 0, model, U, N, k, e, B, hp, 2, d_steps)
-    got, got_l = _run_staged(monkeypatch, 1, model, U, N, k, e, B, hp, 2, d_steps)
-    for (dl, gl), (dr, gr) in zip(got_l, ref_l):
-        np.testing.assert_array_equal(dl, dr, err_msg="D losses")
-        np.testing.assert_array_equal(gl, gr, err_msg="G losses")
-    assert set(ref) == set(got)
-    for n in ref:
-        np.testing.assert_array_equal(got[n], ref[n], err_msg=str(n))
+    ref, ref_l = _run_staged(monkeypatch, "pass_stage=0,lazy_rows=0", model, U, N, k, e, B, hp, 2, d_steps, g_steps)
+    for tune in ("pass_stage=1,lazy_rows=0", "pass_stage=0,lazy_rows=1", "pass_stage=1,lazy_rows=1"):
+        got, got_l = _run_staged(monkeypatch, tune, model, U, N, k, e, B, hp, 2, d_steps, g_steps)
+        for (dl, gl), (dr, gr) in zip(got_l, ref_l):
+            np.testing.assert_array_equal(dl, dr, err_msg="D losses, " + tune)
+            np.testing.assert_array_equal(gl, gr, err_msg="G losses, " + tune)
+        assert set(ref) == set(got)
+        for n in ref:
+            np.testing.assert_array_equal(got[n], ref[n], err_msg="%s, %s" % (n, tune))

@@ -72,15 +72,20 @@ def test_staged_pass_labels(tmp_path):
     p = tmp_path / "trace.csv"
     head = ["ganmf::densify_rows_kernel(ganmf::DensP)", "void ganmf::gemm_bf16k_mfma<false, false, 3, false>(ganmf::GemmP)",
             "ganmf::open_steps_kernel(float*, int, int, int, float)"]
-    _write(p, [head, WPAIR_D_STEP[1:], NEW_D_STEP[1:], WPAIR_D_STEP, G_STEP])
+    ghead = ["ganmf::open_steps_kernel(float*, int, int, int, float)", "ganmf::adam_rows_advance_kernel(float const*)"]
+    lazy_g = G_STEP[:-1]      # a generator step of a lazy pass has no all-rows Adam launch
+    _write(p, [head, WPAIR_D_STEP[1:], NEW_D_STEP[1:], WPAIR_D_STEP, G_STEP, ghead, lazy_g, lazy_g, ["ganmf::adam_rows_flush_kernel(float*)"]])
     COUNTS["D"] = COUNTS["G"] = 0
     lab = [k for k, _ in label(load(str(p)))]
     assert lab[:3] == ["P:CSR rows of the whole pass", "P:generated rows of the whole pass (batched)", "P:lr_t of the pass's steps"]
+    assert lab[3] == "Q:lr_t of the pass's steps" and lab[4].startswith("Q:all-rows Adam over U, rows advanced") and lab[5].startswith("Q:all-rows Adam over U, every row")
+    lab = lab[:3] + lab[6:]      # (the per-pass launches are listed first)
     assert lab[3:9] == ["D:encode", "D:reduce(encode)", "D:decode", "D:dE+d_coef", "D:reduce(dE)", "D:gWd+gWe+adam"]
     assert lab[9:15] == ["D:encode", "D:reduce(encode)", "D:decode", "D:dE+d_coef", "D:gWd+adam+reduce(dE)", "D:gWe+adam"]
     assert lab[15:22] == ["D:gen+rows", "D:encode", "D:reduce(encode)", "D:decode", "D:dE+d_coef", "D:reduce(dE)", "D:gWd+gWe+adam"]
-    assert lab[22] == "G:gen+rows" and len(lab) == 3 + 6 + 6 + 7 + 11
-    assert COUNTS == {"D": 3, "G": 1}
+    assert lab[22] == "G:gen+rows" and lab[32] == "G:adam_rows_U" and lab[33] == "G:gen+rows" and lab[42] == "G:gUb+gV+adam"
+    assert len(lab) == 3 + 6 + 6 + 7 + 11 + 10 + 10
+    assert COUNTS == {"D": 3, "G": 3}
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "step_classes.py"), str(p)], capture_output=True, text=True)
     assert out.returncode == 0 and "in front of the pass" in out.stdout, out.stdout + out.stderr
 

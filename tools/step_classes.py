@@ -56,8 +56,14 @@ def label(disp):
     for i, d in enumerate(disp):
         n = d["name"]
         if "open_steps_kernel" in n:
-            staged, cur, after_dcoef = True, None, None
-            out_pass.append(("P:lr_t of the pass's steps", d))
+            gpass = any("adam_rows_advance" in x["name"] for x in disp[i + 1:i + 2])      # a generator pass: its advance launch follows
+            staged, cur, after_dcoef = not gpass, None, None
+            out_pass.append((("Q" if gpass else "P") + ":lr_t of the pass's steps", d))
+            continue
+        if "adam_rows_advance" in n or "adam_rows_flush" in n:      # the all-rows Adam over U of a whole generator pass (lazy_pass_begin / _end)
+            out_pass.append(("Q:all-rows Adam over U, %s" % ("rows advanced to their step (front of the pass)" if "advance" in n else "every row through the pass (end of the pass)"), d))
+            if "flush" in n:
+                cur = None
             continue
         if "densify_rows_kernel" in n and any("open_steps_kernel" in x["name"] for x in disp[i + 1:i + 4]):
             out_pass.append(("P:CSR rows of the whole pass", d))      # (stage_pass: row expansion, generated rows, then the pass's lr_t table)
@@ -164,7 +170,7 @@ def main():
     # SQ_VALU_MFMA_BUSY_CYCLES over the 1024 SIMDs (256 CUs x 4): clock = busy cycles per SE / duration, MFMA utilisation
     # = MFMA-busy cycles per SIMD / busy cycles per SE
     derived = "SQ_BUSY_CYCLES" in cnames and "SQ_VALU_MFMA_BUSY_CYCLES" in cnames
-    per = {"D": 0.0, "G": 0.0, "P": 0.0}      # total us per kind (P: launches in front of a staged discriminator pass)
+    per = {"D": 0.0, "G": 0.0, "P": 0.0, "Q": 0.0}      # total us per kind (P / Q: launches in front of / around a discriminator / generator pass)
     print("| step:class | kernel | workgroups | launches | avg us |" + "".join(" %s |" % c for c in cnames) +
           (" clock GHz | MFMA busy % |" if derived else ""))
     print("|---|---|---|---|---|" + "---|" * (len(cnames) + (2 if derived else 0)))
@@ -184,11 +190,12 @@ def main():
             extra = " %.2f | %.1f |" % (busy_se / max(avg, 1e-9) / 1e3, 100.0 * a["c"]["SQ_VALU_MFMA_BUSY_CYCLES"] / a["n"] / 1024.0 / max(busy_se, 1.0))
         print("| %s | `%s` | %s | %d | %.2f |" % (k, kern, wg, a["n"], avg) + "".join(" %.4g |" % (a["c"][c] / a["n"]) for c in cnames) + extra)
     nd, ng = max(COUNTS["D"], 1), max(COUNTS["G"], 1)
-    dstep = (per["D"] + per["P"]) / nd      # the launches in front of a staged pass belong to its discriminator steps
-    print("\nD-step %.1f us%s, G-step %.1f us, D+G pair %.1f us (kernel time of the labelled dispatches / steps: %d D, %d G; %d labelled dispatches)" % (
-        dstep, " (of which %.1f us per step in front of the pass)" % (per["P"] / nd) if per["P"] else "", per["G"] / ng, dstep + per["G"] / ng,
+    dstep = (per["D"] + per["P"]) / nd      # the per-pass launches belong to the steps of their pass
+    gstep = (per["G"] + per["Q"]) / ng
+    print("\nD-step %.1f us%s, G-step %.1f us%s, D+G pair %.1f us (kernel time of the labelled dispatches / steps: %d D, %d G; %d labelled dispatches)" % (
+        dstep, " (of which %.1f us per step in front of the pass)" % (per["P"] / nd) if per["P"] else "",
+        gstep, " (of which %.1f us per step around the pass)" % (per["Q"] / ng) if per["Q"] else "", dstep + gstep,
         COUNTS["D"], COUNTS["G"], len(lab)))
-
 
 if __name__ == "__main__":
     main()
