@@ -13,7 +13,7 @@ GANMF_BENCH_FORCE_COMM=1 python bench.py --no-cpu-baseline > gpurun_out/$T/bench
 cd /tmp && export TMPDIR=/tmp
 GANMF_BENCH_FORCE_COMM=1 rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/$T/trace_fc -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps 64 --warmup 32 > $GRAFT_REPO_ROOT/gpurun_out/$T/trace_fc.log 2>&1
 cd $GRAFT_REPO_ROOT
-python3 tools/timeline.py "$(ls gpurun_out/$T/trace_fc/*/*_kernel_trace.csv | head -1)" 40 1 > gpurun_out/$T/timeline_fc_D.txt
-python3 tools/timeline.py "$(ls gpurun_out/$T/trace_fc/*/*_kernel_trace.csv | head -1)" 70 1 > gpurun_out/$T/timeline_fc_G.txt
+python3 tools/timeline.py "$(ls gpurun_out/$T/trace_fc/*/*_kernel_trace.csv | head -1)" 40 1 de_dcoef_kernel > gpurun_out/$T/timeline_fc_D.txt
+python3 tools/timeline.py "$(ls gpurun_out/$T/trace_fc/*/*_kernel_trace.csv | head -1)" 40 1 > gpurun_out/$T/timeline_fc_G.txt
 find gpurun_out/$T -name "*_kernel_trace.csv" -delete
 du -sh gpurun_out/$T

@@ -2,7 +2,9 @@
 """GPU timeline of a few consecutive training steps from a rocprofv3 kernel trace: start offset, duration and queue of every
 kernel between the n-th and the (n + count)-th step front, plus the idle gaps of the whole device.  Shows what the side lane
 of the data-parallel step (reduce-scatter / Adam slice / all-gather) overlaps with and what it leaves exposed.
-usage: timeline.py <kernel_trace.csv> [first_front=40] [fronts=4]"""
+A step of a staged discriminator pass has no front launch of its own (stage_pass): give the substring of a kernel every such step
+launches once as the anchor (e.g. de_dcoef_kernel) and the window runs from one occurrence to the next -- one whole step, rotated.
+usage: timeline.py <kernel_trace.csv> [first_front=40] [fronts=4] [anchor substring]"""
 import csv
 import sys
 
@@ -11,7 +13,9 @@ first = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 count = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 rows = [r for r in csv.DictReader(open(path)) if r.get("Start_Timestamp")]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-fronts = [i for i, r in enumerate(rows) if "front_kernel" in r["Kernel_Name"] or "densify_rows_kernel" in r["Kernel_Name"]]
+anchor = sys.argv[4] if len(sys.argv) > 4 else None
+fronts = [i for i, r in enumerate(rows) if (anchor in r["Kernel_Name"] if anchor else
+                                            "front_kernel" in r["Kernel_Name"] or "densify_rows_kernel" in r["Kernel_Name"])]
 if len(fronts) < first + count + 1:
     first = max(0, len(fronts) - count - 1)
 a, b = fronts[first], fronts[first + count]
