@@ -1056,6 +1056,7 @@ struct GemmPlan {
   int kg = 1;                // fp32 ring kernel, 64 x 64 tiles: K groups of four waves per workgroup (1, 2 or 4)
   int sq_count = 0;          // sq partial entries per batch this plan produces
   int tile_order = 0;        // GemmTune::tile_order
+  int skinny = 0;            // > 0: the streaming kernel for K <= 64 (gemm_skinny.hpp), this many rows per wave
   double est_us = 0;
 };
 
@@ -1228,7 +1229,10 @@ inline void choose_tile_order(GemmP& p, const GemmPlan& pl) {
   p.xb_band = band;
 }
 
+inline hipError_t gemm_dispatch_skinny(hipStream_t st, const GemmP& p0, bool bkm, int rt);
+
 inline hipError_t gemm_dispatch(hipStream_t st, const GemmP& p0, bool akm, bool bkm, const GemmPlan& pl) {
+  if (pl.skinny) return gemm_dispatch_skinny(st, p0, bkm, pl.skinny);
   if (pl.persist) return gemm_dispatch_persist(st, p0, akm, bkm, pl);
   GemmP p = p0;
   choose_tile_order(p, pl);

@@ -27,6 +27,7 @@
 #endif
 #include "gemm_f32.hpp"
 #include "kernels.hpp"
+#include "gemm_skinny.hpp"
 
 namespace ganmf {
 

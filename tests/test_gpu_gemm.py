@@ -169,3 +169,22 @@ def test_gemm_split_bf16_k_groups(akm, bkm, shape, nsplit, monkeypatch):
     monkeypatch.setenv("GANMF_X3KG", "0")
     plain, _ = gemm_f32(A, B, akm, bkm, tile=64, nsplit=nsplit)
     assert not np.array_equal(plain, out) or K == 1      # (it IS another kernel)
+
+
+@pytest.mark.parametrize("akm,bkm", [(False, False), (False, True)])
+@pytest.mark.parametrize("shape", [(256, 50000, 33), (128, 17632, 32), (1, 2048, 1), (64, 2049, 10), (100, 5003, 64), (321, 4100, 7), (70, 3000, 63)])
+def test_gemm_skinny_k_stream(akm, bkm, shape, monkeypatch):
+    """gemm_skinny.hpp: K <= 64 behind a wide output (decode / dF of a narrow autoencoder, the generator product of a small
+    num_factors) as a stream with fp32 FMAs on the way -- the default for such shapes; against the tiled kernels
+    (GANMF_TUNE=skinny=0) and the fp64 product.  Ragged rows, columns and K; strips of 256, 128 and 64 columns."""
+    from ganmf_amd.engine import gemm_f32
+    M, N, K = shape
+    rng = np.random.RandomState(M + N + K)
+    A, B, ref, bound = _mk(rng, M, N, K, akm, bkm)
+    out, _ = gemm_f32(A, B, akm, bkm)
+    err = np.abs(out - ref)
+    assert np.all(err <= 4e-7 * bound * np.sqrt(K) + 1e-30), float((err / (bound + 1e-30)).max())
+    monkeypatch.setenv("GANMF_TUNE", "skinny=0")
+    tiled, _ = gemm_f32(A, B, akm, bkm)
+    assert np.all(np.abs(tiled - ref) <= 4e-7 * bound * np.sqrt(K) + 1e-30)
+    assert np.all(np.abs(tiled - out) <= 8e-7 * bound * np.sqrt(K) + 1e-30)

@@ -30,6 +30,7 @@ def test_presplit_scores_at_fp32_accuracy(monkeypatch, U, N, k):
     ids = rng.permutation(U)[: U - 3]
     idt = np.arange(N - 5)
     got = {}
+    monkeypatch.setenv("GANMF_TUNE", "skinny=0")      # (K <= 64 would otherwise stream through gemm_skinny.hpp: its own test in test_gpu_gemm.py)
     for pre in ("1", "0"):
         monkeypatch.setenv("GANMF_SCORE_PRESPLIT", pre)
         eng = Engine(U, N, k, 8, 8)
