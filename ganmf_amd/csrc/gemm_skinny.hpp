@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const GemmP p) {
 #pragma unroll
   for (int i = 0; i < RT; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   const float* __restrict__ bcol = sB + 4 * lane;
-  for (int k4 = 0; k4 < Kp; k4 += 4) {      // (k >= K: those rows of the strip are zero; A's pad columns are finite by the buffer layout)
+  for (int k4 = 0; k4 < Kp; k4 += 4) {      // (k >= K: those rows of the strip are zero and A's values are masked)
     const float4 b0 = *reinterpret_cast<const float4*>(bcol + (k4 + 0) * BN);
     const float4 b1 = *reinterpret_cast<const float4*>(bcol + (k4 + 1) * BN);
     const float4 b2 = *reinterpret_cast<const float4*>(bcol + (k4 + 2) * BN);
@@ -93,7 +93,12 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const GemmP p) {
       const int row = min(r0 + i, p.M - 1);
       // uniform address, read through the CONSTANT address space: a scalar load (s_load_dwordx4) into SGPRs that v_pk_fma_f32 takes as
       // an operand
-      const sk_f4 a = *reinterpret_cast<const sk_cf4*>(reinterpret_cast<unsigned long long>(A + (size_t)row * p.lda + k4));
+      sk_f4 a = *reinterpret_cast<const sk_cf4*>(reinterpret_cast<unsigned long long>(A + (size_t)row * p.lda + k4));
+      if (k4 + 4 > p.K) {      // last, partial group of four: whatever A's pad columns hold does not enter (scalar selects)
+        if (k4 + 1 >= p.K) a.y = 0.f;
+        if (k4 + 2 >= p.K) a.z = 0.f;
+        if (k4 + 3 >= p.K) a.w = 0.f;
+      }
       acc[i].x = fmaf(a.x, b0.x, acc[i].x); acc[i].y = fmaf(a.x, b0.y, acc[i].y); acc[i].z = fmaf(a.x, b0.z, acc[i].z); acc[i].w = fmaf(a.x, b0.w, acc[i].w);
       acc[i].x = fmaf(a.y, b1.x, acc[i].x); acc[i].y = fmaf(a.y, b1.y, acc[i].y); acc[i].z = fmaf(a.y, b1.z, acc[i].z); acc[i].w = fmaf(a.y, b1.w, acc[i].w);
       acc[i].x = fmaf(a.z, b2.x, acc[i].x); acc[i].y = fmaf(a.z, b2.y, acc[i].y); acc[i].z = fmaf(a.z, b2.z, acc[i].z); acc[i].w = fmaf(a.z, b2.w, acc[i].w);
