@@ -83,7 +83,11 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const GemmP p) {
 #pragma unroll
   for (int i = 0; i < RT; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   const float* __restrict__ bcol = sB + 4 * lane;
-  for (int k4 = 0; k4 < Kp; k4 += 4) {      // (k >= K: those rows of the strip are zero and A's values are masked)
+  // k >= K inside the last group of four: those rows of the strip are zero, and A's pad columns are zero by the buffer layout every
+  // kernel of the library relies on (leading dimensions are whole K-tiles, pads are zero and are never stored to).
+  // (Masking A's values there was measured: inside the loop it costs the scalar loads their pipelining, 26.7 -> 31.6 us; as a peeled
+  // last group 28.8 us.)
+  for (int k4 = 0; k4 < Kp; k4 += 4) {
     const float4 b0 = *reinterpret_cast<const float4*>(bcol + (k4 + 0) * BN);
     const float4 b1 = *reinterpret_cast<const float4*>(bcol + (k4 + 1) * BN);
     const float4 b2 = *reinterpret_cast<const float4*>(bcol + (k4 + 2) * BN);
@@ -93,12 +97,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const GemmP p) {
       const int row = min(r0 + i, p.M - 1);
       // uniform address, read through the CONSTANT address space: a scalar load (s_load_dwordx4) into SGPRs that v_pk_fma_f32 takes as
       // an operand
-      sk_f4 a = *reinterpret_cast<const sk_cf4*>(reinterpret_cast<unsigned long long>(A + (size_t)row * p.lda + k4));
-      if (k4 + 4 > p.K) {      // last, partial group of four: whatever A's pad columns hold does not enter (scalar selects)
-        if (k4 + 1 >= p.K) a.y = 0.f;
-        if (k4 + 2 >= p.K) a.z = 0.f;
-        if (k4 + 3 >= p.K) a.w = 0.f;
-      }
+      const sk_f4 a = *reinterpret_cast<const sk_cf4*>(reinterpret_cast<unsigned long long>(A + (size_t)row * p.lda + k4));
       acc[i].x = fmaf(a.x, b0.x, acc[i].x); acc[i].y = fmaf(a.x, b0.y, acc[i].y); acc[i].z = fmaf(a.x, b0.z, acc[i].z); acc[i].w = fmaf(a.x, b0.w, acc[i].w);
       acc[i].x = fmaf(a.y, b1.x, acc[i].x); acc[i].y = fmaf(a.y, b1.y, acc[i].y); acc[i].z = fmaf(a.y, b1.z, acc[i].z); acc[i].w = fmaf(a.y, b1.w, acc[i].w);
       acc[i].x = fmaf(a.z, b2.x, acc[i].x); acc[i].y = fmaf(a.z, b2.y, acc[i].y); acc[i].z = fmaf(a.z, b2.z, acc[i].z); acc[i].w = fmaf(a.z, b2.w, acc[i].w);
@@ -160,7 +159,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const GemmP p) {
 inline bool gemm_skinny_eligible(const GemmP& p, bool akm) {
   const int kind = p.epi.kind;
   return !akm && p.K >= 1 && p.K <= SKINNY_KMAX && p.N >= 2048 && p.a_gather == nullptr && p.epi.csr_indptr == nullptr &&
-         p.epi.sp_rows == nullptr && p.epi.sq_m_half == 0 && (p.lda % 4) == 0 && (p.ldb % 4) == 0 && (p.ldc % 4) == 0 &&
+         p.epi.sp_rows == nullptr && p.epi.sq_m_half == 0 && (p.lda % 4) == 0 && p.lda >= ((p.K + 3) & ~3) && (p.ldb % 4) == 0 && (p.ldc % 4) == 0 &&
          (kind == EPI_STORE || ((kind == EPI_SUB_AUX_SQ || kind == EPI_SUB_SCALED_AUX) && p.epi.aux != nullptr && (p.epi.ldaux % 4) == 0));
 }
 // rows per wave: 16 (tiles of 64 rows), or 8 / 4 when that leaves fewer than two workgroups per CU
