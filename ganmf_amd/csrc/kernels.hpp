@@ -42,6 +42,8 @@ __device__ inline float block_sum_256(float v, float* red4) {
 //   * copies row rows[b] of user_embeddings into Ub[b, :].
 // Block 0 / thread 0 also opens the optimizer step: lr_t from the beta powers (TF ApplyAdam),
 // then advances the powers.
+__device__ __forceinline__ void open_steps_body(float* __restrict__ scal, int which, int first_slot, int count, float lr);
+
 struct DensP {
   const long long* indptr;
   const int* indices;
@@ -60,6 +62,10 @@ struct DensP {
   int nseg;                      // > 1 (stand-alone launch on wide rows): nseg workgroups per row, one column segment each
   int stage_b;                   // > 0: the rows of a whole pass (stage_pass): list row b belongs to minibatch b / stage_b and lands in that
                                  // minibatch's [real ; generated] block of 2 * stage_b rows; no embedding copy, no optimizer step opened
+  // staged pass only: block 0 also writes lr_t of the pass's discriminator steps (open_d_count slots from open_d_slot) and, when the call's
+  // first generator pass runs its all-rows Adam per pass, of that pass's steps too -- two one-thread launches less per call
+  int open_d_slot, open_d_count, open_g_slot, open_g_count;
+  float lr_d, lr_g;
 };
 
 // (block b of the row expansion, any block size: also runs as extra workgroups of the generator GEMM's launch, gemm_multi.hpp)
@@ -67,6 +73,10 @@ __device__ __forceinline__ void densify_row_body(const DensP& d, const int bid) 
   const int nseg = d.nseg > 1 ? d.nseg : 1;
   const int b = bid / nseg, seg = bid % nseg;
   const bool staged = d.stage_b > 0;
+  if (staged && bid == 0 && threadIdx.x == 0) {
+    if (d.open_d_count > 0) open_steps_body(d.scal, 0, d.open_d_slot, d.open_d_count, d.lr_d);
+    if (d.open_g_count > 0) open_steps_body(d.scal, 1, d.open_g_slot, d.open_g_count, d.lr_g);
+  }
   if (!staged && d.alpha_idx >= 0 && bid == 0 && threadIdx.x == 0) {      // (alpha_idx < 0: the pass opened its steps at once, open_steps_kernel)
     const int o = d.which ? S_B1P_G : S_B1P_D;
     const float b1p = d.scal[o], b2p = d.scal[o + 1];
@@ -243,18 +253,19 @@ __global__ void open_step_kernel(float* __restrict__ scal, int which, int alpha_
 // Opens `count` consecutive optimizer steps at once: lr_t of step i -> scal[first_slot + i], the beta powers advanced `count` times
 // -- the same float operations, in the same order, as `count` single openings (staged discriminator pass: no step of it has a
 // row-expansion launch to open it).
-__global__ void open_steps_kernel(float* __restrict__ scal, int which, int first_slot, int count, float lr) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    const int o = which ? S_B1P_G : S_B1P_D;
-    float b1p = scal[o], b2p = scal[o + 1];
-    for (int i = 0; i < count; ++i) {
-      scal[first_slot + i] = lr * sqrtf(1.f - b2p) / (1.f - b1p);
-      b1p = b1p * ADAM_B1;
-      b2p = b2p * ADAM_B2;
-    }
-    scal[o] = b1p;
-    scal[o + 1] = b2p;
+__device__ __forceinline__ void open_steps_body(float* __restrict__ scal, int which, int first_slot, int count, float lr) {
+  const int o = which ? S_B1P_G : S_B1P_D;
+  float b1p = scal[o], b2p = scal[o + 1];
+  for (int i = 0; i < count; ++i) {
+    scal[first_slot + i] = lr * sqrtf(1.f - b2p) / (1.f - b1p);
+    b1p = b1p * ADAM_B1;
+    b2p = b2p * ADAM_B2;
   }
+  scal[o] = b1p;
+  scal[o + 1] = b2p;
+}
+__global__ void open_steps_kernel(float* __restrict__ scal, int which, int first_slot, int count, float lr) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) open_steps_body(scal, which, first_slot, count, lr);
 }
 
 // dst[b, :] = src[rows[b], :]   (embedding_lookup, GANMF.py:82)

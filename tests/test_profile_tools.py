@@ -70,16 +70,15 @@ def test_staged_pass_labels(tmp_path):
     weight-gradient launch; a ragged last minibatch keeps its own front launch."""
     from step_classes import COUNTS, label, load
     p = tmp_path / "trace.csv"
-    head = ["ganmf::densify_rows_kernel(ganmf::DensP)", "void ganmf::gemm_bf16k_mfma<false, false, 3, false>(ganmf::GemmP)",
-            "ganmf::open_steps_kernel(float*, int, int, int, float)"]
-    ghead = ["ganmf::open_steps_kernel(float*, int, int, int, float)", "ganmf::adam_rows_advance_kernel(float const*)"]
+    head = ["ganmf::densify_rows_kernel(ganmf::DensP)", "void ganmf::gemm_bf16k_mfma<false, false, 3, false>(ganmf::GemmP)"]
+    ghead = ["ganmf::adam_rows_advance_kernel(float const*)"]
     lazy_g = G_STEP[:-1]      # a generator step of a lazy pass has no all-rows Adam launch
     _write(p, [head, WPAIR_D_STEP[1:], NEW_D_STEP[1:], WPAIR_D_STEP, G_STEP, ghead, lazy_g, lazy_g, ["ganmf::adam_rows_flush_kernel(float*)"]])
     COUNTS["D"] = COUNTS["G"] = 0
     lab = [k for k, _ in label(load(str(p)))]
-    assert lab[:3] == ["P:CSR rows of the whole pass", "P:generated rows of the whole pass (batched)", "P:lr_t of the pass's steps"]
-    assert lab[3] == "Q:lr_t of the pass's steps" and lab[4].startswith("Q:all-rows Adam over U, rows advanced") and lab[5].startswith("Q:all-rows Adam over U, every row")
-    lab = lab[:3] + lab[6:]      # (the per-pass launches are listed first)
+    assert lab[:2] == ["P:CSR rows of the whole pass (+ lr_t of its steps)", "P:generated rows of the whole pass (batched)"]
+    assert lab[2].startswith("Q:all-rows Adam over U, rows advanced") and lab[3].startswith("Q:all-rows Adam over U, every row")
+    lab = lab[:2] + ["-"] + lab[4:]      # (the per-pass launches are listed first)
     assert lab[3:9] == ["D:encode", "D:reduce(encode)", "D:decode", "D:dE+d_coef", "D:reduce(dE)", "D:gWd+gWe+adam"]
     assert lab[9:15] == ["D:encode", "D:reduce(encode)", "D:decode", "D:dE+d_coef", "D:gWd+adam+reduce(dE)", "D:gWe+adam"]
     assert lab[15:22] == ["D:gen+rows", "D:encode", "D:reduce(encode)", "D:decode", "D:dE+d_coef", "D:reduce(dE)", "D:gWd+gWe+adam"]

@@ -45,6 +45,25 @@ def _gemm_like(n):
 COUNTS = {"D": 0, "G": 0}      # complete steps labelled (label())
 
 
+def _is_front(n):
+    return "densify_rows_kernel" in n or "sparse_front_kernel" in n or "front_kernel" in n
+
+
+def _starts_staged_pass(disp, i):
+    """A staged discriminator pass (stage_pass): its steps have no front launch of their own, so no front-like kernel lies between the
+    first two d_coef launches behind the pass's row expansion."""
+    seen = 0
+    for x in disp[i + 1:i + 40]:
+        n = x["name"]
+        if "d_coef_kernel" in n or "de_dcoef_kernel" in n:
+            seen += 1
+            if seen == 2:
+                return True
+        elif _is_front(n) or "adam_rows" in n or "pair_kernel<" in n:
+            return False
+    return False
+
+
 def label(disp):
     """[(class label, dispatch)] for every dispatch that belongs to a complete training step."""
     steps, cur = [], None
@@ -55,9 +74,10 @@ def label(disp):
     expect_pass_gemm = False
     for i, d in enumerate(disp):
         n = d["name"]
-        if "open_steps_kernel" in n:
-            gpass = any("adam_rows_advance" in x["name"] for x in disp[i + 1:i + 2])      # a generator pass: its advance launch follows
-            staged, cur, after_dcoef = not gpass, None, None
+        if "open_steps_kernel" in n:      # a later pass of a call (the first pass's lr_t table rides in the pass's row-expansion launch)
+            gpass = any("adam_rows_advance" in x["name"] for x in disp[i + 1:i + 2])
+            if not gpass:
+                staged, cur, after_dcoef = True, None, None
             out_pass.append((("Q" if gpass else "P") + ":lr_t of the pass's steps", d))
             continue
         if "adam_rows_advance" in n or "adam_rows_flush" in n:      # the all-rows Adam over U of a whole generator pass (lazy_pass_begin / _end)
@@ -65,9 +85,10 @@ def label(disp):
             if "flush" in n:
                 cur = None
             continue
-        if "densify_rows_kernel" in n and any("open_steps_kernel" in x["name"] for x in disp[i + 1:i + 4]):
-            out_pass.append(("P:CSR rows of the whole pass", d))      # (stage_pass: row expansion, generated rows, then the pass's lr_t table)
+        if "densify_rows_kernel" in n and _starts_staged_pass(disp, i):
+            out_pass.append(("P:CSR rows of the whole pass (+ lr_t of its steps)", d))      # (stage_pass: row expansion, then the generated rows)
             cur, expect_pass_gemm = None, True
+            staged, after_dcoef = True, None
             continue
         if expect_pass_gemm and "gemm_" in n:
             out_pass.append(("P:generated rows of the whole pass (batched)", d))
