@@ -493,7 +493,7 @@ def main():
                                      "(3 exact bf16 pieces per operand, 6 piece products on v_mfma_f32_32x32x16_bf16, fp32 accumulate) in "
                                      "16-wave workgroups (gemm_bf16k.hpp) or, for the two fused-Adam weight-gradient GEMMs, 4-wave "
                                      "workgroups; gUb + gV on the fp32 MFMA",
-                       "launches": "D-step 6, G-step 10, plus per pass: three launches in front of a discriminator pass (CSR rows, generated rows and lr_t of all its full minibatches: the generator is frozen during the pass) and three around a generator pass (lr_t of its steps, the embeddings of the scheduled rows advanced to their step, ONE all-rows Adam over U behind the pass instead of one per step: with g_reg = 0 a row is read once and has a gradient once per pass) (generator GEMM + CSR rows, dE + d_coef, gWd + gWe, gUb + gV share a launch)",
+                       "launches": "D-step 6, G-step 10, plus per pass: two launches in front of a discriminator pass (the CSR rows of all its full minibatches -- that launch also writes lr_t of every step of the pass -- and their generated rows: the generator is frozen during the pass) and two around a generator pass (the embeddings of the scheduled rows advanced to their step, ONE all-rows Adam over U behind the pass instead of one per step: with g_reg = 0 a row is read once and has a gradient once per pass) (generator GEMM + CSR rows, dE + d_coef, gWd + gWe, gUb + gV share a launch)",
                        "global_steps_per_s": round(done / el, 2), "rows_per_s": round(world * done * w["B"] / el, 1),
                        "parallelism": "dp%d (users sharded row-wise; RCCL reduce-scatter of the D and V gradients, Adam on the rank's "
                                       "slice, all-gather of the parameters)" % world},
