@@ -30,9 +30,15 @@ TAG = {"gen": "gemm_generator[B,k]x[N,k]^T", "encode": "gemm_encode[2B,N]x[N,e]"
        "gWd+gWe+adam": "gemm_gWd + gemm_gWe, fused Adam"}
 
 
-def algorithmic(cls, B, N, k, e, U):
+def algorithmic(cls, B, N, k, e, U, wgs=0):
     step, name = cls.split(":")
     g = lambda M, Nn, K: 4 * (M * K + K * Nn + M * Nn)
+    ldk = (k + 1 + 63) // 64 * 64
+    if step == "P" and name.startswith("CSR rows"): return 4 * wgs * N                 # one workgroup per scheduled row: the X row written once
+    if step == "P" and name.startswith("generated rows"):                              # batches of ceil(B/64) x ceil(N/64) tiles
+        return (wgs // max(((B + 63) // 64) * ((N + 63) // 64), 1)) * g(B, N, k)
+    if step == "Q" and "advanced" in name: return 16 * (wgs * 256 // max(ldk // 4, 1)) * k    # theta, m, v read, theta written, per scheduled row
+    if step == "Q" and "every row" in name: return 24 * U * k                                   # one sweep of theta, m, v per PASS
     if name == "gen": return g(B, N, k)
     if name == "gen+rows": return g(B, N, k) + 4 * B * (N + 2 * k)
     if name == "dE+d_coef": return g(2 * B, e, N) + 8 * 2 * B * e
@@ -67,7 +73,7 @@ def per_class(d, counter):
     f = max(glob.glob(d + "/*/*counter_collection.csv"), key=os.path.getmtime)   # newest pass if the directory was reused
     acc = collections.OrderedDict()
     for cls, disp in label(load(f)):
-        a = acc.setdefault(cls, {"n": 0, "v": 0.0, "kernel": disp["name"]})
+        a = acc.setdefault(cls, {"n": 0, "v": 0.0, "kernel": disp["name"], "wgs": int(disp["grid"] or 0) // int(disp["wgsize"] or 256)})
         a["n"] += 1
         a["v"] += disp["counters"].get(counter, 0.0)
     return acc
@@ -87,7 +93,7 @@ def main():
             "class": cls, "kernel": f["kernel"].replace("void ganmf::", "").split("(")[0], "launches_sampled": f["n"],
             "FETCH_SIZE_KiB_raw": round(f_kib, 1), "WRITE_SIZE_KiB_raw": round(w_kib, 1),
             "hbm_bytes_per_launch": int((2 * f_kib + w_kib) * 1024),
-            "algorithmic_bytes": int(algorithmic(cls, B, N, k, e, U))}
+            "algorithmic_bytes": int(algorithmic(cls, B, N, k, e, U, f.get("wgs", 0)))}
     json.dump(out, sys.stdout, indent=1)
 
 
