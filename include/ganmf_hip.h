@@ -132,7 +132,13 @@ int ganmf_set_adam_powers(ganmf_handle* h, const float in4[4]);
  * d_steps*ceil(n/batch) resp. g_steps*ceil(n/batch) floats (may be NULL).
  * With world_size > 1 `n_steps_per_pass` (>= ceil(n/batch)) forces every rank to issue the same
  * number of collectives; pass 0 for the default.  `global_batch_rows[i]` = rows in the i-th slice
- * summed over all ranks (NULL when world_size == 1).  Blocking. */
+ * summed over all ranks (NULL when world_size == 1).  Blocking.
+ * Because the reference freezes the generator for a whole discriminator pass and the discriminator for a whole
+ * generator pass (GANMF.py:176-189, 191-203), the call does per PASS what does not depend on the steps before it --
+ * the CSR rows and generated rows of every full minibatch of a discriminator pass; with g_reg == 0 the all-rows
+ * Adam over user_embeddings of a generator pass -- with the float operations of the per-step form, bit for bit
+ * (GANMF_TUNE=pass_stage=0,lazy_rows=0 runs every step on its own).  Parameters and moments
+ * are consistent whenever the call has returned. */
 int ganmf_train_epoch(ganmf_handle* h, const int32_t* perm, int64_t n, int32_t d_steps,
                       int32_t g_steps, int64_t n_steps_per_pass, const int32_t* global_batch_rows,
                       float* d_losses, float* g_losses);
