@@ -185,6 +185,35 @@ def parallelism_object(eng, prof, world, steps_profiled, rows_per_s):
             "note": "timed in the profiled repeat (events around every launch and join: slower than the timed region)"}
 
 
+REPLICATED = (("We", 0), ("be", 1), ("Wd", 2), ("bd", 3), ("V", 101))      # GANMF tensors every rank holds a full copy of
+
+
+def replica_check(eng, world, dist=None, crc=None):
+    """The invariant of the reduce-scatter -> Adam-on-the-slice -> all-gather design (csrc/lib/dataparallel.inc dp_update): after any
+    number of steps every rank holds BITWISE the same replicated tensors, and RCCL's communicator has as many ranks as the launcher
+    started.  CRC-32C (ganmf_crc32c) of each tensor on every rank, gathered over the gloo control plane; every rank returns the same
+    verdict.  A peer-write ordering bug on the side lane shows here before it shows in a loss."""
+    if crc is None:
+        from ganmf_amd.tf_bundle import crc32c as crc
+    mine = {name: int(crc(np.ascontiguousarray(eng.get_tensor(tid), dtype=np.float32))) for name, tid in REPLICATED}
+    mine["rccl_world_size"] = int(eng.comm_info()[0])
+    everyone = [mine]
+    if world > 1:
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine)
+    crcs = {}
+    for name, _ in REPLICATED:
+        vals = ["%08x" % v[name] for v in everyone]
+        crcs[name] = vals[0] if len(set(vals)) == 1 else vals      # (one value when the ranks agree, the per-rank list when they do not)
+    return {"replicas_bitwise_equal": all(isinstance(v, str) for v in crcs.values()),
+            "rccl_world_size_equals_launcher_world_size": all(v["rccl_world_size"] == world for v in everyone),
+            "ranks_checked": len(everyone), "crc32c": crcs}
+
+
+def replicas_ok(check):
+    return bool(check["replicas_bitwise_equal"] and check["rccl_world_size_equals_launcher_world_size"])
+
+
 def extra_workload(w, e, world, rank, local_rank, steps, warmup, sync, torch, dist, force_comm):
     """One more data-parallel line (bench.py --gpus N > 1): `w` with emb_dim e, every rank its own shard; same protocol as the
     headline (REPEATS event-timed repeats of `steps` steps, MAX over ranks, median)."""
@@ -252,6 +281,7 @@ def extra_workload(w, e, world, rank, local_rank, steps, warmup, sync, torch, di
            "value": round(world * steps / el, 2), "unit": "steps/s", "ms_per_step": round(el / steps * 1e3, 4),
            "value_samples": [round(world * steps / t, 2) for t in ev_s],
            "parallelism": parallelism_object(eng, prof, world, max(steps, 16), world * steps * w["B"] / el)}
+    out["parallelism"].update(replica_check(eng, world, dist))
     eng.close()
     return out
 
@@ -345,9 +375,13 @@ def main():
     eng.bench_scores(w["U"], transposed=False, iters=100)          # (clock ramp: the first ~20 ms of work on an idle GPU run slower)
     ms_sc = eng.bench_scores(w["U"], transposed=False, iters=100)
     sc_tf = 2.0 * w["U"] * w["N"] * w["k"] / ms_sc / 1e9
-    os.environ["GANMF_TUNE"] = "score_product=1"      # (read per call) the whole product: both split passes + the GEMM launch
+    user_tune = os.environ.get("GANMF_TUNE")          # (a caller's own plan overrides stay in force for the engines built later)
+    os.environ["GANMF_TUNE"] = (user_tune + "," if user_tune else "") + "score_product=1"      # (read per call) the whole product: both split passes + the GEMM launch
     ms_prod = eng.bench_scores(w["U"], transposed=False, iters=50)
-    del os.environ["GANMF_TUNE"]
+    if user_tune is None:
+        del os.environ["GANMF_TUNE"]
+    else:
+        os.environ["GANMF_TUNE"] = user_tune
     scoring = {"shape": [w["U"], w["N"], w["k"]], "ms": round(ms_sc, 4), "achieved": round(sc_tf, 2),
                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(sc_tf / PEAK_F32_MFMA_TFLOPS, 4),
                "kernel": "gemm_bf16p_persist: persistent 8-wave tile walk over operands split ONCE into three bf16 planes "
@@ -411,6 +445,10 @@ def main():
     run_steps(eng, perm, w["B"], max(steps, 96))      # (at least 48 launches per class: a short K alone averages over too few)
     prof = eng.profile_read()
     eng.profile(False)
+
+    # ---- data-parallel runs verify themselves: replicas bitwise equal after all of the above, RCCL's world = the launcher's ----
+    check = replica_check(eng, world, dist) if (world > 1 or force_comm) else None
+    failed_checks = [] if check is None or replicas_ok(check) else ["configs[1]"]
 
     out = None
     if rank == 0:
@@ -502,6 +540,7 @@ def main():
         }
         if world > 1 or force_comm:
             out["parallelism"] = parallelism_object(eng, prof, world, max(steps, 96), world * done * w["B"] / el)
+            out["parallelism"].update(check)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(urm, params, w, args.cpu_seconds)
     eng.close()
@@ -515,6 +554,7 @@ def main():
                 extra.append(extra_workload(C4_SHARD, e4, world, rank, local_rank, min(steps, 20), min(warmup, 6), sync, torch, dist, force_comm))
             except Exception as ex:      # never lose the headline line to the extra ones (every rank fails or succeeds alike)
                 extra.append({"workload": "configs[3] shard, emb_dim=%d" % e4, "error": "%s: %s" % (type(ex).__name__, ex)})
+        failed_checks += [x["workload"] for x in extra if "parallelism" in x and not replicas_ok(x["parallelism"])]
         if rank == 0:
             out["configs3_sharded"] = extra
     if world > 1:
@@ -523,6 +563,9 @@ def main():
     if rank == 0:
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     os.close(json_fd)
+    if failed_checks:      # (every rank reaches the same verdict: the line is written, the run fails)
+        sys.stderr.write("bench.py: replicated tensors differ between ranks, or RCCL's world size is not the launcher's: %s\n" % failed_checks)
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

@@ -11,9 +11,10 @@ class DisGANMF(GANMF):
     RECOMMENDER_NAME = 'DisGANMF'
 
     def __init__(self, URM_train, mode='user', seed=1234, verbose=False, is_experiment=False, device=0, devices=None,
-                 dist_backend=None, world_size=None):
+                 dist_backend=None, world_size=None, score_contract=None):
         super(DisGANMF, self).__init__(URM_train, mode=mode, verbose=verbose, seed=seed, is_experiment=is_experiment,
-                                       device=device, devices=devices, dist_backend=dist_backend, world_size=world_size)
+                                       device=device, devices=devices, dist_backend=dist_backend, world_size=world_size,
+                                       score_contract=score_contract)
 
     # tensor ids follow tf.get_collection order (DisGANMF.py:121): layer_l/kernel, layer_l/bias, D_output/{kernel,bias}
     def _d_names(self):
@@ -36,7 +37,7 @@ class DisGANMF(GANMF):
                                         d_act=d_hidden_act, mfma=self.mfma, **hp)
         self.engine.set_urm(self._URM_fit)
         self.engine.set_seen(self._URM_eval)
-        self.engine.set_score_filter(None, mask_cold=True)      # MF contract (GANMF._compute_item_score)
+        self._reset_score_filter()      # score_contract (GANMF.__init__): the reference's own semantics unless "mf" was asked for
         self.params = {'D': [_TensorRef(i, n) for i, n in enumerate(self._d_names())],
                        'G': [_TensorRef(t, n) for t, n in self._G_TENSORS]}
         from .GANMF import _SessionShim

@@ -62,9 +62,19 @@ class GANMF(BaseRecommender):
                   (2, 'autoencoder/decoding/kernel'), (3, 'autoencoder/decoding/bias'))
     _G_TENSORS = ((L.T_USER_EMB, 'generator/user_embeddings'), (L.T_ITEM_EMB, 'generator/item_embeddings'))
 
+    SCORE_CONTRACTS = ("ganmf", "mf")
+
     def __init__(self, URM_train, mode='user', verbose=False, seed=1234, is_experiment=False, device=0, devices=None,
-                 dist_backend=None, world_size=None):
-        """`devices` (beyond the reference's signature; also GANMF_DEVICES="0,1,2,3" in the environment, so that the
+                 dist_backend=None, world_size=None, score_contract=None):
+        """`score_contract` (beyond the reference's signature; also GANMF_SCORE_CONTRACT in the environment) selects what
+        `_compute_item_score` / `recommend` / the device evaluator return for the two corners the reference's classes differ in:
+          "ganmf" (default) = GANRec/GANMF.py:285-292 exactly: the class derives from BaseRecommender, every user -- with or
+                    without a training interaction -- gets the finite scores U[ids] . V^T, and `items_to_compute` is accepted
+                    and ignored;
+          "mf"    = Base/BaseMatrixFactorizationRecommender.py:113-119,128-143, the contract the north star names: only
+                    `items_to_compute` keep their scores (the others -inf) and users without a training interaction score
+                    -inf everywhere (empty recommendation lists).
+        `devices` (beyond the reference's signature; also GANMF_DEVICES="0,1,2,3" in the environment, so that the
         reference's drivers need no change): fit() shards the generator's users row-wise over these GPUs, one rank process
         per GPU over RCCL (ganmf_amd/dist.py ShardedEngine; north star: "users shard row-wise across the 8 GPUs of one
         node").  dist_backend="local" + world_size=N (GANMF_DIST_BACKEND / GANMF_WORLD_SIZE) puts N ranks on ONE GPU over the
@@ -88,6 +98,9 @@ class GANMF(BaseRecommender):
         self.devices = list(devices) if devices is not None else None
         self.dist_backend = dist_backend or os.environ.get("GANMF_DIST_BACKEND") or "process"
         self.world_size = world_size if world_size is not None else (int(os.environ["GANMF_WORLD_SIZE"]) if os.environ.get("GANMF_WORLD_SIZE") else None)
+        self.score_contract = score_contract or os.environ.get("GANMF_SCORE_CONTRACT") or "ganmf"
+        if self.score_contract not in self.SCORE_CONTRACTS:
+            raise ValueError("score_contract must be one of %r, given %r" % (self.SCORE_CONTRACTS, self.score_contract))
         self.logsdir = os.path.join('plots', self.RECOMMENDER_NAME, datetime.now().strftime("%Y%m%d-%H%M%S"))
         self.is_experiment = is_experiment
         if not self.is_experiment:
@@ -121,10 +134,14 @@ class GANMF(BaseRecommender):
         self.engine = self._make_engine(num_factors, emb_dim, batch_size, mfma=self.mfma, **hp)
         self.engine.set_urm(self._URM_fit)
         self.engine.set_seen(self._URM_eval)            # for device-side recommend()
-        self.engine.set_score_filter(None, mask_cold=True)      # MF contract: users without a training interaction score -inf
+        self._reset_score_filter()
         self.params = {'D': [_TensorRef(t, n) for t, n in self._D_TENSORS],
                        'G': [_TensorRef(t, n) for t, n in self._G_TENSORS]}
         self.sess = _SessionShim(self)
+
+    def _reset_score_filter(self):
+        """no item filter; the cold-user mask only under the MF contract (the reference's GANMF scores every user)"""
+        self.engine.set_score_filter(None, mask_cold=(self.score_contract == "mf"))
 
     def _sharded(self):
         if self.dist_backend == "local":
@@ -252,26 +269,27 @@ class GANMF(BaseRecommender):
 
     # ---- scoring (GANMF.py:285-292) ---------------------------------------------------------------
     def _compute_item_score(self, user_id_array, items_to_compute=None):
-        """Scores in evaluation orientation with the MF contract's masks (BaseMatrixFactorizationRecommender.py:113-119,128-143):
-        `items_to_compute` given -> every other item is -inf (the reference's GANMF.py:285-292 takes the argument and ignores
-        it); users without a training interaction are -inf everywhere.  Both masks are applied on the device."""
+        """Scores in evaluation orientation.  score_contract "ganmf" (default; GANMF.py:285-292): U[ids] . V^T for every user,
+        `items_to_compute` ignored.  "mf" (BaseMatrixFactorizationRecommender.py:113-119,128-143): `items_to_compute` given ->
+        every other item is -inf; users without a training interaction are -inf everywhere; both masks applied on the device."""
         self._require_engine()
         ids = np.asarray(user_id_array).reshape(-1)
-        if items_to_compute is None:
+        if items_to_compute is None or self.score_contract != "mf":
             return self.engine.scores(ids, transposed=(self.mode == 'item'))
         with self._item_filter(items_to_compute):
             return self.engine.scores(ids, transposed=(self.mode == 'item'))
 
     def _item_filter(self, items_to_compute):
-        """context: scores / recommend / evaluate restricted to `items_to_compute`; the cold-user mask stays on"""
+        """context (MF contract only): scores / recommend / evaluate restricted to `items_to_compute`; the cold-user mask stays on"""
         eng = self.engine
+        reset = self._reset_score_filter
 
         class _Ctx(object):
             def __enter__(self_inner):
                 eng.set_score_filter(items_to_compute, mask_cold=True)
 
             def __exit__(self_inner, *exc):
-                eng.set_score_filter(None, mask_cold=True)
+                reset()
                 return False
         return _Ctx()
 
@@ -286,7 +304,7 @@ class GANMF(BaseRecommender):
         self._require_engine()
         ids = np.atleast_1d(np.asarray(user_id_array)).reshape(-1)
         if 1 <= cutoff <= min(self._DEVICE_TOPK_MAX, self.n_items):
-            if items_to_compute is None:
+            if items_to_compute is None or self.score_contract != "mf":
                 items, _ = self.engine.recommend(ids, cutoff, transposed=(self.mode == 'item'), remove_seen=remove_seen_flag)
             else:
                 with self._item_filter(items_to_compute):

@@ -20,7 +20,7 @@ PROF_MAX = 48
 
 # every exported symbol of include/ganmf_hip.h (checked by tests/test_abi.py)
 SYMBOLS = [
-    "ganmf_create", "ganmf_destroy", "ganmf_comm_unique_id", "ganmf_comm_init", "ganmf_comm_init_local", "ganmf_comm_info", "ganmf_set_urm_csr",
+    "ganmf_create", "ganmf_destroy", "ganmf_comm_unique_id", "ganmf_comm_init", "ganmf_comm_init_local", "ganmf_comm_abort", "ganmf_comm_info", "ganmf_set_urm_csr",
     "ganmf_set_tensor", "ganmf_get_tensor", "ganmf_tensor_shape", "ganmf_get_adam_powers",
     "ganmf_set_adam_powers", "ganmf_train_epoch", "ganmf_train_epoch_ragged", "ganmf_train_step", "ganmf_scores",
     "ganmf_set_seen_csr", "ganmf_set_score_filter", "ganmf_recommend", "ganmf_set_test_csr", "ganmf_evaluate", "ganmf_snapshot_best", "ganmf_restore_best", "ganmf_profile_enable", "ganmf_profile_read", "ganmf_stream_timer",
@@ -79,6 +79,7 @@ def load_library():
         "ganmf_comm_unique_id": (C.c_int, [P(C.c_uint8)]),
         "ganmf_comm_init": (C.c_int, [vp, P(C.c_uint8)]),
         "ganmf_comm_init_local": (C.c_int, [vp, i32]),
+        "ganmf_comm_abort": (C.c_int, [vp]),
         "ganmf_comm_info": (C.c_int, [vp, P(i32), P(i32)]),
         "ganmf_set_urm_csr": (C.c_int, [vp, P(C.c_int64), P(C.c_int32), f32p, i64, i64]),
         "ganmf_set_tensor": (C.c_int, [vp, C.c_int, C.c_int, f32p, i64]),

@@ -16,6 +16,8 @@ enum Scal : int {
   S_ALPHA_D_ALT = 6,                                   // lr_t of odd discriminator steps (data-parallel: step i's encoder update still
                                                        // reads its lr_t on the side lane while step i+1 opens on the main lane)
   S_SUM_REAL = 8, S_SUM_FAKE = 9, S_SUM_FM = 10,        // sum of squares (local, then all-reduced)
+  S_B1P_G_SAVED = 12, S_B2P_G_SAVED = 13,              // the generator's beta powers as they were before a staged discriminator pass opened
+                                                       // the call's first generator pass early (rolled back when a D step fails)
   S_COUNT = 16,
   S_TAB = 16                                           // from here: lr_t of every discriminator step of a staged pass (open_steps_kernel), one slot per step
 };
@@ -75,7 +77,10 @@ __device__ __forceinline__ void densify_row_body(const DensP& d, const int bid) 
   const bool staged = d.stage_b > 0;
   if (staged && bid == 0 && threadIdx.x == 0) {
     if (d.open_d_count > 0) open_steps_body(d.scal, 0, d.open_d_slot, d.open_d_count, d.lr_d);
-    if (d.open_g_count > 0) open_steps_body(d.scal, 1, d.open_g_slot, d.open_g_count, d.lr_g);
+    if (d.open_g_count > 0) {
+      d.scal[S_B1P_G_SAVED] = d.scal[S_B1P_G]; d.scal[S_B2P_G_SAVED] = d.scal[S_B2P_G];
+      open_steps_body(d.scal, 1, d.open_g_slot, d.open_g_count, d.lr_g);
+    }
   }
   if (!staged && d.alpha_idx >= 0 && bid == 0 && threadIdx.x == 0) {      // (alpha_idx < 0: the pass opened its steps at once, open_steps_kernel)
     const int o = d.which ? S_B1P_G : S_B1P_D;
@@ -263,6 +268,10 @@ __device__ __forceinline__ void open_steps_body(float* __restrict__ scal, int wh
   }
   scal[o] = b1p;
   scal[o + 1] = b2p;
+}
+// a failed discriminator pass: the generator steps that its staged row expansion opened ahead of time never ran
+__global__ void restore_g_powers_kernel(float* __restrict__ scal) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) { scal[S_B1P_G] = scal[S_B1P_G_SAVED]; scal[S_B2P_G] = scal[S_B2P_G_SAVED]; }
 }
 __global__ void open_steps_kernel(float* __restrict__ scal, int which, int first_slot, int count, float lr) {
   if (blockIdx.x == 0 && threadIdx.x == 0) open_steps_body(scal, which, first_slot, count, lr);

@@ -196,7 +196,20 @@ class _ThreadRank(object):
         self._t.join(timeout)
         return not self._t.is_alive()
 
-    def kill(self):      # (threads cannot be ended; the loopback group is marked failed when an engine closes, which wakes its peers)
+    def kill(self):
+        """A peer failed.  Threads cannot be ended, and the engine must not be destroyed under a thread that is still inside a
+        library call on it: the loopback group is marked failed (ganmf_comm_abort touches nothing but the group's own state),
+        which makes the call in flight return with an error; the engine is closed once its thread has come back."""
+        eng = self.eng
+        if eng is not None and hasattr(eng, "comm_abort"):
+            try:
+                eng.comm_abort()
+            except Exception:
+                pass
+        if self._t is not None:
+            self._t.join(150.0)      # (the loopback rendezvous itself gives up after 120 s)
+            if self._t.is_alive():
+                return               # never free a handle that is in use: leak it instead
         self.close()
 
     def result(self, timeout=600.0):
@@ -209,6 +222,8 @@ class _ThreadRank(object):
         return out
 
     def close(self):
+        if self._t is not None and self._t.is_alive():      # a request still inside the library (kill() gave up on it): the handle stays
+            return
         if self.eng is not None:
             self.eng.close()
             self.eng = None

@@ -221,6 +221,12 @@ class Engine:
         L.check(self.lib.ganmf_comm_info(self.h, C.byref(w), C.byref(r)), "ganmf_comm_info")
         return int(w.value), int(r.value)
 
+    def comm_abort(self):
+        """end this engine's communicator from ANOTHER thread than the one inside a training call (ganmf_comm_abort): the
+        call in flight returns with an error instead of waiting for a peer that failed; close() is what is left to do"""
+        if self.h:
+            L.check(self.lib.ganmf_comm_abort(self.h), "ganmf_comm_abort")
+
     def comm_init_local(self, group_id):
         """join the in-process loopback communicator `group_id` (all world_size engines of this process must)"""
         L.check(self.lib.ganmf_comm_init_local(self.h, int(group_id)), "ganmf_comm_init_local")

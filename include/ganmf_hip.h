@@ -102,6 +102,12 @@ int ganmf_comm_info(ganmf_handle* h, int32_t* world_size, int32_t* rank);
  * (same process, same device, one host thread each) all-reduce among themselves by rendezvous; sums run in rank
  * order.  For exercising the data-parallel path with world_size > 1 on one GPU (tests/test_gpu_dist_local.py). */
 int ganmf_comm_init_local(ganmf_handle* h, int32_t group_id);
+/* Ends the handle's communicator WITHOUT touching anything else of the handle: the loopback group is marked failed and its waiting
+ * members wake up with an error; an RCCL communicator is aborted (ncclCommAbort).  The one entry point that may be called from
+ * another host thread while the handle's own thread is inside a training call -- how a driver whose peer rank failed gets the
+ * survivors out of a collective that can no longer complete, BEFORE it destroys their handles (ganmf_amd/dist.py _ThreadRank.kill).
+ * Training calls on the handle fail from then on; ganmf_destroy is the only thing left to do with it. */
+int ganmf_comm_abort(ganmf_handle* h);
 
 /* Replaces the per-minibatch host work `URM_train[uids].toarray()` + feed_dict upload
  * (GANMF.py:183-187,198-201): the CSR matrix (training orientation, this handle's rows) is

@@ -299,6 +299,27 @@ def mf_contract_golden():
         for i, l in enumerate(lists):
             pad[i, :len(l)] = l
         out[name] = pad
+
+    # The reference's OWN GANMF contract on the same matrix and factors (GANRec/GANMF.py:285-292): the class derives from
+    # BaseRecommender (no cold-user mask), `_compute_item_score` is the plain product U[ids] . V^T for every user and takes
+    # `items_to_compute` without reading it.  The product is restated here (the TF session cannot run); everything around it --
+    # seen-item removal, partition / sort order, -inf filtering of the lists -- is the reference's own BaseRecommender.recommend.
+    from Base.BaseRecommender import BaseRecommender
+
+    class RefGANMFScores(BaseRecommender):
+        RECOMMENDER_NAME = "ganmf_contract"
+
+        def _compute_item_score(self, user_id_array, items_to_compute=None):
+            return np.dot(U[np.asarray(user_id_array).reshape(-1)], V.T)
+
+    rec = RefGANMFScores(urm)
+    out["ganmf_scores_all"] = rec._compute_item_score(users)
+    for name, kw in (("ganmf_rank_all_seen", dict(remove_seen_flag=True)), ("ganmf_rank_subset_seen", dict(remove_seen_flag=True, items_to_compute=items)),
+                     ("ganmf_rank_all_unseen", dict(remove_seen_flag=False))):
+        lists = rec.recommend(users, cutoff=10, **kw)
+        assert all(len(l) == 10 for l in lists)      # every user, cold or not, is recommended items
+        out[name] = np.array(lists, dtype=np.int32)
+    assert np.array_equal(out["ganmf_rank_all_seen"], out["ganmf_rank_subset_seen"])      # items_to_compute changes nothing
     np.savez_compressed(os.path.join(OUT, "mf_contract.npz"), **out)
     print("MF contract fixture: %d users (%d cold), %d of %d items to compute" % (len(users), len(cold), len(items), n_items))
 

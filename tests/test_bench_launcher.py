@@ -87,3 +87,80 @@ def test_parallelism_object_shape():
     assert p["per_tensor"]["Wd"]["exposed_us_per_step"] == 0.0
     assert p["collective_us_per_step"] == 160.0 and p["exposed_collective_us_per_step"] == 5.0 and p["adam_slice_us_per_step"] == 20.0
     json.dumps(p)
+
+
+class _ReplicaEng(object):
+    """stand-in engine: five replicated tensors, what RCCL would report as its world size"""
+
+    def __init__(self, seed, comm_world):
+        import numpy as np
+        self.t = {tid: np.random.RandomState(seed + tid).rand(7, 5).astype(np.float32) for tid in (0, 1, 2, 3, 101)}
+        self.comm_world = comm_world
+
+    def get_tensor(self, tid):
+        return self.t[tid]
+
+    def comm_info(self):
+        return self.comm_world, 0
+
+
+def test_replica_check_fields_single_rank():
+    """GANMF_BENCH_FORCE_COMM=1 on one GPU: one rank, trivially equal, RCCL world 1 = launcher world 1; a communicator that reports
+    another size than the launcher started fails the check."""
+    import zlib
+    b = _bench()
+    crc = lambda a: zlib.crc32(a.tobytes())
+    c = b.replica_check(_ReplicaEng(1, 1), 1, None, crc=crc)
+    assert c["replicas_bitwise_equal"] is True and c["rccl_world_size_equals_launcher_world_size"] is True and c["ranks_checked"] == 1
+    assert set(c["crc32c"]) == {"We", "be", "Wd", "bd", "V"} and all(isinstance(v, str) and len(v) == 8 for v in c["crc32c"].values())
+    assert b.replicas_ok(c)
+    bad = b.replica_check(_ReplicaEng(1, 2), 1, None, crc=crc)
+    assert bad["rccl_world_size_equals_launcher_world_size"] is False and not b.replicas_ok(bad)
+    json.dumps(c)
+
+
+@pytest.mark.parametrize("diverge", [False, True])
+def test_replica_check_over_gloo_world_2(tmp_path, capfd, diverge):
+    """Two rank processes started by bench.launch_ranks, gloo control plane, stand-in engines: equal replicas -> true on every rank;
+    one element of one tensor different on rank 1 -> false, with the per-rank CRCs of that tensor in the object, on EVERY rank (each
+    must reach the verdict that makes it exit non-zero)."""
+    script = tmp_path / "rank.py"
+    script.write_text(textwrap.dedent("""
+        import importlib.util, json, os, sys, zlib
+        import numpy as np
+        import torch.distributed as dist
+        rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        spec = importlib.util.spec_from_file_location("bench_under_test", %r)
+        b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
+        class Eng(object):
+            def __init__(self):
+                self.t = {tid: np.random.RandomState(tid).rand(33, 9).astype(np.float32) for tid in (0, 1, 2, 3, 101)}
+                if %r and rank == 1:
+                    self.t[2][5, 3] = np.nextafter(self.t[2][5, 3], np.float32(2.0))      # one ulp in one element of Wd
+            def get_tensor(self, tid): return self.t[tid]
+            def comm_info(self): return world, rank
+        c = b.replica_check(Eng(), world, dist, crc=lambda a: zlib.crc32(a.tobytes()))
+        open(os.path.join(%r, "check%%d.json" %% rank), "w").write(json.dumps(c))
+        dist.barrier(); dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"parallelism": c}))
+        sys.exit(0 if b.replicas_ok(c) else 3)
+    """ % (os.path.join(ROOT, "bench.py"), diverge, str(tmp_path))))
+    b = _bench()
+    if diverge:
+        with pytest.raises(SystemExit) as ex:
+            b.launch_ranks(2, [], script=str(script))
+        assert ex.value.code == 1
+    else:
+        b.launch_ranks(2, [], script=str(script))
+        line = json.loads(capfd.readouterr().out.strip().splitlines()[-1])
+        assert line["parallelism"]["replicas_bitwise_equal"] is True
+    checks = [json.load(open(tmp_path / ("check%d.json" % r))) for r in range(2)]
+    assert checks[0] == checks[1] and checks[0]["ranks_checked"] == 2
+    assert checks[0]["replicas_bitwise_equal"] is (not diverge)
+    assert checks[0]["rccl_world_size_equals_launcher_world_size"] is True
+    if diverge:
+        assert isinstance(checks[0]["crc32c"]["Wd"], list) and len(set(checks[0]["crc32c"]["Wd"])) == 2
+        assert all(isinstance(checks[0]["crc32c"][n], str) for n in ("We", "be", "bd", "V"))

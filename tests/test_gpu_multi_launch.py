@@ -149,3 +149,41 @@ def test_per_pass_forms_are_bit_identical(case, monkeypatch):
         assert set(ref) == set(got)
         for n in ref:
             np.testing.assert_array_equal(got[n], ref[n], err_msg="%s, %s" % (n, tune))
+
+
+def test_lazy_pass_arena_pads_are_zero_whatever_the_allocator_returns(monkeypatch):
+    """The per-pass gUb arena (lib/step_ganmf.inc lazy_chunk_alloc) comes from plain hipMalloc; GEMM and slab stores mask the columns
+    >= k, and adam_rows_flush_kernel applies the update to whole ldk-wide rows.  A recycled allocation holding a NaN bit pattern in a
+    pad column would therefore reach the pads of user_embeddings and, through F = Ub . V^T, every score.  The test fills device
+    memory of the arena's size classes with 0xFF bytes (a NaN pattern), frees it, and then runs lazy generator passes with k far from
+    a multiple of 64: scores must stay finite and equal the per-step path bit for bit."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+    hip.hipFree.argtypes = [C.c_void_p]
+
+    def poison():
+        blocks = []
+        for size in [64 << 20] * 6 + [512 << 20, 128 << 20, 32 << 20, 16 << 20]:
+            p = C.c_void_p()
+            if hip.hipMalloc(C.byref(p), size) != 0:
+                break
+            assert hip.hipMemset(p, 0xFF, size) == 0
+            blocks.append(p)
+        assert hip.hipDeviceSynchronize() == 0
+        for p in blocks:
+            assert hip.hipFree(p) == 0
+        assert len(blocks) >= 6
+
+    U, N, k, e, B = 700, 1100, 20, 64, 32
+    hp = dict(d_lr=1e-4, g_lr=2e-4, d_reg=1e-4, g_reg=0.0, m=10.0, recon_coefficient=0.05)
+    ref, ref_l = _run_staged(monkeypatch, "pass_stage=0,lazy_rows=0", "ganmf", U, N, k, e, B, hp, 3, 1, 2)
+    poison()
+    got, got_l = _run_staged(monkeypatch, "pass_stage=1,lazy_rows=1", "ganmf", U, N, k, e, B, hp, 3, 1, 2)
+    assert np.all(np.isfinite(got["scores"]))
+    for n in ref:
+        np.testing.assert_array_equal(got[n], ref[n], err_msg=n)
+    for (dl, gl), (dr, gr) in zip(got_l, ref_l):
+        np.testing.assert_array_equal(dl, dr)
+        np.testing.assert_array_equal(gl, gr)

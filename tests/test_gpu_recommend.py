@@ -230,43 +230,103 @@ def test_device_metrics_reject_bad_input():
 
 @pytest.mark.parametrize("mode", ["user", "item"])
 def test_mf_contract_items_to_compute_and_cold_users(mode, golden_dir):
-    """Base/BaseMatrixFactorizationRecommender.py:113-119,128-143 through the HIP path: the expected scores and rankings were
-    produced by the reference's own class (oracle/make_golden.py::mf_contract_golden).  Item mode scores the same evaluation
-    matrix from the transposed model (generator rows = items)."""
+    """BOTH scoring contracts through the HIP path on one matrix with cold training rows (fixture: oracle/make_golden.py::
+    mf_contract_golden, expected outputs produced by the reference's own classes):
+      score_contract="mf"    Base/BaseMatrixFactorizationRecommender.py:113-119,128-143 -- `items_to_compute` masks the other
+                             items, users without a training interaction score -inf everywhere and are recommended nothing;
+      score_contract="ganmf" (default) GANRec/GANMF.py:285-292 -- plain U[ids] . V^T for every user, `items_to_compute` ignored:
+                             a cold training row is recommended items.
+    Scores, the device top-k route, the host route and the device evaluator.  Item mode scores the same evaluation matrix from
+    the transposed model (generator rows = items)."""
     from ganmf_amd.GANMF import GANMF
+    from ganmf_amd.evaluation import EvaluatorHoldoutFast
     g = np.load(os.path.join(golden_dir, "mf_contract.npz"))
     n_users, n_items = (int(x) for x in g["urm_shape"])
     urm = sps.csr_matrix((np.ones(len(g["urm_indices"]), np.float32), g["urm_indices"], g["urm_indptr"]), shape=(n_users, n_items))
     k = g["U"].shape[1]
-    model = GANMF(urm, mode=mode, is_experiment=True)
-    model._build(k, 16, 32)
-    # the evaluation-orientation factors of the fixture: in item mode the generator's "users" are the catalogue items
-    model.engine.set_tensor(100, g["U"] if mode == "user" else g["V"])
-    model.engine.set_tensor(101, g["V"] if mode == "user" else g["U"])
-    model.URM_train = model._URM_eval
-    users, items = g["users"], g["items_to_compute"]
+    users, items, cold = g["users"], g["items_to_compute"], g["cold_users"]
+
+    def build(**kw):
+        model = GANMF(urm, mode=mode, is_experiment=True, **kw)
+        model._build(k, 16, 32)
+        # the evaluation-orientation factors of the fixture: in item mode the generator's "users" are the catalogue items
+        model.engine.set_tensor(100, g["U"] if mode == "user" else g["V"])
+        model.engine.set_tensor(101, g["V"] if mode == "user" else g["U"])
+        model.URM_train = model._URM_eval
+        return model
 
     def same(got, want):
         assert np.array_equal(np.isneginf(got), np.isneginf(want))
         fin = np.isfinite(want)
         assert np.abs(got[fin] - want[fin]).max() <= 2e-6 * np.abs(want[fin]).max()
 
+    pad = lambda lists: np.array([l + [-1] * (10 - len(l)) for l in lists], dtype=np.int32)
+
+    # ---- the MF contract ------------------------------------------------------------------------------------------------------
+    model = build(score_contract="mf")
     same(model._compute_item_score(users), g["scores_all"])                                   # cold users: -inf everywhere
     same(model._compute_item_score(users, items_to_compute=items), g["scores_subset"])        # other items: -inf
-    assert np.all(np.isneginf(model._compute_item_score(g["cold_users"])))
-    pad = lambda lists: np.array([l + [-1] * (10 - len(l)) for l in lists], dtype=np.int32)
+    assert np.all(np.isneginf(model._compute_item_score(cold)))
     # device top-k route (scores never leave the GPU) and the host route (return_scores) agree with the reference's lists
     assert np.array_equal(pad(model.recommend(users, cutoff=10, remove_seen_flag=True)), g["rank_all_seen"])
     assert np.array_equal(pad(model.recommend(users, cutoff=10, remove_seen_flag=True, items_to_compute=items)), g["rank_subset_seen"])
     assert np.array_equal(pad(model.recommend(users, cutoff=10, remove_seen_flag=False, items_to_compute=items)), g["rank_subset_unseen"])
     host_lists, _ = model.recommend(users, cutoff=10, remove_seen_flag=True, items_to_compute=items, return_scores=True)
     assert np.array_equal(pad(host_lists), g["rank_subset_seen"])
+    assert all(len(l) == 0 for l in model.recommend(cold, cutoff=10))
     # the filter does not leak into later calls
     same(model._compute_item_score(users), g["scores_all"])
     # engine-level errors: an item beyond the score width, cold masking without the seen matrix
     from ganmf_amd import _lib as L
     with pytest.raises(L.GanmfError):
         model.engine.set_score_filter([10 ** 6], mask_cold=True)
+    mf = model
+
+    # ---- the reference GANMF's own contract (the default) ---------------------------------------------------------------------
+    model = build()
+    assert model.score_contract == "ganmf"
+    want = g["ganmf_scores_all"]
+    assert np.all(np.isfinite(want))
+    same(model._compute_item_score(users), want)
+    same(model._compute_item_score(users, items_to_compute=items), want)                      # accepted and ignored
+    assert np.all(np.isfinite(model._compute_item_score(cold)))
+    assert np.array_equal(pad(model.recommend(users, cutoff=10, remove_seen_flag=True)), g["ganmf_rank_all_seen"])
+    assert np.array_equal(pad(model.recommend(users, cutoff=10, remove_seen_flag=True, items_to_compute=items)), g["ganmf_rank_subset_seen"])
+    assert np.array_equal(pad(model.recommend(users, cutoff=10, remove_seen_flag=False)), g["ganmf_rank_all_unseen"])
+    host_lists, _ = model.recommend(users, cutoff=10, remove_seen_flag=True, items_to_compute=items, return_scores=True)
+    assert np.array_equal(pad(host_lists), g["ganmf_rank_all_seen"])
+    assert all(len(l) == 10 for l in model.recommend(cold, cutoff=10))                        # a cold training row IS recommended items
+
+    # ---- device evaluator: test items of the cold rows count under "ganmf" and cannot be hit under "mf" -------------------------
+    # test matrix: for every fixture user, the first three items of the reference GANMF's own list -> each of them is a hit
+    t = sps.lil_matrix((n_users, n_items), dtype=np.float32)
+    for u, row in zip(users, g["ganmf_rank_all_seen"]):
+        t[int(u), [int(i) for i in row[:3]]] = 1.0
+    test = t.tocsr()
+    res = {}
+    for name, m in (("ganmf", model), ("mf", mf)):
+        ev = EvaluatorHoldoutFast(test, [5])
+        assert ev.use_device_metrics
+        dev, _ = ev.evaluateRecommender(m)
+        ev.use_device_metrics = False
+        host, _ = ev.evaluateRecommender(m)
+        for key in ("PRECISION", "RECALL", "MAP", "NDCG"):
+            assert abs(dev[5][key] - host[5][key]) <= 1e-12, (name, key)
+        res[name] = dev[5]
+    n_cold = sum(1 for u in users if u in set(cold.tolist()))
+    assert n_cold == 3
+    assert abs(res["ganmf"]["RECALL"] - 1.0) <= 1e-12                                          # every user's three test items are in the top five
+    assert abs(res["mf"]["RECALL"] - (len(users) - n_cold) / len(users)) <= 1e-12             # the cold rows are recommended nothing
+    # environment switch (the reference's drivers construct the class themselves)
+    os.environ["GANMF_SCORE_CONTRACT"] = "mf"
+    try:
+        assert GANMF(urm, mode=mode, is_experiment=True).score_contract == "mf"
+    finally:
+        del os.environ["GANMF_SCORE_CONTRACT"]
+    with pytest.raises(ValueError):
+        GANMF(urm, mode=mode, is_experiment=True, score_contract="other")
+    model.engine.close()
+    mf.engine.close()
 
 
 def test_concurrent_engines_bit_identical(golden_dir):

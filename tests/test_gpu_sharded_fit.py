@@ -247,3 +247,49 @@ def test_process_backend_one_rank_rccl_collectives_execute(monkeypatch):
     finally:
         sh.close()
         plain.close()
+
+
+def test_two_rank_process_backend():
+    """TWO rank processes on two real devices over an RCCL communicator of world size 2 -- the production form of the sharded fit
+    (GANRec/GANMF.py:146-149 is the single session it replaces) -- against the union-batch fp64 oracle and the plain single-GPU
+    engine: the owner-split schedule of ShardedEngine makes the union over ranks of step i the reference's minibatch i.  Skipped on
+    a one-GPU box (RCCL takes one rank per device); the day a box with two devices runs the suite, this path is checked."""
+    from ganmf_amd import _lib as L
+    from ganmf_amd.dist import ShardedEngine
+    from ganmf_amd.engine import Engine
+    if L.load_library().ganmf_device_count() < 2:
+        pytest.skip("needs two GPUs: one RCCL rank per device")
+    rng = np.random.RandomState(12)
+    U, N, k, e, B = 301, 420, 13, 40, 64
+    urm = _urm(rng, U, N, 0.06)
+    hp = dict(d_lr=1e-3, g_lr=1e-3, d_reg=1e-4, g_reg=0.0, m=5.0, recon_coefficient=0.1)
+    o = GANMFOracle(U, N, k, e, dtype=np.float64, seed=4, **hp)
+    w0 = o.get_params()
+    sh = ShardedEngine(U, N, k, e, B, devices=[0, 1], backend="process", **hp)
+    plain = Engine(U, N, k, e, B, **hp)
+    try:
+        assert sh.world == 2
+        for eng in (sh, plain):
+            eng.set_urm(urm)
+            for n, tid in (("We", 0), ("be", 1), ("Wd", 2), ("bd", 3), ("U", 100), ("V", 101)):
+                eng.set_tensor(tid, w0[n])
+        for ep in range(3):
+            perm = rng.permutation(U)
+            dl_ref, gl_ref = o.train_epoch(urm, perm, B)
+            dl0, gl0 = plain.train_epoch(perm, 1, 1)
+            dl1, gl1 = sh.train_epoch(perm, 1, 1)
+            np.testing.assert_allclose(dl1, dl_ref, rtol=1e-4)
+            np.testing.assert_allclose(gl1, gl_ref, rtol=1e-4)
+            np.testing.assert_allclose(dl1, dl0, rtol=1e-5)
+        for n, tid in (("We", 0), ("be", 1), ("Wd", 2), ("bd", 3), ("U", 100), ("V", 101)):
+            got = sh.get_tensor(tid)
+            assert _err(got, o.p[n]) <= 1e-4, n
+            assert _err(got, plain.get_tensor(tid).astype(np.float64)) <= 1e-4, n
+        assert _err(sh.scores(np.arange(32)), o.scores(np.arange(32))) <= 1e-4
+        # every rank holds the same replicated tensors, bit for bit (one writer per slice, then all-gather)
+        for tid in (0, 1, 2, 3, 101):
+            copies = sh._all("get_tensor", tid)
+            np.testing.assert_array_equal(copies[0], copies[1])
+    finally:
+        sh.close()
+        plain.close()
