@@ -172,7 +172,9 @@ __device__ __forceinline__ void bf16k_mainloop(const GemmP& p, const int tm, con
       pc[0][0] += (unsigned)tok;
     } else
 #endif
-    it.template split<NPIECE, F16>(v, pc, it.km != (tok != 0), my_scale);
+    // (the fp16 form multiplies every element by the scale before anything selects on the token: there the scale carries the dependency
+    // on the wait -- without it nothing orders `a.x * scale` behind the wait but the scheduler's habit, tools/check_asm_prefetch.py)
+    it.template split<NPIECE, F16>(v, pc, it.km != (tok != 0), F16 ? __uint_as_float(__float_as_uint(my_scale) | (unsigned)tok) : my_scale);
     unsigned* o = my_planes + b * BF16K_OPER;
 #pragma unroll
     for (int q = 0; q < NPIECE; ++q) *reinterpret_cast<u32x4*>(o + q * FA::PLANE) = pc[q];
