@@ -1057,6 +1057,7 @@ struct GemmPlan {
   int sq_count = 0;          // sq partial entries per batch this plan produces
   int tile_order = 0;        // GemmTune::tile_order
   int skinny = 0;            // > 0: the streaming kernel for K <= 64 (gemm_skinny.hpp), this many rows per wave
+  int skinny_n = 0;          // 1: the streaming kernel for N <= 32 behind a long K (gemm_skinny.hpp, gemm_skinny_n_kernel)
   double est_us = 0;
 };
 
@@ -1230,9 +1231,11 @@ inline void choose_tile_order(GemmP& p, const GemmPlan& pl) {
 }
 
 inline hipError_t gemm_dispatch_skinny(hipStream_t st, const GemmP& p0, bool bkm, int rt);
+inline hipError_t gemm_dispatch_skinny_n(hipStream_t st, const GemmP& p0, bool bkm);
 
 inline hipError_t gemm_dispatch(hipStream_t st, const GemmP& p0, bool akm, bool bkm, const GemmPlan& pl) {
   if (pl.skinny) return gemm_dispatch_skinny(st, p0, bkm, pl.skinny);
+  if (pl.skinny_n) return gemm_dispatch_skinny_n(st, p0, bkm);
   if (pl.persist) return gemm_dispatch_persist(st, p0, akm, bkm, pl);
   GemmP p = p0;
   choose_tile_order(p, pl);

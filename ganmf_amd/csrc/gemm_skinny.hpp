@@ -202,4 +202,158 @@ inline hipError_t gemm_dispatch_skinny(hipStream_t st, const GemmP& p0, bool bkm
   return hipGetLastError();
 }
 
+
+// ---- Skinny-N products (round 5): C[M, N <= 32] = A[M, K] . op(B) with a LONG K ---------------------------------------------------------------
+// The encode product and dE of a narrow autoencoder (emb_dim 32: the reference's default, GANMF.py:88, and BASELINE configs[3] at e = 32) read a
+// [2B, 50 000] activation matrix (51 MB) for a [2B, 32] result: every A element is used ONCE, the product is a stream over A with 16 FLOP per
+// byte.  The tiled kernels give such a product 64 x 64 tiles of which half the columns are padding, stage A through LDS and walk K in 64-wide
+// tiles behind a barrier each: 2.3-3.0 TB/s (encode 19.5 us, dE + d_coef 21.4 us at the configs[3] shard).  Here a workgroup of eight waves owns
+// ALL rows of a 256-row block and one 256-wide K slice; wave w = the 32 x 32 output block of rows 32 w .. 32 w + 31:
+//   * A goes from global memory STRAIGHT into MFMA operand registers: lane (i, h) loads the 32 bytes k = 16 s + 8 h .. + 7 of row i for step s
+//     -- exactly its fragment of v_mfma_f32_32x32x16_bf16 -- and splits them (the exact three-way split of gemm_bf16s.hpp, once per element:
+//     nobody else reads them); the slice is fully unrolled, so the sixteen loads a lane keeps in flight are counted exactly by the compiler;
+//   * the B slice [256][32] is split ONCE per workgroup into three bf16 planes [n][256 k] in LDS (row stride 264: conflict-free ds_read_b128);
+//   * the same six piece products in the same order into the same two accumulators as every split-bf16 kernel of the library (fp32-accurate).
+//     (A first version ran the fp32 MFMA on the raw operands: 128 dependent 64-cycle MFMAs per wave = 8 us of matrix pipe per CU, 19 us per
+//     launch against 23 for the tiled kernel; the split form needs 3.6 us of SIMD time.)
+// Output: one fp32 slab per K slice, summed by splitk_reduce_kernel with the product's epilogue as for every split product (fixed order).
+constexpr int SKN_KPS = 256;          // K slice of a workgroup (GemmPlan::kps)
+constexpr int SKN_STEPS = SKN_KPS / 16;
+constexpr int SKN_PF = 8;             // steps (two 16-byte loads per lane each) in flight
+constexpr int SKN_NMAX = 32;
+constexpr int SKN_BM = 256;
+constexpr int SKN_LDP = SKN_KPS / 2 + 4;      // dwords per plane row: 256 bf16 + 16 bytes
+constexpr int SKN_PLANE = 32 * SKN_LDP;       // dwords per piece plane
+
+template <bool BKM>
+__global__ __launch_bounds__(512) void gemm_skinny_n_kernel(const GemmP p) {
+  __shared__ __attribute__((aligned(16))) unsigned skn_planes[3 * SKN_PLANE];      // 49.5 KiB
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int sp = (int)blockIdx.x % p.nsplit, tm = (int)blockIdx.x / p.nsplit;
+  const int kbeg = sp * p.k_per_split;
+
+  // ---- this lane's A stream: requested first, SKN_PF steps deep
+  const int row = tm * SKN_BM + wave * 32 + li;
+  const bool row_ok = row < p.M;
+  const float* __restrict__ arow = p.A + (size_t)(row_ok ? row : 0) * p.lda;
+  auto a_src = [&](int s, int half) -> const float* {      // 16 bytes: k = kbeg + 16 s + 8 lh + 4 half .. + 3 (pad columns up to lda are zero; past lda: the zero page)
+    const int k = kbeg + 16 * s + 8 * lh + 4 * half;
+    return (row_ok && k + 3 < p.lda) ? arow + k : p.zero_page + 4 * (lane & 7);
+  };
+  sk_f4 ra[SKN_PF][2];
+#pragma unroll
+  for (int s = 0; s < SKN_PF; ++s) {
+    ra[s][0] = *reinterpret_cast<const sk_f4*>(a_src(s, 0));
+    ra[s][1] = *reinterpret_cast<const sk_f4*>(a_src(s, 1));
+  }
+
+  // ---- B slice -> three bf16 planes [n][k] in LDS (elements past K or N are zero: A's zero padding then meets zeros, never another tensor's
+  // bytes).  One item = row n, eight consecutive k: 1024 items, two per thread.
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int idx = tid + it * 512;
+    int n, q;
+    float x[8];
+    if constexpr (BKM) {      // B is [K, ldb] row-major: consecutive lanes take consecutive columns n (128-byte rows)
+      n = idx & 31; q = idx >> 5;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = kbeg + 8 * q + j;
+        x[j] = (n < p.N && k < p.K) ? p.B[(size_t)k * p.ldb + n] : 0.f;
+      }
+    } else {                  // B is [N, ldb], K-contiguous: element (k, n) = B[n * ldb + k]; consecutive lanes take consecutive k groups
+      q = idx & 31; n = idx >> 5;
+      const int k = kbeg + 8 * q;
+      const float* src = p.B + (size_t)n * p.ldb + k;
+      if (n < p.N && k + 7 < p.K) {
+        const float4 v0 = *reinterpret_cast<const float4*>(src), v1 = *reinterpret_cast<const float4*>(src + 4);
+        x[0] = v0.x; x[1] = v0.y; x[2] = v0.z; x[3] = v0.w; x[4] = v1.x; x[5] = v1.y; x[6] = v1.z; x[7] = v1.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = (n < p.N && k + j < p.K) ? src[j] : 0.f;
+      }
+    }
+    u32x4 pc[3];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      unsigned hh, mm, ll;
+      split_bf16x3(x[2 * j], x[2 * j + 1], hh, mm, ll);
+      pc[0][j] = hh; pc[1][j] = mm; pc[2][j] = ll;
+    }
+#pragma unroll
+    for (int pi = 0; pi < 3; ++pi) *reinterpret_cast<u32x4*>(skn_planes + pi * SKN_PLANE + n * SKN_LDP + 4 * q) = pc[pi];
+  }
+  __syncthreads();
+
+  f32x16 acc, accl;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc[r] = 0.f; accl[r] = 0.f; }
+  const unsigned* __restrict__ bl = skn_planes + li * SKN_LDP + 4 * lh;      // this lane's fragment of step 0, piece 0
+#pragma unroll
+  for (int s = 0; s < SKN_STEPS; ++s) {
+    const sk_f4 a0 = ra[s % SKN_PF][0], a1 = ra[s % SKN_PF][1];
+    u32x4 pa[3], pb[3];
+#pragma unroll
+    for (int pi = 0; pi < 3; ++pi) pb[pi] = *reinterpret_cast<const u32x4*>(bl + pi * SKN_PLANE + 8 * s);
+    {
+      unsigned hh, mm, ll;
+      split_bf16x3(a0.x, a0.y, hh, mm, ll); pa[0][0] = hh; pa[1][0] = mm; pa[2][0] = ll;
+      split_bf16x3(a0.z, a0.w, hh, mm, ll); pa[0][1] = hh; pa[1][1] = mm; pa[2][1] = ll;
+      split_bf16x3(a1.x, a1.y, hh, mm, ll); pa[0][2] = hh; pa[1][2] = mm; pa[2][2] = ll;
+      split_bf16x3(a1.z, a1.w, hh, mm, ll); pa[0][3] = hh; pa[1][3] = mm; pa[2][3] = ll;
+    }
+    if (s + SKN_PF < SKN_STEPS) {
+      ra[s % SKN_PF][0] = *reinterpret_cast<const sk_f4*>(a_src(s + SKN_PF, 0));
+      ra[s % SKN_PF][1] = *reinterpret_cast<const sk_f4*>(a_src(s + SKN_PF, 1));
+    }
+    // (mid,mid) (hi,lo) (lo,hi) (mid,hi) (hi,mid) -> accl, (hi,hi) -> acc: the order of gemm_bf16s_body
+    accl = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pa[1]), __builtin_bit_cast(bf16x8, pb[1]), accl, 0, 0, 0);
+    accl = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pa[0]), __builtin_bit_cast(bf16x8, pb[2]), accl, 0, 0, 0);
+    accl = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pa[2]), __builtin_bit_cast(bf16x8, pb[0]), accl, 0, 0, 0);
+    accl = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pa[1]), __builtin_bit_cast(bf16x8, pb[0]), accl, 0, 0, 0);
+    accl = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pa[0]), __builtin_bit_cast(bf16x8, pb[1]), accl, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pa[0]), __builtin_bit_cast(bf16x8, pb[0]), acc, 0, 0, 0);
+  }
+  acc += accl;
+  // ---- this slice's slab: register r of lane (i, h) is row 8 (r / 4) + 4 h + r % 4, column i of the wave's block
+  float* __restrict__ C = p.C + (size_t)sp * p.c_split_stride;
+  if (li < p.N) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ro = tm * SKN_BM + wave * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
+      if (ro < p.M) C[(size_t)ro * p.ldc + li] = acc[r];
+    }
+  }
+}
+
+// Which products: N <= 32 behind a long K (an A of at least 16 MB) with a K-contiguous A, no batches, nothing that only the tiled kernels' operand fetch
+// does (row gather, planes); the epilogue is applied by the slab sum, so every kind the reduce kernel knows is fine.
+inline bool gemm_skinny_n_eligible(const GemmP& p, bool akm) {
+  return !akm && p.N >= 1 && p.N <= SKN_NMAX && p.K >= 2048 && (long long)p.M * p.K >= (4LL << 20) &&      // (below 16 MB of A the tiled kernels' fewer slabs win: 64 x 17 633 13.5 vs 10.7 us)
+         std::max(p.nbatch, 1) == 1 && p.a_gather == nullptr && p.a_planes == nullptr &&
+         p.epi.csr_indptr == nullptr && p.epi.sp_rows == nullptr && p.epi.sq_m_half == 0 && p.epi.kind != EPI_ADAM &&
+         (p.lda % 4) == 0 && (p.ldb % 4) == 0;
+}
+inline bool plan_skinny_n(GemmPlan& pl, const GemmP& g, bool akm) {
+  if (!gemm_skinny_n_eligible(g, akm)) return false;
+  const int ns = (g.K + SKN_KPS - 1) / SKN_KPS;
+  if (ns < 2) return false;
+  pl.skinny = 0; pl.skinny_n = 1; pl.persist = 0;
+  pl.nsplit = ns; pl.kps = SKN_KPS;
+  pl.tiles_m = (g.M + SKN_BM - 1) / SKN_BM; pl.tiles_n = 1;
+  pl.mode = MFMA_BF16X3; pl.tile = 64; pl.kg = 1;
+  pl.sq_count = 0;      // (partials come from the slab sum: run_gemm / gemm_run set their count)
+  return true;
+}
+inline hipError_t gemm_dispatch_skinny_n(hipStream_t st, const GemmP& p0, bool bkm) {
+  GemmP p = p0;
+  if (p.nsplit < 2 || p.k_per_split != SKN_KPS || !p.zero_page) return hipErrorInvalidValue;
+  const int grid = p.nsplit * ((p.M + SKN_BM - 1) / SKN_BM);
+  if (bkm) GANMF_LAUNCH((gemm_skinny_n_kernel<true>), dim3(grid), dim3(512), 0, st, p);
+  else GANMF_LAUNCH((gemm_skinny_n_kernel<false>), dim3(grid), dim3(512), 0, st, p);
+  return hipGetLastError();
+}
+
 }  // namespace ganmf

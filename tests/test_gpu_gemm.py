@@ -188,3 +188,25 @@ def test_gemm_skinny_k_stream(akm, bkm, shape, monkeypatch):
     tiled, _ = gemm_f32(A, B, akm, bkm)
     assert np.all(np.abs(tiled - ref) <= 4e-7 * bound * np.sqrt(K) + 1e-30)
     assert np.all(np.abs(tiled - out) <= 8e-7 * bound * np.sqrt(K) + 1e-30)
+
+
+@pytest.mark.parametrize("bkm", [False, True])
+@pytest.mark.parametrize("shape", [(256, 32, 50001), (128, 32, 50000), (100, 17, 42001), (300, 32, 14100), (257, 31, 16385), (2049, 5, 2050)])
+def test_gemm_skinny_n_stream(bkm, shape, monkeypatch):
+    """gemm_skinny.hpp gemm_skinny_n_kernel: N <= 32 behind a long K (encode and dE at emb_dim 32: a [2B, 50 000] activation read once for
+    a [2B, 32] result) as a stream on the fp32 MFMA, one 256-wide K slice per workgroup, slabs summed in split order -- the default for such
+    shapes; against the fp64 product and the tiled kernels (GANMF_TUNE=skinny=0).  Ragged rows (more than one 256-row block too), fewer than
+    32 columns, K that ends inside a slice and inside a 4-float group, both layouts of B; bitwise reproducible."""
+    from ganmf_amd.engine import gemm_f32
+    M, N, K = shape
+    rng = np.random.RandomState(M + N + K)
+    A, B, ref, bound = _mk(rng, M, N, K, False, bkm)
+    monkeypatch.setenv("GANMF_DEBUG_PLAN", "1")
+    out, _ = gemm_f32(A, B, False, bkm)
+    err = np.abs(out - ref)
+    assert np.all(err <= 4e-7 * bound * np.sqrt(K) + 1e-30), float((err / (bound + 1e-30)).max())
+    again, _ = gemm_f32(A, B, False, bkm)
+    assert np.array_equal(out, again)
+    monkeypatch.setenv("GANMF_TUNE", "skinny=0")
+    tiled, _ = gemm_f32(A, B, False, bkm)
+    assert np.all(np.abs(tiled - out) <= 8e-7 * bound * np.sqrt(K) + 1e-30)
