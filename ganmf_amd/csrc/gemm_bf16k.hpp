@@ -246,7 +246,7 @@ __device__ __forceinline__ void gemm_bf16k_body(const GemmP& p, const int bid, c
   f32x16 acc[1][1];
   bf16k_mainloop<AKM, BKM, NPIECE, F16, 0>(p, tm, tn, sp, bz, smem, acc[0][0], [] {});
   static_assert(4 * 64 * 64 <= 2 * BF16K_OPER, "the plane buffers must hold the four staged partial tiles");
-  gemm_epilogue<64, 64, 1, 1, 4>(p, acc, smem, TileCoord{tm, tn, sp, bz, tm * 64, tn * 64});
+  gemm_epilogue<64, 64, 1, 1, 4, AKM && BKM>(p, acc, smem, TileCoord{tm, tn, sp, bz, tm * 64, tn * 64});
 }
 
 template <bool AKM, bool BKM, int NPIECE = 3, bool F16 = false>

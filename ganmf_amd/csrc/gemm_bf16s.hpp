@@ -302,7 +302,7 @@ __device__ __forceinline__ void gemm_bf16s_body(const GemmP& p, const int bid, c
         for (int b = 0; b < TN; ++b) acc[a][b] *= un;
     }
   }
-  gemm_epilogue<BM, BN, TM, TN>(p, acc, smem, TileCoord{tm, tn, sp, bz, m0, n0});
+  gemm_epilogue<BM, BN, TM, TN, 1, AKM && BKM>(p, acc, smem, TileCoord{tm, tn, sp, bz, m0, n0});
 #ifdef GANMF_PERSIST_DIAG_BUILD
   if (p.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
 #endif

@@ -500,7 +500,11 @@ struct TileCoord { int tm, tn, sp, bz, m0, n0; };
 // KG > 1: the workgroup has KG groups of four waves that each hold a partial sum of the SAME tile (they split the
 // chunks of every K-tile between them, gemm_f32_mfma); group g stages its accumulators at smem + g * BM * BN and the row
 // pass adds the KG images in group order (fixed order: bitwise reproducible).
-template <int BM, int BN, int TM, int TN, int KG = 1>
+// ADAM_OK: the instantiation carries the fused TF-Adam row pass (EPI_ADAM).  Every product that ends in it is a weight gradient, a TN
+// product (gWd_ext, gWe_ext, gV, DisGANMF's layer gradients): the NT / NN kernels are built without it (gemm_dispatch rejects the
+// combination), which takes the row pass, its twelve hoisted streams and the IEEE sqrt / divide sequences out of two thirds of the
+// GEMM code objects.
+template <int BM, int BN, int TM, int TN, int KG = 1, bool ADAM_OK = true>
 __device__ inline void gemm_epilogue(const GemmP& p, const f32x16 (&acc)[TM][TN], float* smem, const TileCoord& tc_) {
   constexpr int WM = BM / 2, WN = BN / 2;
   constexpr int NTHR = 256 * KG;
@@ -535,10 +539,15 @@ __device__ inline void gemm_epilogue(const GemmP& p, const f32x16 (&acc)[TM][TN]
   ct = smem;
   const int tc = tid % C4, tr = tid / C4;
   const int col = n0 + tc * 4;
-  const bool adam = !deferred && e.kind == EPI_ADAM;
+  const bool adam = ADAM_OK && !deferred && e.kind == EPI_ADAM;
   const float alpha = adam ? *e.adam_alpha : 0.f;
   float* __restrict__ theta_out = e.adam_theta_out ? e.adam_theta_out : e.adam_theta;
-  const bool publish = deferred && p.counters != nullptr;
+#ifdef GANMF_PERSIST_DIAG_BUILD
+  const bool inlaunch = deferred && p.counters != nullptr;      // in-launch split-K reduction: an experiment (measured level / slower)
+#else
+  constexpr bool inlaunch = false;
+#endif
+  const bool publish = inlaunch;
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   const __amdgpu_buffer_rsrc_t slab_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)C, (short)0, 0x7fffffff, 0x00020000);
 #ifdef GANMF_PERSIST_DIAG_BUILD
@@ -665,7 +674,7 @@ __device__ inline void gemm_epilogue(const GemmP& p, const f32x16 (&acc)[TM][TN]
     }
   }
   bool write_sq = !deferred && e.sq_partials;
-  if (deferred && p.counters) {
+  if (inlaunch) {
     // ---- in-launch split-K reduction (cdna guide §5 "In-launch split-K reduction", sc1 form):
     // write-through slab stores -> every wave drains vmcnt -> workgroup barrier -> lane 0 relaxed
     // agent fetch_add; the workgroup that draws nsplit-1 acquires (L1 invalidate) and reduces.
@@ -889,7 +898,7 @@ __device__ __forceinline__ void gemm_f32_body(const GemmP& p, const int bid, con
 
   GANMF_GEMM_STAMP(2);
   static_assert(KG * BM * BN <= NS * BUF, "the ring must hold the KG staged partial tiles");
-  gemm_epilogue<BM, BN, TM, TN, KG>(p, acc, smem, TileCoord{tm, tn, sp, bz, m0, n0});
+  gemm_epilogue<BM, BN, TM, TN, KG, AKM && BKM>(p, acc, smem, TileCoord{tm, tn, sp, bz, m0, n0});
 #ifdef GANMF_PERSIST_DIAG_BUILD
   if (p.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
 #endif
@@ -1147,6 +1156,14 @@ inline GemmPlan gemm_plan(int M, int N, int K, int nbatch, bool wants_sq, const 
   // 6130 -> 6660 steps/s with two per SIMD, 6760-6830 with four); co-resident ring-2 workgroups already interleave
   best.kg = (best.tile == 64 && best.mode == MFMA_F32 && best.ring <= 3) ? (tune.kg ? tune.kg : (best.ring == 3 ? 4 : 1)) : 1;
   if (best.kg == 4 && best.ring != 3) best.kg = 2;
+#ifndef GANMF_PERSIST_DIAG_BUILD
+  // the product build carries two fp32 64 x 64 points: one K group on a 2-slot ring (co-resident workgroups) and four K groups on a 3-slot
+  // ring (a CU to itself); overrides that name another point (GANMF_TUNE kg = 2, ring = 4, ring = 3 with kg = 1) land on the nearest one
+  if (best.tile == 64 && best.mode == MFMA_F32) {
+    if (best.kg >= 2 && best.ring >= 3) { best.kg = 4; best.ring = 3; }
+    else { best.kg = 1; best.ring = 2; }
+  }
+#endif
   best.sq_count = wants_sq ? best.tiles_m * best.tiles_n : 0;   // (separate reduce kernel: GEMM_RED_GRID, set by gemm_run)
   return best;
 }
@@ -1234,6 +1251,7 @@ inline hipError_t gemm_dispatch_skinny(hipStream_t st, const GemmP& p0, bool bkm
 inline hipError_t gemm_dispatch_skinny_n(hipStream_t st, const GemmP& p0, bool bkm);
 
 inline hipError_t gemm_dispatch(hipStream_t st, const GemmP& p0, bool akm, bool bkm, const GemmPlan& pl) {
+  if (p0.epi.kind == EPI_ADAM && !(akm && bkm)) return hipErrorInvalidValue;      // (the fused Adam row pass exists in the TN kernels only)
   if (pl.skinny) return gemm_dispatch_skinny(st, p0, bkm, pl.skinny);
   if (pl.skinny_n) return gemm_dispatch_skinny_n(st, p0, bkm);
   if (pl.persist) return gemm_dispatch_persist(st, p0, akm, bkm, pl);
@@ -1241,7 +1259,9 @@ inline hipError_t gemm_dispatch(hipStream_t st, const GemmP& p0, bool akm, bool 
   choose_tile_order(p, pl);
   if (pl.mode == MFMA_BF16 || pl.mode == MFMA_BF16X3 || pl.mode == MFMA_F16) return gemm_dispatch_staged(st, p, akm, bkm, pl);
   if (pl.tile == 128) return pl.ring >= 3 ? gemm_launch_t<128, 128, 32, 3>(st, p, akm, bkm) : gemm_launch_t<128, 128, 32, 2>(st, p, akm, bkm);
+#ifdef GANMF_PERSIST_DIAG_BUILD      // two K groups: between the planner's two points (one group on a shared CU, four on a CU of its own); sweeps only
   if (pl.kg == 2) return pl.ring == 3 ? gemm_launch_t<64, 64, 64, 3, 2>(st, p, akm, bkm) : gemm_launch_t<64, 64, 64, 2, 2>(st, p, akm, bkm);
+#endif
 #ifdef GANMF_PERSIST_DIAG_BUILD
   // diagnostic build (make DIAG=1), GANMF_GEMM_STAMPS=1: where the time of a 16-wave launch goes -- dispatch ramp, first K-tile,
   // K loop, epilogue + store drain -- from four 100 MHz stamps per workgroup, printed for the first launches of every shape
@@ -1280,8 +1300,11 @@ inline hipError_t gemm_dispatch(hipStream_t st, const GemmP& p0, bool akm, bool 
   }
 #endif
   if (pl.kg == 4) return gemm_launch_t<64, 64, 64, 3, 4>(st, p, akm, bkm);
+#ifdef GANMF_PERSIST_DIAG_BUILD      // a 4-slot ring and a 3-slot ring with one K group: measured level, sweeps only
   if (pl.ring == 4) return gemm_launch_t<64, 64, 64, 4>(st, p, akm, bkm);   // 128 KiB ring: three K-tiles (96 KiB) in flight
-  return pl.ring == 3 ? gemm_launch_t<64, 64, 64, 3>(st, p, akm, bkm) : gemm_launch_t<64, 64, 64, 2>(st, p, akm, bkm);
+  if (pl.ring == 3) return gemm_launch_t<64, 64, 64, 3>(st, p, akm, bkm);
+#endif
+  return gemm_launch_t<64, 64, 64, 2>(st, p, akm, bkm);
 }
 
 }  // namespace ganmf
