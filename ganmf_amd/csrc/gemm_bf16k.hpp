@@ -29,6 +29,7 @@ struct SplitItemK {
   const float* ptr;
   long long inc;      // floats per K-tile
   int aux, dst, ld;
+  int dst1 = 0;      // K-major: dword offset of the item's second k-row RELATIVE to dst
   bool km;
   __device__ inline void init(bool km_, const float* __restrict__ base, int ld_, int r0, int rlimit, int kbeg, const float* zero, int w,
                               const int* __restrict__ gather = nullptr) {
@@ -43,14 +44,16 @@ struct SplitItemK {
       inc = ok ? 64 : 0;
       aux = 0;
       dst = row * 32 + 4 * (c8 ^ S::swz(row));
-    } else {
+      dst1 = 0;
+    } else {      // (round 5) the [k][64 rows] bf16 image of SplitStage<64, 64, true>: four consecutive rows of two k-rows, two 8-byte stores per piece
       using S = SplitStage<64, 64, true>;
       const int kp = w / S::RQ, rq = w % S::RQ;
       const bool ok = (r0 + 4 * rq) < ld;
       ptr = base + (size_t)(kbeg + 2 * kp) * ld + r0 + 4 * rq;
       inc = (long long)64 * ld;
       aux = ok ? 2 * kp : -1;
-      dst = kp * 64 + ((4 * rq) ^ (((kp >> 2) & 1) << 5));
+      dst = (2 * kp) * S::KROW + 4 * ((rq >> 1) ^ S::swzk(2 * kp)) + 2 * (rq & 1);
+      dst1 = (2 * kp + 1) * S::KROW + 4 * ((rq >> 1) ^ S::swzk(2 * kp + 1)) + 2 * (rq & 1) - dst;
     }
   }
   // the two source addresses of the item in the K-tile that starts kleft k's before the end of the range (no memory access here)
@@ -62,27 +65,29 @@ struct SplitItemK {
     }
     ptr += inc;
   }
+  // `tok`: the token of the counted wait that covers this item's two loads (bf16k_wait_vm): the first instruction that reads a loaded
+  // register carries it as an operand, so nothing of the split can be scheduled in front of the wait.  (Rounds 3-4 folded it into the
+  // layout predicate of eight selects: a K-major item then paired its elements across the two k-rows it held.  With the [k][rows] image
+  // an item of either layout is eight consecutive elements and the selects are gone: 8 of 71 vector instructions per wave and K-tile.)
   template <int NPIECE, bool F16>
-  __device__ inline void split(const f32x4k (&v)[2], u32x4 (&pc)[3], const bool km, const float scale) const {
-    // the four (k, k + 1) pairs: 8 consecutive k of one row, or two k-rows of four consecutive rows.  (Scalars and selects, no
-    // private arrays: hipcc parks those in LDS / scratch and then waits for every load where it is issued.)
+  __device__ inline void split(const f32x4k (&v)[2], u32x4 (&pc)[3], const int tok, const float scale) const {
+    // the four pairs of the item: 8 consecutive k of one row, or four rows of k-row k followed by the same four rows of k-row k + 1.  (Scalars, no private arrays: hipcc
+    // parks those in LDS / scratch and then waits for every load where it is issued.)
     const f32x4k a = v[0], b = v[1];
-    const float p0a = a.x,               p0b = km ? b.x : a.y;
-    const float p1a = km ? a.y : a.z,    p1b = km ? b.y : a.w;
-    const float p2a = km ? a.z : b.x,    p2b = km ? b.z : b.y;
-    const float p3a = km ? a.w : b.z,    p3b = b.w;
     if constexpr (NPIECE == 3) {
       unsigned h, m, l;
-      split_bf16x3(p0a, p0b, h, m, l); pc[0][0] = h; pc[1][0] = m; pc[2][0] = l;
-      split_bf16x3(p1a, p1b, h, m, l); pc[0][1] = h; pc[1][1] = m; pc[2][1] = l;
-      split_bf16x3(p2a, p2b, h, m, l); pc[0][2] = h; pc[1][2] = m; pc[2][2] = l;
-      split_bf16x3(p3a, p3b, h, m, l); pc[0][3] = h; pc[1][3] = m; pc[2][3] = l;
+      split_bf16x3_tok(a.x, a.y, h, m, l, tok); pc[0][0] = h; pc[1][0] = m; pc[2][0] = l;
+      split_bf16x3_tok(a.z, a.w, h, m, l, tok); pc[0][1] = h; pc[1][1] = m; pc[2][1] = l;
+      split_bf16x3_tok(b.x, b.y, h, m, l, tok); pc[0][2] = h; pc[1][2] = m; pc[2][2] = l;
+      split_bf16x3_tok(b.z, b.w, h, m, l, tok); pc[0][3] = h; pc[1][3] = m; pc[2][3] = l;
     } else if constexpr (F16) {      // one IEEE fp16 piece after the exact power-of-two scale (static loss scaling per GEMM, gemm_f32.hpp)
-      pc[0][0] = cvt_pk_f16(p0a * scale, p0b * scale); pc[0][1] = cvt_pk_f16(p1a * scale, p1b * scale);
-      pc[0][2] = cvt_pk_f16(p2a * scale, p2b * scale); pc[0][3] = cvt_pk_f16(p3a * scale, p3b * scale);
+      // (every element is multiplied by the scale before anything else reads it: the scale carries the token)
+      const float sc = __uint_as_float(__float_as_uint(scale) | (unsigned)tok);
+      pc[0][0] = cvt_pk_f16(a.x * sc, a.y * sc); pc[0][1] = cvt_pk_f16(a.z * sc, a.w * sc);
+      pc[0][2] = cvt_pk_f16(b.x * sc, b.y * sc); pc[0][3] = cvt_pk_f16(b.z * sc, b.w * sc);
     } else {                         // one bf16 piece, round to nearest even
-      pc[0][0] = cvt_pk_bf16(p0a, p0b); pc[0][1] = cvt_pk_bf16(p1a, p1b);
-      pc[0][2] = cvt_pk_bf16(p2a, p2b); pc[0][3] = cvt_pk_bf16(p3a, p3b);
+      pc[0][0] = cvt_pk_bf16_tok(a.x, a.y, tok); pc[0][1] = cvt_pk_bf16_tok(a.z, a.w, tok);
+      pc[0][2] = cvt_pk_bf16_tok(b.x, b.y, tok); pc[0][3] = cvt_pk_bf16_tok(b.z, b.w, tok);
     }
   }
 };
@@ -91,7 +96,7 @@ constexpr int BF16K_OPER = 3 * (64 * 64 / 2) * 2;      // dwords of one plane bu
 constexpr int BF16K_PD = 4;                            // K-tiles in flight in registers (32 registers)
 
 // `s_waitcnt vmcnt(n)` (n wave-uniform, 0 .. 9) that hands out a token (always 0) every first use of the awaited registers is made to
-// depend on (SplitItemK::split folds it into the layout predicate of the pair selects), so that no consumer is scheduled above the wait.
+// depend on (SplitItemK::split hands it to the first conversion of every pair as an operand), so that no consumer is scheduled above the wait.
 // (A wait tied to the registers themselves, "+v", made hipcc COPY them in front of it on some paths: a read of a register whose load is
 // still in flight.)
 __device__ __forceinline__ int bf16k_wait_vm(int n, const f32x4k& v0, const f32x4k& v1) {
@@ -172,12 +177,19 @@ __device__ __forceinline__ void bf16k_mainloop(const GemmP& p, const int tm, con
       pc[0][0] += (unsigned)tok;
     } else
 #endif
-    // (the fp16 form multiplies every element by the scale before anything selects on the token: there the scale carries the dependency
-    // on the wait -- without it nothing orders `a.x * scale` behind the wait but the scheduler's habit, tools/check_asm_prefetch.py)
-    it.template split<NPIECE, F16>(v, pc, it.km != (tok != 0), F16 ? __uint_as_float(__float_as_uint(my_scale) | (unsigned)tok) : my_scale);
+    it.template split<NPIECE, F16>(v, pc, tok, my_scale);
     unsigned* o = my_planes + b * BF16K_OPER;
+    if (it.km) {      // (wave-uniform) K-major image: the item's two k-rows are two 8-byte stores per piece
+      typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-    for (int q = 0; q < NPIECE; ++q) *reinterpret_cast<u32x4*>(o + q * FA::PLANE) = pc[q];
+      for (int q = 0; q < NPIECE; ++q) {
+        *reinterpret_cast<u32x2*>(o + q * FA::PLANE) = u32x2{pc[q][0], pc[q][1]};
+        *reinterpret_cast<u32x2*>(o + q * FA::PLANE + it.dst1) = u32x2{pc[q][2], pc[q][3]};
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < NPIECE; ++q) *reinterpret_cast<u32x4*>(o + q * FA::PLANE) = pc[q];
+    }
   };
   // prologue: K-tiles 0 .. PD-1 requested, tile 0 split into buffer 0
   static_for<0, PD>([&](auto ss) { if (decltype(ss)::value < nt) load_tile(ss); });

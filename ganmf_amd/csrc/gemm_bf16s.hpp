@@ -15,8 +15,14 @@
 //   * LDS plane layouts (dword = two bf16 with consecutive k, low half first):
 //       K-contiguous operand  [row][BK/2], the 16-byte chunk (8 k's) index XOR-swizzled by the row
 //                             -> one conflict-free ds_read_b128 per piece and fragment;
-//       K-major operand       [k/2][R], the row index XOR 32 on odd groups of four k-pairs
-//                             -> four conflict-free ds_read_b32 per piece and fragment.
+//       K-major operand       (round 5) [k][R] bf16 -- the operand's own orientation, two rows per dword -- with the 16-byte chunk
+//                             (8 rows) index XORed by f(k & 3), read with the TRANSPOSING ds_read_b64_tr_b16: two reads per
+//                             piece and fragment (k + 0..3 and k + 4..7 of the lane's eight) at 256 B/clk instead of four
+//                             ds_read_b32 at 128 B/clk (rounds 1-4: [k/2][R] dwords of (k, k + 1) pairs), conflict-free; an item
+//                             is four consecutive rows of TWO k-rows (two 16-byte loads whose lanes tile whole 256-byte row
+//                             segments: a first version with 8 rows of one k-row per item -- 16-byte loads at a 32-byte lane
+//                             stride -- tripled the time the NN kernels wait for memory), paired ALONG the row like a
+//                             K-contiguous item and filed as two 8-byte stores per piece.
 //     A lane (i = lane & 31, h = lane >> 5) holds k = 16c + 8h + 0..7 of MFMA step c for both operands.
 //   * NPIECE = 1 rounds each operand to a single bf16 (RNE), or with F16 = true to a single fp16 after an exact
 //     power-of-two scale and a clamp to the fp16 range: the mixed-precision modes (MFMA_BF16 / MFMA_F16).
@@ -32,6 +38,13 @@ struct SplitStage {
   static constexpr int PLANE = R * BK / 2;    // dwords per piece plane
   static constexpr int CH = BK / 8;           // K-contiguous: 16-byte chunks per row
   static constexpr int RQ = R / 4;            // K-major: row quads per k-row
+  static constexpr int KROW = R / 2;          // K-major: dwords per k-row of a plane
+  static_assert(R == 64 || R == 128, "K-major chunk swizzle is laid out for 64- and 128-row operand tiles");
+  // K-major: XOR on the chunk index of k-row k.  A transposing read covers k-rows k0 .. k0 + 3 (k0 a multiple of four) x 16 rows per
+  // 16-lane group, two groups per 32-lane half: with 128-byte k-rows (R = 64) rows k0 + 2, k0 + 3 fall on the banks of k0, k0 + 1 and
+  // move to the other half of their 128 bytes; with 256-byte k-rows (R = 128) all four share their banks and take four different
+  // 64-byte groups (the layout of round 4's wgrad_stream.hpp, SQ_LDS_BANK_CONFLICT 0)
+  __device__ static inline int swzk(int k) { return R == 64 ? ((k & 3) >> 1) << 2 : (k & 3) << 2; }
   static_assert(NW % 256 == 0 && NI >= 1, "tile too small for 256 threads");
   static_assert(BK == 32 || BK == 64, "BK must be 32 or 64");
 
@@ -40,7 +53,8 @@ struct SplitStage {
   const float* zp;          // this lane's 32-byte line of the zero page
   const float* ptr[NI];     // source of the next tile (KM: first of the two k-rows)
   int aux[NI];              // !KM: pointer increment per tile (0: zero-page lane); KM: first k-row of the item or -1
-  int dst[NI];              // dword offset inside a plane
+  int dst[NI];              // dword offset inside a plane (K-major: of the item's first k-row)
+  int dst1[NI];             // K-major: of its second k-row
 
   __device__ inline void init(const float* __restrict__ base, int ld, int r0, int rlimit, int kbeg,
                               const float* zero, int tid) {
@@ -59,7 +73,8 @@ struct SplitStage {
         const bool ok = (r0 + 4 * rq) < ld;
         ptr[j] = base + (size_t)(kbeg + 2 * kp) * ld + r0 + 4 * rq;
         aux[j] = ok ? 2 * kp : -1;
-        dst[j] = kp * R + ((4 * rq) ^ (((kp >> 2) & 1) << 5));
+        dst[j] = (2 * kp) * KROW + 4 * ((rq >> 1) ^ swzk(2 * kp)) + 2 * (rq & 1);
+        dst1[j] = (2 * kp + 1) * KROW + 4 * ((rq >> 1) ^ swzk(2 * kp + 1)) + 2 * (rq & 1);
       }
     }
   }
@@ -89,7 +104,7 @@ struct SplitStage {
   __device__ inline void store(unsigned* __restrict__ planes, const float4 (&v)[NI][2], float scale = 1.f) const {
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
-      // the four (k, k+1) pairs of this item: 8 consecutive k of one row, or two k-rows of four consecutive rows
+      // the four pairs of this item: 8 consecutive k of one row, or 8 consecutive rows of one k-row
       // (no private arrays here: hipcc parks them in scratch / LDS)
       const float4 a = v[j][0], b = v[j][1];
       u32x4 pc[3];
@@ -108,15 +123,19 @@ struct SplitStage {
           pc[0][q] = cvt_pk_bf16(x0, x1);
         }
       };
-      if constexpr (KM) {
-        one(a.x, b.x, std::integral_constant<int, 0>{}); one(a.y, b.y, std::integral_constant<int, 1>{});
-        one(a.z, b.z, std::integral_constant<int, 2>{}); one(a.w, b.w, std::integral_constant<int, 3>{});
-      } else {
-        one(a.x, a.y, std::integral_constant<int, 0>{}); one(a.z, a.w, std::integral_constant<int, 1>{});
-        one(b.x, b.y, std::integral_constant<int, 2>{}); one(b.z, b.w, std::integral_constant<int, 3>{});
-      }
+      // (either layout pairs along its dwords: eight k of one row; or four rows of k-row k, then four rows of k-row k + 1)
+      one(a.x, a.y, std::integral_constant<int, 0>{}); one(a.z, a.w, std::integral_constant<int, 1>{});
+      one(b.x, b.y, std::integral_constant<int, 2>{}); one(b.z, b.w, std::integral_constant<int, 3>{});
 #pragma unroll
-      for (int q = 0; q < NPIECE; ++q) *reinterpret_cast<u32x4*>(planes + q * PLANE + dst[j]) = pc[q];
+      for (int q = 0; q < NPIECE; ++q) {
+        if constexpr (KM) {
+          typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+          *reinterpret_cast<u32x2*>(planes + q * PLANE + dst[j]) = u32x2{pc[q][0], pc[q][1]};
+          *reinterpret_cast<u32x2*>(planes + q * PLANE + dst1[j]) = u32x2{pc[q][2], pc[q][3]};
+        } else {
+          *reinterpret_cast<u32x4*>(planes + q * PLANE + dst[j]) = pc[q];
+        }
+      }
     }
   }
 
@@ -125,10 +144,21 @@ struct SplitStage {
     if constexpr (!KM) {
       return *reinterpret_cast<const u32x4*>(plane + (rb + i) * (BK / 2) + 4 * ((2 * c + h) ^ swz(i)));
     } else {
-      const unsigned* q = plane + (8 * c + 4 * h) * R + ((rb + i) ^ (h << 5));
-      u32x4 r;
-      r[0] = q[0]; r[1] = q[R]; r[2] = q[2 * R]; r[3] = q[3 * R];
-      return r;
+      // ds_read_b64_tr_b16: lane 4 qq + pp of a 16-lane group supplies the address of k-row qq, rows 4 pp .. 4 pp + 3 of a 4 (k) x 16 (rows)
+      // block and receives row (lane & 15) of the four k-rows.  Group gi = (i >> 4) takes rows 16 gi .. 16 gi + 15 of the 32-row block;
+      // lane half h the k-rows 16 c + 8 h + 0..7, in two reads (+ 0..3, + 4..7: the same k & 3, hence the same chunk XOR).
+      const int l16 = i & 15, gi = i >> 4, qq = l16 >> 2, pp = l16 & 3;
+      const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned*)plane;
+      const unsigned addr = base + (unsigned)((16 * c + 8 * h + qq) * (KROW * 4) + ((((rb >> 3) + 2 * gi + (pp >> 1)) ^ swzk(qq)) << 4) + ((pp & 1) << 3));
+#if defined(__HIP_DEVICE_COMPILE__)      // (LDS pointers are 32 bits wide in the device pass only)
+      typedef __attribute__((address_space(3))) s16x4* lds_s16x4_p;
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)addr);
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(addr + 4 * (KROW * 4)));
+      return __builtin_bit_cast(u32x4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+#else
+      (void)addr;
+      return u32x4{0u, 0u, 0u, 0u};
+#endif
     }
   }
 };

@@ -98,6 +98,23 @@ __device__ inline unsigned cvt_pk_bf16(float x0, float x1) {
   return r;
 }
 
+// the same conversion carrying a scalar token as a fourth operand (never read by the instruction: it is text in a comment): the
+// conversion cannot be scheduled in front of whatever produced the token -- how the 16-wave kernel orders the FIRST reads of its prefetch
+// registers behind its hand-counted vmcnt wait (gemm_bf16k.hpp bf16k_wait_vm) without a select per element
+__device__ inline unsigned cvt_pk_bf16_tok(float x0, float x1, int tok) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2 ; behind wait token %3" : "=v"(r) : "v"(x0), "v"(x1), "s"(tok));
+  return r;
+}
+__device__ inline void split_bf16x3_tok(float x0, float x1, unsigned& hi, unsigned& mid, unsigned& lo, int tok) {
+  hi = cvt_pk_bf16_tok(x0, x1, tok);
+  float r0 = x0 - __uint_as_float(hi << 16), r1 = x1 - __uint_as_float(hi & 0xffff0000u);
+  mid = cvt_pk_bf16(r0, r1);
+  r0 -= __uint_as_float(mid << 16);
+  r1 -= __uint_as_float(mid & 0xffff0000u);
+  lo = cvt_pk_bf16(r0, r1);
+}
+
 // two fp32 -> two IEEE fp16 in one dword (x0 in the low half), round to nearest even, clamped to the finite fp16 range
 // (an overflow would otherwise become an infinity and poison the accumulators)
 __device__ inline unsigned cvt_pk_f16(float x0, float x1) {

@@ -188,3 +188,47 @@ def test_local_group_errors():
     with pytest.raises(L.GanmfError, match="world_size"):
         b.comm_init_local(5)
     a.close(); b.close()
+
+
+def test_comm_abort_releases_a_rank_waiting_for_a_failed_peer():
+    """ganmf_comm_abort (the one entry point that may be called from another thread than the one inside a training call): rank 0 of a
+    two-rank loopback group enters its epoch, rank 1 never does (it "failed" on the host side); the driver aborts rank 0's communicator
+    and the training call returns with an error instead of waiting out the rendezvous -- and only THEN are the engines destroyed
+    (ganmf_amd/dist.py _ThreadRank.kill: never free a handle under a thread that is still inside the library)."""
+    import time
+    from ganmf_amd import _lib as L
+    from ganmf_amd.dist import _ThreadRank
+    from ganmf_amd.engine import Engine
+    U, N, k, e, B = 40, 61, 5, 9, 8
+    rng = np.random.RandomState(0)
+    urm = sps.csr_matrix((rng.rand(U, N) < 0.2).astype(np.float32))
+    hp = dict(d_lr=1e-3, g_lr=1e-3, d_reg=0.0, g_reg=0.0, m=1.0, recon_coefficient=0.1)
+    bounds = shard_bounds(U, 2)
+
+    def factory(rank):
+        lo, hi = bounds[rank]
+        eng = Engine(hi - lo, N, k, e, B, world_size=2, rank=rank, row_offset=lo, **hp)
+        eng.set_urm(urm[lo:hi])
+        return eng
+
+    ranks = [_ThreadRank(lambda r=r, **kw: factory(r)) for r in range(2)]
+    for rk in ranks:
+        rk.submit("__create__")
+    for rk in ranks:
+        rk.result(60)
+    for rk in ranks:
+        rk.submit("comm_init_local", 4242)
+    for rk in ranks:
+        rk.result(60)
+    steps, grows = epoch_plan([b - a for a, b in bounds], B)
+    ranks[0].submit("train_epoch", rng.permutation(bounds[0][1] - bounds[0][0]), 1, 1, steps_per_pass=steps, global_batch_rows=grows)
+    time.sleep(1.0)                      # rank 0 is inside the library now, waiting for rank 1 in the first collective
+    assert not ranks[0].ready(0.0)
+    t0 = time.time()
+    ranks[0].kill()                      # comm_abort -> the call returns -> the engine is closed
+    assert time.time() - t0 < 30
+    assert ranks[0].eng is None and not ranks[0]._t.is_alive()
+    status, err = ranks[0]._out
+    assert status == "err" and isinstance(err, L.GanmfError) and "peer failed" in str(err)
+    ranks[1].kill()
+    assert ranks[1].eng is None
