@@ -189,7 +189,9 @@ int ganmf_recommend(ganmf_handle* h, const int32_t* ids, int64_t n, int transpos
  * without a training interaction ("cold") scores -inf for ALL items; the reference's GANMF._compute_item_score, GANMF.py:285-292,
  * accepts items_to_compute and ignores it).  items == NULL / n_items == 0: no item restriction.  mask_cold_rows != 0: rows that are
  * empty in the matrix of ganmf_set_seen_csr (URM_train, evaluation orientation) are cold; it must be set when the scoring call is
- * made.  The filter stays until it is set again. */
+ * made.  The filter stays until it is set again.  A handle starts WITHOUT either mask, which is the reference GANMF's own contract
+ * (GANMF.py:285-292: finite scores for every user, items_to_compute ignored); the host classes switch the masks on only under
+ * score_contract="mf" (ganmf_amd/GANMF.py). */
 int ganmf_set_score_filter(ganmf_handle* h, const int32_t* items, int64_t n_items, int mask_cold_rows);
 
 /* Replaces save_current_model / load_model (GANMF.py:249-255, Utils_.py:292-294): device-side
