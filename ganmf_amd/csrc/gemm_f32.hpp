@@ -266,6 +266,20 @@ __device__ inline float4 sparse_rows_quad(const EpiD& e, int row, int col) {
   return s;
 }
 
+// theta - lr_t m / (sqrt(v) + eps), the last line of TF ApplyAdam, for every Adam kernel of the library (one definition: the fused
+// epilogues, the stand-alone and the per-row kernels must agree bit for bit).  v_sqrt_f32 and v_rcp_f32 are 1 ulp each, so the step is
+// within 2.5 ulp (3e-7 relative) of the correctly rounded quotient -- with |step| <= lr that is 1e-10 on parameters whose own fp32
+// spacing is 1e-9 ... 1e-7, three orders inside the path's stated tolerance (1e-4 relative on the scores), and the explicit fma gives every call
+// site the same rounding.  The IEEE sqrtf / divide sequences cost ~20 more vector instructions per element (2 us of the 46 us
+// weight-gradient launch, profiles/r04_wgrad_stream.md); `make ADAM_IEEE=1` builds them.
+__device__ __forceinline__ float adam_step(float x, float ma, float v) {
+#ifdef GANMF_ADAM_IEEE
+  return x - ma / (sqrtf(v) + ADAM_EPS);
+#else
+  return __builtin_fmaf(-ma, __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v) + ADAM_EPS), x);
+#endif
+}
+
 // TF ApplyAdam on one element (GANMF.py:104-105,138; training_ops ApplyAdam functor)
 __device__ inline void adam_update(float g, float alpha, float reg, float& th, float& m, float& v, float& sq) {
   const float x = th;
@@ -273,11 +287,7 @@ __device__ inline void adam_update(float g, float alpha, float reg, float& th, f
   const float gr = g + reg * x;
   m += (gr - m) * (1.f - ADAM_B1);
   v += (gr * gr - v) * (1.f - ADAM_B2);
-#if 0
-  th = x - (m * alpha) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v) + ADAM_EPS);
-#else
-  th = x - (m * alpha) / (sqrtf(v) + ADAM_EPS);
-#endif
+  th = adam_step(x, m * alpha, v);
 }
 
 __device__ inline float epi_apply(const EpiD& e, float v, int row, int col, int ldc, const float* __restrict__ aux,

@@ -459,7 +459,7 @@ __global__ __launch_bounds__(256) void adam_dense_kernel(float* __restrict__ th,
       const float gr = gp[j] + reg * x;
       mp[j] += (gr - mp[j]) * (1.f - ADAM_B1);
       vp[j] += (gr * gr - vp[j]) * (1.f - ADAM_B2);
-      tp[j] = x - (mp[j] * alpha) / (sqrtf(vp[j]) + ADAM_EPS);
+      tp[j] = adam_step(x, mp[j] * alpha, vp[j]);
     }
     reinterpret_cast<float4*>(th)[i] = t;
     reinterpret_cast<float4*>(mo)[i] = m;
@@ -478,7 +478,7 @@ __device__ __forceinline__ void adam_row_elem(float g, float reg, float alpha, f
   const float gr = g + reg * x;
   m = m * ADAM_B1 + gr * (1.f - ADAM_B1);
   v = v * ADAM_B2 + (gr * gr) * (1.f - ADAM_B2);
-  th = x - alpha * m / (sqrtf(v) + ADAM_EPS);
+  th = adam_step(x, alpha * m, v);
 }
 
 // AdamOptimizer._apply_sparse_shared over ALL rows of user_embeddings (TF-1 Adam is not lazy,
@@ -810,7 +810,7 @@ __global__ __launch_bounds__(DZ_COLS * DZ_GROUPS) void dis_dz_top_kernel(const f
       mm += (gr - mm) * (1.f - ADAM_B1);
       vv += (gr * gr - vv) * (1.f - ADAM_B2);
       mo[c] = mm; vo[c] = vv;
-      th[c] = x - (mm * scal[alpha_idx]) / (sqrtf(vv) + ADAM_EPS);
+      th[c] = adam_step(x, mm * scal[alpha_idx], vv);
     } else {
       gwo[c] = t;
     }
@@ -872,7 +872,7 @@ __global__ __launch_bounds__(64 * UIDG_GROUPS) void dis_uid_grad_kernel(const fl
       mm += (gr - mm) * (1.f - ADAM_B1);
       vv += (gr * gr - vv) * (1.f - ADAM_B2);
       mo[n] = mm; vo[n] = vv;
-      th[n] = x - (mm * scal[alpha_idx]) / (sqrtf(vv) + ADAM_EPS);
+      th[n] = adam_step(x, mm * scal[alpha_idx], vv);
     } else {
       out[n] = t;
     }
