@@ -55,6 +55,28 @@ def test_combined_launches_bit_identical(shape, g_reg, monkeypatch):
             np.testing.assert_array_equal(got[n], ref[n], err_msg="%s, GANMF_MULTI=%d" % (n, multi + 32 * defer + 64))
 
 
+@pytest.mark.parametrize("shape", [
+    (700, 1100, 64, 200, 96),          # 18 tile columns of gWd over 8 XCD rectangles of 2 or 3
+    (300, 300, 16, 70, 64),            # 5 tile columns: three of the eight rectangles are empty
+    (900, 3706, 32, 992, 128),         # the ML-1M tile grid (16 x 58)
+])
+def test_wgrad_blocked_tile_order_bit_identical(shape, monkeypatch):
+    """GANMF_TUNE wgrad_xb: gWd of the fused-Adam pair launch walks its tiles XCD rectangle by rectangle (default: bands of 16 tile
+    rows) instead of in list order.  Every tile is the same sum and the same in-place Adam update whatever the order."""
+    U, N, k, e, B = shape
+    hp = dict(d_lr=1e-4, g_lr=2e-4, d_reg=1e-4, g_reg=0.0, m=10.0, recon_coefficient=0.05)
+    monkeypatch.setenv("GANMF_TUNE", "wgrad_xb=0")
+    ref, ref_l = _run(monkeypatch, 31, 1, U, N, k, e, B, hp, epochs=2)
+    for xb in ("16", "2", "1"):
+        monkeypatch.setenv("GANMF_TUNE", "wgrad_xb=" + xb)
+        got, got_l = _run(monkeypatch, 31, 1, U, N, k, e, B, hp, epochs=2)
+        for (dl, gl), (dr, gr) in zip(got_l, ref_l):
+            np.testing.assert_array_equal(dl, dr, err_msg="D losses, wgrad_xb=" + xb)
+            np.testing.assert_array_equal(gl, gr, err_msg="G losses, wgrad_xb=" + xb)
+        for n in ref:
+            np.testing.assert_array_equal(got[n], ref[n], err_msg="%s, wgrad_xb=%s" % (n, xb))
+
+
 def test_second_item_buffer_survives_snapshot_and_restore(monkeypatch):
     """The fused gV update ping-pongs item_embeddings between two buffers: best-weights snapshot / restore and a tensor
     upload in the middle of training must act on the live one (an odd number of generator steps leaves it in the second)."""
