@@ -531,7 +531,10 @@ struct TileCoord { int tm, tn, sp, bz, m0, n0; };
 // product (gWd_ext, gWe_ext, gV, DisGANMF's layer gradients): the NT / NN kernels are built without it (gemm_dispatch rejects the
 // combination), which takes the row pass, its twelve hoisted streams and the IEEE sqrt / divide sequences out of two thirds of the
 // GEMM code objects.
-template <int BM, int BN, int TM, int TN, int KG = 1, bool ADAM_OK = true>
+// NIMG / STAGED (gemm_bf16w.hpp): the caller has staged NIMG partial images of the tile at smem + g * BM * BN itself (its waves are not the
+// 2 x 2 grid this function files); the row pass below is shared.  A tile with fewer float4 than threads (64 x 32 on 1024) leaves the
+// threads past it idle.
+template <int BM, int BN, int TM, int TN, int KG = 1, bool ADAM_OK = true, int NIMG = KG, bool STAGED = false>
 __device__ inline void gemm_epilogue(const GemmP& p, const f32x16 (&acc)[TM][TN], float* smem, const TileCoord& tc_) {
   constexpr int WM = BM / 2, WN = BN / 2;
   constexpr int NTHR = 256 * KG;
@@ -545,13 +548,15 @@ __device__ inline void gemm_epilogue(const GemmP& p, const f32x16 (&acc)[TM][TN]
   // instruction (measured ~2 TB/s chip-wide on 15-90 MB outputs); instead the tile is staged
   // through the now idle ring as a natural [BM][BN] image and written as whole rows, 16 B per lane.
   float* __restrict__ ct = smem + kg * (BM * BN);
+  if constexpr (!STAGED) {
 #pragma unroll
-  for (int a = 0; a < TM; ++a)
+    for (int a = 0; a < TM; ++a)
 #pragma unroll
-    for (int b = 0; b < TN; ++b)
+      for (int b = 0; b < TN; ++b)
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        ct[(wr * WM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * BN + wc * WN + b * 32 + li] = acc[a][b][r];
+        for (int r = 0; r < 16; ++r)
+          ct[(wr * WM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * BN + wc * WN + b * 32 + li] = acc[a][b][r];
+  }
   __syncthreads();
 
   float* __restrict__ C = p.C + (size_t)sp * p.c_split_stride + (size_t)bz * p.c_batch_stride;
@@ -561,8 +566,10 @@ __device__ inline void gemm_epilogue(const GemmP& p, const f32x16 (&acc)[TM][TN]
   const float* __restrict__ aux = (e.aux && !csr0) ? e.aux + (size_t)bz * e.aux_batch_stride : nullptr;
   const bool sp_add = !(p.nsplit > 1) && e.sp_rows != nullptr;      // gWe_ext: the real rows' share comes from the CSC matrix
   float sq = 0.f;
-  constexpr int C4 = BN / 4, RPP = NTHR / C4;
+  constexpr int C4 = BN / 4, RPP = NTHR / C4 < BM ? NTHR / C4 : BM;
+  constexpr bool SPARE = NTHR / C4 > BM;      // more threads than float4 in the tile: rows past BM are nobody's
   static_assert(BM % RPP == 0, "row pass must cover the tile in whole steps");
+  static_assert(!SPARE || !ADAM_OK, "the hoisted Adam streams assume every thread owns a row");
   ct = smem;
   const int tc = tid % C4, tr = tid / C4;
   const int col = n0 + tc * 4;
@@ -605,7 +612,7 @@ __device__ inline void gemm_epilogue(const GemmP& p, const f32x16 (&acc)[TM][TN]
         if (row < p.M && col < p.N) {
           float4 v = *reinterpret_cast<const float4*>(ct + row_l * BN + tc * 4);
 #pragma unroll
-          for (int g = 1; g < KG; ++g) {
+          for (int g = 1; g < NIMG; ++g) {
             const float4 w = *reinterpret_cast<const float4*>(ct + g * (BM * BN) + row_l * BN + tc * 4);
             v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
           }
@@ -637,10 +644,10 @@ __device__ inline void gemm_epilogue(const GemmP& p, const f32x16 (&acc)[TM][TN]
 #pragma unroll 4
   for (int j = 0; j < BM / RPP; ++j) {
     const int row_l = tr + j * RPP, row = m0 + row_l;
-    if (row < p.M && col < p.N) {
+    if (row < p.M && col < p.N && (!SPARE || row_l < BM)) {
       float4 v = *reinterpret_cast<const float4*>(ct + row_l * BN + tc * 4);
 #pragma unroll
-      for (int g = 1; g < KG; ++g) {
+      for (int g = 1; g < NIMG; ++g) {
         const float4 w = *reinterpret_cast<const float4*>(ct + g * (BM * BN) + row_l * BN + tc * 4);
         v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
       }
@@ -727,7 +734,7 @@ __device__ inline void gemm_epilogue(const GemmP& p, const f32x16 (&acc)[TM][TN]
 #pragma unroll 2
     for (int j = 0; j < BM / RPP; ++j) {
       const int row = m0 + tr + j * RPP;
-      if (row < p.M && col < p.N) {
+      if (row < p.M && col < p.N && (!SPARE || tr + j * RPP < BM)) {
         const size_t off = (size_t)row * p.ldc + col;
         float4 s4 = *reinterpret_cast<const float4*>(slab + off);
 #pragma unroll 4
@@ -1094,6 +1101,7 @@ struct GemmPlan {
   int tile_order = 0;        // GemmTune::tile_order
   int skinny = 0;            // > 0: the streaming kernel for K <= 64 (gemm_skinny.hpp), this many rows per wave
   int skinny_n = 0;          // 1: the streaming kernel for N <= 32 behind a long K (gemm_skinny.hpp, gemm_skinny_n_kernel)
+  int wide32 = 0;            // 1: the 16-wave split-bf16 loop on 64 x 32 tiles with 128-deep K-tiles, unsplit (gemm_bf16w.hpp)
   double est_us = 0;
 };
 
@@ -1276,11 +1284,13 @@ inline void choose_tile_order(GemmP& p, const GemmPlan& pl) {
 
 inline hipError_t gemm_dispatch_skinny(hipStream_t st, const GemmP& p0, bool bkm, int rt);
 inline hipError_t gemm_dispatch_skinny_n(hipStream_t st, const GemmP& p0, bool bkm);
+inline hipError_t gemm_dispatch_bf16w(hipStream_t st, const GemmP& p, bool bkm);
 
 inline hipError_t gemm_dispatch(hipStream_t st, const GemmP& p0, bool akm, bool bkm, const GemmPlan& pl) {
   if (p0.epi.kind == EPI_ADAM && !(akm && bkm)) return hipErrorInvalidValue;      // (the fused Adam row pass exists in the TN kernels only)
   if (pl.skinny) return gemm_dispatch_skinny(st, p0, bkm, pl.skinny);
   if (pl.skinny_n) return gemm_dispatch_skinny_n(st, p0, bkm);
+  if (pl.wide32) return gemm_dispatch_bf16w(st, p0, bkm);
   if (pl.persist) return gemm_dispatch_persist(st, p0, akm, bkm, pl);
   GemmP p = p0;
   choose_tile_order(p, pl);

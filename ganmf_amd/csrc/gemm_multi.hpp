@@ -28,6 +28,7 @@
 #include "gemm_f32.hpp"
 #include "kernels.hpp"
 #include "gemm_skinny.hpp"
+#include "gemm_bf16w.hpp"
 
 namespace ganmf {
 

@@ -171,6 +171,30 @@ def test_gemm_split_bf16_k_groups(akm, bkm, shape, nsplit, monkeypatch):
     assert not np.array_equal(plain, out) or K == 1      # (it IS another kernel)
 
 
+@pytest.mark.parametrize("shape", [(128, 3706, 992), (128, 3706, 993), (64, 32, 128), (1, 1, 1), (65, 33, 129), (100, 70, 1030), (128, 2113, 748),
+                                   (37, 500, 384), (200, 100, 257), (64, 96, 2000)])
+@pytest.mark.parametrize("bkm", [False, True])
+def test_gemm_bf16w_64x32_tiles(shape, bkm, monkeypatch):
+    """gemm_bf16w.hpp: the 16-wave split-bf16 loop on 64 x 32 tiles with 128-deep K-tiles (eight K groups), unsplit, B K-contiguous (dF of
+    the generator step) or K-major (its decode: [k][32 n] image, transposing fragment reads) -- the ML-1M and hetrec shapes, 1 .. 16 K-tiles (fewer than the three prefetch slots, tile counts that are no
+    multiple of three), K tails, a last K-tile that reaches past the leading dimension (K = 1030: ld 1088 < 1152), ragged rows and
+    columns.  fp32-accurate like the 64 x 64 kernel, run-to-run identical, and another kernel than the default plan's."""
+    from ganmf_amd.engine import gemm_f32
+    M, N, K = shape
+    rng = np.random.RandomState(M + 3 * N + 7 * K)
+    A, B, ref, bound = _mk(rng, M, N, K, False, bkm)
+    monkeypatch.setenv("GANMF_TUNE", "bf16w=2")
+    out, _ = gemm_f32(A, B, False, bkm)
+    err = np.abs(out - ref)
+    assert np.all(err <= 4e-7 * bound * np.sqrt(K) + 1e-30), float((err / (bound + 1e-30)).max())
+    again, _ = gemm_f32(A, B, False, bkm)
+    np.testing.assert_array_equal(out, again)
+    monkeypatch.setenv("GANMF_TUNE", "bf16w=0")
+    plain, _ = gemm_f32(A, B, False, bkm)
+    assert np.all(np.abs(plain - out) <= 8e-7 * bound * np.sqrt(K) + 1e-30)
+    assert not np.array_equal(plain, out) or K == 1
+
+
 @pytest.mark.parametrize("akm,bkm", [(False, False), (False, True)])
 @pytest.mark.parametrize("shape", [(256, 50000, 33), (128, 17632, 32), (1, 2048, 1), (64, 2049, 10), (100, 5003, 64), (321, 4100, 7), (70, 3000, 63)])
 def test_gemm_skinny_k_stream(akm, bkm, shape, monkeypatch):

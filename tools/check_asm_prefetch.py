@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Build-time lint for the inline-asm operand prefetch of gemm_bf16k.hpp (advisor finding, round 3).
 
-bf16k_mainloop issues its operand loads from `asm volatile("global_load_dwordx4 ...")` and waits for them with hand-counted
+bf16k_mainloop (and bf16w_mainloop, gemm_bf16w.hpp) issues its operand loads from `asm volatile("global_load_dwordx4 ...")` and waits for them with hand-counted
 `s_waitcnt vmcnt(n)`: hipcc does not know that those registers have a load in flight, so nothing but the source's token
 dependencies keeps it from copying or reading one before its wait -- a silent wrong-result bug that depends on the compiler
 version.  This tool compiles the kernel instantiations to gfx950 assembly (no GPU needed) and walks every kernel with a model of
@@ -32,6 +32,8 @@ template __global__ void gemm_bf16k_mfma<true, true, 3, false>(const GemmP);
 template __global__ void gemm_bf16k_mfma<false, false, 1, false>(const GemmP);
 template __global__ void gemm_bf16k_mfma<false, true, 1, true>(const GemmP);
 template __global__ void front_kernel<4, true>(const GemmP, const DensP);
+template __global__ void gemm_bf16w_mfma<false>(const GemmP);
+template __global__ void gemm_bf16w_mfma<true>(const GemmP);
 template __global__ void de_dcoef_kernel<4, true>(const GemmP, const DCoefP, const int);
 }
 """ % ROOT
@@ -121,7 +123,7 @@ def main():
                 cur = None
     problems, checked, asm_loads = [], 0, 0
     for name, lines in kernels.items():
-        if "bf16k" not in name and "front_kernel" not in name and "de_dcoef" not in name:
+        if "bf16k" not in name and "bf16w" not in name and "front_kernel" not in name and "de_dcoef" not in name:
             continue
         n_asm = sum(1 for _, l in lines if "global_load_dwordx4" in l)
         if n_asm == 0:
