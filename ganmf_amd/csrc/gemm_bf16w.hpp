@@ -6,9 +6,9 @@
 //   * 1024 threads = 8 K groups x (2 x 1 waves): K-tile 128 = eight 16-wide chunks, chunk g to K group g; a wave owns ONE 32 x 32 block
 //     (16 accumulator registers + 16 for the small products), reads six 16-byte fragments and issues six MFMAs per K-tile -- per k half
 //     of the fragment reads, barriers and MFMA issues of the 64 x 64 form;
-//   * staging: (64 + 32) x 128 elements per K-tile = 12 per thread: three items of four consecutive k (one 16-byte load, two pair splits,
-//     three 8-byte plane stores each) -- A rows r and r + 32 and B row r, 32 threads along a row's 512 bytes; per k three quarters of the
-//     64 x 64 form's split work, the same for every thread;
+//   * staging: (64 + 32) x 128 elements per K-tile = 12 per thread, the same for every thread: eight consecutive k of an A row (two
+//     16-byte loads, four pair splits, one 16-byte store per piece; 16 threads along a row's 512 bytes) and four consecutive k of a B row
+//     (one load, two pair splits, one 8-byte store per piece); per k three quarters of the 64 x 64 form's split work;
 //   * PD = 2 K-tiles in flight in registers (24 registers), loads from inline asm behind hand-counted waits whose token the first
 //     conversion of every pair carries (the technique and its lint: gemm_bf16k.hpp, tools/check_asm_prefetch.py).  (PD = 3 / 4: the
 //     stand-alone product level / 0.5-1 us slower, the step 1.2 % / 2.2 % slower than with PD = 2 -- 2.8 us of fetch are in flight
@@ -58,25 +58,26 @@ __device__ __forceinline__ void bf16w_mainloop(const GemmP& p, const int tm, con
 #pragma unroll
   for (int r = 0; r < 16; ++r) { acc[r] = 0.f; accl[r] = 0.f; }
 
-  // this thread's three items: k-quad kq of A rows m0 + row, m0 + row + 32 and of B row n0 + row
+  // this thread's items: eight consecutive k (k-octet c8) of A row m0 + arow -- two 16-byte loads, one 16-byte store per piece -- and the
+  // k-quad kq of B row n0 + row (one load, one 8-byte store per piece)
   const int row = tid >> 5, kq = tid & 31;
+  const int arow = tid >> 4, c8 = tid & 15;
   const float* const zp = p.zero_page + (tid & 255) * 8;
-  const bool ok0 = m0 + row < p.M, ok1 = m0 + row + 32 < p.M, ok2 = n0 + row < p.N;
-  const float* s0 = ok0 ? p.A + (size_t)bz * p.a_batch_stride + (size_t)(m0 + row) * p.lda + 4 * kq : zp;
-  const float* s1 = ok1 ? p.A + (size_t)bz * p.a_batch_stride + (size_t)(m0 + row + 32) * p.lda + 4 * kq : zp;
+  const bool ok0 = m0 + arow < p.M, ok2 = n0 + row < p.N;
+  const float* s0 = ok0 ? p.A + (size_t)bz * p.a_batch_stride + (size_t)(m0 + arow) * p.lda + 8 * c8 : zp;
   // B K-major ([K, ldb], n contiguous): the item is four consecutive n of ONE k-row -- k-row tid / 8 of the K-tile, n-quad tid % 8 (eight
   // threads along a k-row's 128 bytes); k-rows past K do not exist (zero page), columns N .. ldb - 1 are zero
   const int kb = tid >> 3, nq = tid & 7;
   const bool okn = n0 + 4 * nq < p.ldb;
   const float* s2 = !BKM ? (ok2 ? p.B + (size_t)(n0 + row) * p.ldb + 4 * kq : zp) : (okn ? p.B + (size_t)kb * p.ldb + n0 + 4 * nq : zp);
-  const int i0 = ok0 ? BK : 0, i1 = ok1 ? BK : 0;
+  const int i0 = ok0 ? BK : 0;
   const long long i2 = !BKM ? (ok2 ? BK : 0) : (okn ? (long long)BK * p.ldb : 0);
   int kleft = p.K;      // (K-major B) k-rows from the next tile to request to the end of the range
   // columns K .. ld - 1 of an operand row are zero (every leading dimension is a multiple of 64 floats and pads are never stored to:
   // what the 64-deep K-tiles of the other kernels rely on); the LAST 128-deep tile may reach past ld, where the next row begins
-  const int klast = (nt - 1) * BK + 4 * kq;
-  const bool in_a = klast < p.lda, in_b = klast < p.ldb;
-  const int dst = row * (BK / 2) + ((((kq >> 1) ^ (row & 15))) << 2) + ((kq & 1) << 1);      // dword offset inside a plane (rows r and r + 32: same XOR)
+  const bool in_a = (nt - 1) * BK + 8 * c8 < p.lda, in_b = (nt - 1) * BK + 4 * kq < p.ldb;
+  const int dsta = arow * (BK / 2) + ((c8 ^ (arow & 15)) << 2);                                // dword offsets inside a plane
+  const int dst = row * (BK / 2) + ((((kq >> 1) ^ (row & 15))) << 2) + ((kq & 1) << 1);
   // K-major B image: [k][32 n] bf16, 64 bytes per k-row, no XOR -- a half-wave's stores and its transposing reads each cover four
   // consecutive k-rows = 256 contiguous bytes
   const int dstb = !BKM ? dst : kb * (BN / 2) + 2 * nq;
@@ -89,7 +90,7 @@ __device__ __forceinline__ void bf16w_mainloop(const GemmP& p, const int tm, con
     constexpr int s = decltype(ss)::value;
     const bool last = tload == nt - 1, past = tload >= nt;      // (past: a prologue slot behind a short K range -- requested all the same, from the zero page)
     const float* a0 = ((last && !in_a) || past) ? zp : s0;
-    const float* a1 = ((last && !in_a) || past) ? zp : s1;
+    const float* a1 = a0 + 4;
     const float* b0 = !BKM ? (((last && !in_b) || past) ? zp : s2) : ((kb < kleft) ? s2 : zp);
     kleft -= BK;
     f32x4k l0, l1, l2;
@@ -97,7 +98,7 @@ __device__ __forceinline__ void bf16w_mainloop(const GemmP& p, const int tm, con
     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(l1) : "v"(a1) : "memory");
     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(l2) : "v"(b0) : "memory");
     rg[s][0] = l0; rg[s][1] = l1; rg[s][2] = l2;
-    s0 += i0; s1 += i1; s2 += i2;
+    s0 += i0; s2 += i2;
     ++tload;
   };
   // `nwait` = vector-memory loads issued after the three of the K-tile in slot s (loads return in order)
@@ -105,16 +106,13 @@ __device__ __forceinline__ void bf16w_mainloop(const GemmP& p, const int tm, con
     constexpr int s = decltype(ss)::value;
     const f32x4k v0 = rg[s][0], v1 = rg[s][1], v2 = rg[s][2];
     const int tok = bf16w_wait_vm(nwait, v0, v1, v2);
-    unsigned* o = buf + b * BF16W_OPER + dst;
-    unsigned h0, m0_, l0, h1, m1, l1;
+    unsigned* o = buf + b * BF16W_OPER + dsta;
+    unsigned h0, m0_, l0, h1, m1, l1, h2, m2, l2, h3, m3, l3;
     split_bf16x3_tok(v0.x, v0.y, h0, m0_, l0, tok); split_bf16x3_tok(v0.z, v0.w, h1, m1, l1, tok);
-    *reinterpret_cast<u32x2*>(o) = u32x2{h0, h1};
-    *reinterpret_cast<u32x2*>(o + PA) = u32x2{m0_, m1};
-    *reinterpret_cast<u32x2*>(o + 2 * PA) = u32x2{l0, l1};
-    split_bf16x3_tok(v1.x, v1.y, h0, m0_, l0, tok); split_bf16x3_tok(v1.z, v1.w, h1, m1, l1, tok);
-    *reinterpret_cast<u32x2*>(o + 32 * (BK / 2)) = u32x2{h0, h1};
-    *reinterpret_cast<u32x2*>(o + 32 * (BK / 2) + PA) = u32x2{m0_, m1};
-    *reinterpret_cast<u32x2*>(o + 32 * (BK / 2) + 2 * PA) = u32x2{l0, l1};
+    split_bf16x3_tok(v1.x, v1.y, h2, m2, l2, tok); split_bf16x3_tok(v1.z, v1.w, h3, m3, l3, tok);
+    *reinterpret_cast<u32x4*>(o) = u32x4{h0, h1, h2, h3};
+    *reinterpret_cast<u32x4*>(o + PA) = u32x4{m0_, m1, m2, m3};
+    *reinterpret_cast<u32x4*>(o + 2 * PA) = u32x4{l0, l1, l2, l3};
     split_bf16x3_tok(v2.x, v2.y, h0, m0_, l0, tok); split_bf16x3_tok(v2.z, v2.w, h1, m1, l1, tok);
     unsigned* ob = buf + b * BF16W_OPER + 3 * PA + dstb;
     *reinterpret_cast<u32x2*>(ob) = u32x2{h0, h1};
