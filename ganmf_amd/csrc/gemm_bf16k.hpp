@@ -4,7 +4,7 @@
 // <= 256 workgroups: one per CU), where the 4-wave staged kernel is latency-bound (27 us against the fp32 ring kernel's 21 on the
 // encode GEMM) and the fp32 ring kernel is MFMA-bound at the 2.0 GHz the chip holds (profiles/r03_gemm_stamps.md).
 //   * staging: waves 0-7 own the A tile, waves 8-15 the B tile, one item of 8 elements per thread and K-tile (two 16-byte loads,
-//     four pair splits, three 16-byte plane stores); the loads of PD = 4 K-tiles are in flight in registers (32 registers), so the
+//     four pair splits, three 16-byte plane stores); the loads of PD = 2 K-tiles (one-piece forms: 4) are in flight in registers, so the
 //     fetch latency is covered without an LDS ring and without more workgroups per CU;
 //   * two plane buffers (2 x 48 KiB) and ONE barrier per K-tile: in iteration t every wave reads its fragments of buffer t & 1 and
 //     issues its six MFMAs, then splits K-tile t + 1 into buffer (t + 1) & 1 (last read in iteration t - 1, behind the barrier);
@@ -93,7 +93,11 @@ struct SplitItemK {
 };
 
 constexpr int BF16K_OPER = 3 * (64 * 64 / 2) * 2;      // dwords of one plane buffer: three pieces x (A + B) = 48 KiB
-constexpr int BF16K_PD = 4;                            // K-tiles in flight in registers (32 registers)
+// K-tiles in flight in registers.  Three-piece loop (1.0 us per K-tile): TWO -- 2 us of fetch in flight cover the latency, and a launch that
+// opens with half the requests per CU leaves more of the fabric to its neighbours' tails: the step + 1.4-1.8 % on the slower boxes against
+// the four of rounds 3-4 (8 722 -> 8 875, 8 746 -> 8 868 in one-call alternations; three: + 1.0 %), level on the fast ones.  One-piece
+// loops (one MFMA per K-tile, ~0.6 us): four.
+template <int NPIECE> constexpr int bf16k_pd() { return NPIECE == 3 ? 2 : 4; }
 
 // `s_waitcnt vmcnt(n)` (n wave-uniform, 0 .. 9) that hands out a token (always 0) every first use of the awaited registers is made to
 // depend on (SplitItemK::split hands it to the first conversion of every pair as an operand), so that no consumer is scheduled above the wait.
@@ -119,8 +123,8 @@ __device__ __forceinline__ void bf16k_mainloop(const GemmP& p, const int tm, con
                                                f32x16& acc_out, Entry&& at_entry) {
   static_assert(NPIECE == 3 || NPIECE == 1, "pieces per operand");
   static_assert(!F16 || NPIECE == 1, "fp16 pieces only in the single-piece mode");
-  static_assert(2 * 3 + EXTRA <= 9, "bf16k_wait_vm covers 0 .. 9");
-  constexpr int BM = 64, BN = 64, BK = 64, PD = BF16K_PD;
+  static_assert(2 * (bf16k_pd<NPIECE>() - 1) + EXTRA <= 9, "bf16k_wait_vm covers 0 .. 9");
+  constexpr int BM = 64, BN = 64, BK = 64, PD = bf16k_pd<NPIECE>();
   const float sa = (F16 && p.a_scale != 0.f) ? p.a_scale : 1.f, sb = (F16 && p.b_scale != 0.f) ? p.b_scale : 1.f;
   using FA = SplitStage<64, 64, AKM>;
   using FB = SplitStage<64, 64, BKM>;
@@ -196,8 +200,9 @@ __device__ __forceinline__ void bf16k_mainloop(const GemmP& p, const int tm, con
   store_tile(std::integral_constant<int, 0>{}, 0, 2 * (min(nt, PD) - 1));
   // everything requested so far lands before the loop is entered (the requests went out back to back with tile 0's, which the split
   // above has waited for): should hipcc move a prefetch register at the loop header, it moves a register that is complete
-  asm volatile("s_waitcnt vmcnt(0)" :: "v"(rg[0][0]), "v"(rg[0][1]), "v"(rg[1][0]), "v"(rg[1][1]), "v"(rg[2][0]), "v"(rg[2][1]), "v"(rg[3][0]), "v"(rg[3][1]));
-  static_assert(PD == 4, "the wait above names every prefetch register");
+  if constexpr (PD == 4) asm volatile("s_waitcnt vmcnt(0)" :: "v"(rg[0][0]), "v"(rg[0][1]), "v"(rg[1][0]), "v"(rg[1][1]), "v"(rg[2][0]), "v"(rg[2][1]), "v"(rg[3][0]), "v"(rg[3][1]));
+  else asm volatile("s_waitcnt vmcnt(0)" :: "v"(rg[0][0]), "v"(rg[0][1]), "v"(rg[1][0]), "v"(rg[1][1]));
+  static_assert(PD == 4 || PD == 2, "the wait above names every prefetch register");
   at_entry();
   __syncthreads();
 
