@@ -592,7 +592,10 @@ __device__ inline void gemm_epilogue(const GemmP& p, const f32x16 (&acc)[TM][TN]
     // four row steps are fetched BEFORE the first of them is written back: written as one loop the stores of step j and the
     // loads of step j + 1 go through the same pointers, so the compiler keeps them in order and the row pass becomes four
     // dependent load -> update -> store rounds of HBM latency each.
-    constexpr int J = BM / RPP, JC = J < 4 ? J : 4;
+    // (JC row steps' streams requested ahead.  Rounds 2-4: four -- a lone workgroup's row pass then waits for HBM once instead of four
+    // times; with six workgroups of the weight-gradient launch resident per CU the others' K loops cover that wait, and the twelve
+    // requests per thread at once cost more than they hide: the launch 45.3 / 44.5 / 44.1 us with JC = 4 / 2 / 1, round 5)
+    constexpr int J = BM / RPP, JC = 1;
     static_assert(J % JC == 0, "row steps in whole chunks");
     for (int j0 = 0; j0 < J; j0 += JC) {
       float4 t4[JC], m4[JC], v4[JC];
