@@ -4,7 +4,7 @@
 // <= 256 workgroups: one per CU), where the 4-wave staged kernel is latency-bound (27 us against the fp32 ring kernel's 21 on the
 // encode GEMM) and the fp32 ring kernel is MFMA-bound at the 2.0 GHz the chip holds (profiles/r03_gemm_stamps.md).
 //   * staging: waves 0-7 own the A tile, waves 8-15 the B tile, one item of 8 elements per thread and K-tile (two 16-byte loads,
-//     four pair splits, three 16-byte plane stores); the loads of PD = 2 K-tiles (one-piece forms: 4) are in flight in registers, so the
+//     four pair splits, three 16-byte plane stores); the loads of PD = 2 K-tiles are in flight in registers, so the
 //     fetch latency is covered without an LDS ring and without more workgroups per CU;
 //   * two plane buffers (2 x 48 KiB) and ONE barrier per K-tile: in iteration t every wave reads its fragments of buffer t & 1 and
 //     issues its six MFMAs, then splits K-tile t + 1 into buffer (t + 1) & 1 (last read in iteration t - 1, behind the barrier);
@@ -95,9 +95,10 @@ struct SplitItemK {
 constexpr int BF16K_OPER = 3 * (64 * 64 / 2) * 2;      // dwords of one plane buffer: three pieces x (A + B) = 48 KiB
 // K-tiles in flight in registers.  Three-piece loop (1.0 us per K-tile): TWO -- 2 us of fetch in flight cover the latency, and a launch that
 // opens with half the requests per CU leaves more of the fabric to its neighbours' tails: the step + 1.4-1.8 % on the slower boxes against
-// the four of rounds 3-4 (8 722 -> 8 875, 8 746 -> 8 868 in one-call alternations; three: + 1.0 %), level on the fast ones.  One-piece
-// loops (one MFMA per K-tile, ~0.6 us): four.
-template <int NPIECE> constexpr int bf16k_pd() { return NPIECE == 3 ? 2 : 4; }
+// the four of rounds 3-4 (8 722 -> 8 875, 8 746 -> 8 868 in one-call alternations; three: + 1.0 %), + 2.7 % on a fast one (9 000-9 070 ->
+// 9 230-9 310).  The one-piece loops (one MFMA per K-tile) likewise: DisGANMF at configs[4] 17 059 / 17 353 -> 17 283 / 17 576 steps/s in
+// fp16, 17 281 / 17 524 -> 17 766 / 17 960 in bf16.
+template <int NPIECE> constexpr int bf16k_pd() { return 2; }
 
 // `s_waitcnt vmcnt(n)` (n wave-uniform, 0 .. 9) that hands out a token (always 0) every first use of the awaited registers is made to
 // depend on (SplitItemK::split hands it to the first conversion of every pair as an operand), so that no consumer is scheduled above the wait.
