@@ -208,14 +208,14 @@ inline bool gemm_bf16w_eligible(const GemmP& p, bool akm, bool bkm) {
 
 // `force`: whenever eligible (tests); otherwise where the 64 x 64 plan spreads a few tiles over the chip as K slices + a slab-sum launch
 // and the 64 x 32 grid fits the chip in one round, by the two kernels' measured costs (one workgroup per CU):
-// 64 x 64: 5.2 us + 1.0 us per 64-deep K-tile of a slice + 4.7 us for the slab sum; 64 x 32: 4.2 us + 1.38 us per 128-deep K-tile
+// 64 x 64: 5.3 us + 0.94 us per 64-deep K-tile of a slice + 4.7 us for the slab sum; 64 x 32: 4.4 us + 1.3 us per 128-deep K-tile
 inline bool plan_bf16w(GemmPlan& pl, const GemmP& g, bool akm, bool bkm, bool force) {
   if (!gemm_bf16w_eligible(g, akm, bkm)) return false;
   const int tm = (g.M + BF16W_BM - 1) / BF16W_BM, tn = (g.N + BF16W_BN - 1) / BF16W_BN;
   if (!force) {
     if (!(pl.mode == MFMA_BF16X3 && pl.tile == 64 && pl.kg == 4 && pl.nsplit >= 2 && !pl.persist && !pl.skinny && !pl.skinny_n)) return false;
     if ((long long)tm * tn > GEMM_CUS) return false;
-    const double est64 = 5.2 + 1.0 * ((pl.kps + 63) / 64) + 4.7, est32 = 4.2 + 1.38 * ((g.K + BF16W_BK - 1) / BF16W_BK);
+    const double est64 = 5.3 + 0.94 * ((pl.kps + 63) / 64) + 4.7, est32 = 4.4 + 1.3 * ((g.K + BF16W_BK - 1) / BF16W_BK);
     if (est32 > est64 - 0.5) return false;
   }
   const bool wants_sq = pl.sq_count > 0 || g.epi.sq_partials != nullptr;
