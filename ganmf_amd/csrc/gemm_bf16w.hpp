@@ -219,6 +219,7 @@ inline bool plan_bf16w(GemmPlan& pl, const GemmP& g, bool akm, bool bkm, bool fo
     if (est32 > est64 - 0.5) return false;
   }
   const bool wants_sq = pl.sq_count > 0 || g.epi.sq_partials != nullptr;
+  pl.est_us = 4.4 + 1.3 * ((g.K + BF16W_BK - 1) / BF16W_BK);
   pl.wide32 = 1; pl.skinny = 0; pl.skinny_n = 0; pl.persist = 0;
   pl.mode = MFMA_BF16X3; pl.tile = 64; pl.kg = BF16W_KG; pl.ring = 2; pl.bk = BF16W_BK;
   pl.tiles_m = tm; pl.tiles_n = tn; pl.nsplit = 1; pl.kps = g.K;
