@@ -32,8 +32,14 @@ the wall-clock median and the per-call overhead.  With --gpus N > 1 (or GANMF_BE
 `parallelism` (per replicated tensor: collective time and exposed join-wait time per step; RCCL's own world size; rows/s) and
 `configs3_sharded` (BASELINE.json configs[3]: one 25 000 x 50 000 shard per rank at emb_dim 32 and 1024, same protocol).
 
-Extra objects on the JSON line: `roofline` (dominant kernel of the step = the 16-wave split-bf16 GEMM of gemm_bf16k.hpp -- fp32 in, fp32-accurate, priced
-against the fp32 MFMA peak -- on its largest class; `roofline_fused_adam` = the HBM-bound launch of the two fused-Adam weight-gradient GEMMs; HIP-event timed on the
+SURVEY 8(d)'s full report: the reference runs its discriminator passes and its generator passes as separate loops (GANRec/GANMF.py:176-189
+vs 191-203), so beside `value` (whole-epoch steps/s: D and G passes as fit() issues them) the line carries `d_steps_per_s` and `g_steps_per_s`
+(D-only / G-only ganmf_train_epoch calls over the same slices, event-timed, median of five, right after the timed region) and
+`cpu_baseline.value_1thread` beside the all-threads figure.
+
+Extra objects on the JSON line: `roofline` (dominant DEVICE FUNCTION of the step = gemm_bf16k_mfma<false, true, 3, false>, the 16-wave split-bf16 GEMM of
+gemm_bf16k.hpp with a K-major B -- fp32 in, fp32-accurate, priced against the fp32 MFMA peak -- over ALL of its launch classes: `frac` = sum of
+algorithmic FLOPs / sum of launch durations; `frac_best_class` = its best class alone); `roofline_fused_adam` = the HBM-bound launch of the two fused-Adam weight-gradient GEMMs; HIP-event timed on the
 library's stream in a profiled repeat of the same steps (at least 96) right after the timed region — events
 stay out of the timed region so that `value` is not perturbed), `cpu_baseline` (the numpy fp32
 oracle = a port of the reference's per-step procedure, timed on this box's host cores on a
@@ -76,6 +82,87 @@ def run_steps(eng, perm, B, n_steps):
     return n_steps
 
 
+def run_pass_steps(eng, perm, B, n_steps, kind):
+    """n_steps updates of ONE kind ("D" | "G"): the passes of run_steps as calls of their own (ganmf_train_epoch with d_steps = 1, g_steps = 0
+    or the reverse) -- the reference's two loops, GANRec/GANMF.py:176-189 and 191-203, timed apart."""
+    per_call = len(perm) // B
+    done = 0
+    while done < n_steps:
+        c = min(per_call, n_steps - done)
+        eng.train_epoch(perm[:c * B], 1 if kind == "D" else 0, 0 if kind == "D" else 1)
+        done += c
+    return n_steps
+
+
+# The dominant DEVICE FUNCTION of the step (most kernel time of any one symbol in the rocprofv3 trace, profiles/r0N_bench_kernel_summary.md) and
+# the launch classes that run it under the default plan: the encode product of both steps and the discriminator step's decode (the generator
+# step's decode runs gemm_bf16w_mfma<true>, its dE gemm_bf16k_mfma<false, false, ...>, the D-step's dE rides in de_dcoef_kernel).
+DOMINANT_FN = "gemm_bf16k_mfma<false, true, 3, false>"
+DOMINANT_FN_CLASSES = (("D", "gemm_encode[2B,N]x[N,e]"), ("G", "gemm_encode[2B,N]x[N,e]"), ("D", "gemm_decode[2B,e]x[e,N]"))
+TRAFFIC_KEY = {"D": " (D-step)", "G": " (G-step)"}
+
+
+def roofline_objects(prof_d, prof_g, traffic=None, traffic_source=None):
+    """`roofline` (+ `roofline_fused_adam`, the per-class `kernels` table) from the library's profiled D-only and G-only repeats.
+    `roofline.frac` is the dominant device function over ALL of its classes: sum of algorithmic FLOPs / sum of launch durations / peak;
+    `frac_best_class` its best class alone; `frac_time_weighted` every launch class of the 16-wave GEMM family (combined launches included)."""
+    rows = [dict(p, step="D") for p in prof_d] + [dict(p, step="G") for p in prof_g]
+    kernels = []
+    for p in rows:
+        avg_ms = p["ms"] / max(p["launches"], 1)
+        row = {"step": p["step"], "name": p["name"], "launches": p["launches"], "avg_us": round(avg_ms * 1e3, 2), "total_ms": round(p["ms"], 3)}
+        if p["flops"] > 0:
+            row["tflops"] = round(p["flops"] / max(p["ms"], 1e-9) / 1e9, 2)
+        if p["bytes"] > 0:
+            row["gbs"] = round(p["bytes"] / max(p["ms"], 1e-9) / 1e6, 1)
+        kernels.append(row)
+    gemms = [p for p in rows if p["flops"] > 0 and p["ms"] > 0]
+    fam = [p for p in gemms if not ("gWd" in p["name"] or "gWe" in p["name"] or "gV" in p["name"])]
+    fused = [p for p in gemms if "gWd" in p["name"] or "gWe" in p["name"]]
+    dom = [p for p in fam if (p["step"], p["name"]) in DOMINANT_FN_CLASSES] or fam or gemms      # (another plan: the whole family)
+    roofline = None
+    if dom:
+        fl, ms, n = sum(p["flops"] for p in dom), sum(p["ms"] for p in dom), sum(p["launches"] for p in dom)
+        tf = fl / ms / 1e9
+        classes = [{"step": p["step"], "name": p["name"], "launches": p["launches"], "avg_launch_us": round(p["ms"] / p["launches"] * 1e3, 2),
+                    "achieved": round(p["flops"] / p["ms"] / 1e9, 2), "frac": round(p["flops"] / p["ms"] / 1e9 / PEAK_F32_MFMA_TFLOPS, 4)} for p in dom]
+        best = max(classes, key=lambda c: c["frac"])
+        roofline = {"kernel": DOMINANT_FN + " (gemm_bf16k.hpp; all of its launch classes)", "bound": "mfma", "achieved": round(tf, 2),
+                    "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "flops_per_launch": fl / n, "avg_launch_us": round(ms / n * 1e3, 2), "launches": n, "classes": classes,
+                    "frac_best_class": best["frac"], "best_class": "%s:%s" % (best["step"], best["name"])}
+        if fam:
+            fam_tf = sum(p["flops"] for p in fam) / sum(p["ms"] for p in fam) / 1e9
+            roofline["frac_time_weighted"] = round(fam_tf / PEAK_F32_MFMA_TFLOPS, 4)
+            roofline["achieved_time_weighted"] = round(fam_tf, 2)
+            roofline["classes_time_weighted"] = ["%s:%s" % (p["step"], p["name"]) for p in fam]
+        if traffic:      # HBM bytes per launch from the committed rocprofv3 PMC passes, launch-weighted over the function's classes
+            hit = [(p, traffic.get(p["name"] + TRAFFIC_KEY[p["step"]])) for p in dom]
+            if hit and all(v for _, v in hit):
+                roofline["traffic"] = round(sum(v["hbm_bytes_per_launch"] * p["launches"] for p, v in hit) / n)
+                roofline["algorithmic_bytes_per_launch"] = round(sum(v["algorithmic_bytes"] * p["launches"] for p, v in hit) / n)
+                roofline["traffic_source"] = traffic_source
+    roofline_fused = None
+    if fused:
+        fa_ms = sum(p["ms"] for p in fused)
+        fa_n = max(p["launches"] for p in fused)          # per discriminator step
+        fa_bytes = sum(p["bytes"] for p in fused)          # operands once + the six Adam streams (theta, m, v in and out)
+        roofline_fused = {"kernel": " + ".join(p["name"] for p in fused), "bound": "hbm",
+                          "achieved": round(fa_bytes / fa_ms / 1e6, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                          "frac": round(fa_bytes / fa_ms / 1e6 / PEAK_HBM_GBS, 4), "traffic": None,
+                          "algorithmic_bytes_per_step": round(fa_bytes / fa_n),
+                          "avg_us_per_step": round(fa_ms / fa_n * 1e3, 2)}
+        if traffic:
+            fc = [v for k, v in traffic.items() if any(k.startswith(p["name"].replace(" (one launch)", "")) for p in fused)]
+            if fc:
+                roofline_fused["traffic"] = sum(v["hbm_bytes_per_launch"] for v in fc)
+                roofline_fused["traffic_source"] = traffic_source
+    if roofline is not None:
+        step_flops, step_ms = sum(p["flops"] for p in rows), sum(p["ms"] for p in rows)
+        roofline["whole_step_tflops_kernel_time"] = round(step_flops / max(step_ms, 1e-9) / 1e9, 2)
+    return roofline, roofline_fused, kernels
+
+
 def cpu_baseline(urm, params, w, seconds):
     """Port of the reference's per-step procedure (densify + dense GEMMs + dense TF-Adam) in numpy
     fp32 on the host cores; bounded sample of the same workload."""
@@ -93,22 +180,34 @@ def cpu_baseline(urm, params, w, seconds):
         X = np.asarray(urm[uids].toarray(), dtype=np.float32)
         o.g_step(uids, X)
     pair(0)  # warm-up
-    n, t0 = 0, time.perf_counter()
-    while True:
-        pair(n + 1)
-        n += 1
-        el = time.perf_counter() - t0
-        if el >= seconds or n >= 200:
-            break
+
+    def sample(budget, first):
+        n, t0 = 0, time.perf_counter()
+        while True:
+            pair(first + n)
+            n += 1
+            el = time.perf_counter() - t0
+            if el >= budget or n >= 200:
+                return n, el
+    # two thirds of the budget on all threads of the BLAS pool (`value`, `cores`), one third on ONE thread (`value_1thread`: BASELINE.md section 2
+    # quotes the reference's CPU path both ways)
+    n, el = sample(seconds * 2.0 / 3.0, 1)
     threads = os.cpu_count()
+    out1 = {}
     try:
-        from threadpoolctl import threadpool_info
+        from threadpoolctl import threadpool_info, threadpool_limits
         threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
-    except Exception:
-        pass
-    return {"value": round(2 * n / el, 3), "unit": "steps/s", "cores": int(threads), "kind": "port",
-            "sample": "%d D + %d G updates (B=%d) of the same synthetic workload, numpy fp32 oracle incl. "
-                      "URM[uids].toarray() densify and dense Adam, %.1f s" % (n, n, B, el)}
+        with threadpool_limits(limits=1):
+            n1, el1 = sample(seconds / 3.0, n + 1)
+        out1 = {"value_1thread": round(2 * n1 / el1, 3),
+                "sample_1thread": "%d D + %d G updates, BLAS pool limited to one thread (threadpoolctl), %.1f s" % (n1, n1, el1)}
+    except Exception as ex:      # (no threadpoolctl: the all-threads figure stands alone)
+        out1 = {"value_1thread": None, "sample_1thread": "not measured: %s" % ex}
+    out = {"value": round(2 * n / el, 3), "unit": "steps/s", "cores": int(threads), "kind": "port",
+           "sample": "%d D + %d G updates (B=%d) of the same synthetic workload, numpy fp32 oracle incl. "
+                     "URM[uids].toarray() densify and dense Adam, %.1f s" % (n, n, B, el)}
+    out.update(out1)
+    return out
 
 
 def launch_ranks(n, argv, script=None):
@@ -164,7 +263,10 @@ def parallelism_object(eng, prof, world, steps_profiled, rows_per_s):
     per replicated tensor the reduce-scatter + all-gather time on the side lane, the Adam pass on the rank's slice, and the time the
     MAIN lane waited at the join in front of the tensor's next reader -- the part of the collective that was NOT hidden.
     Per step = per minibatch update (D and G steps counted alike, as `value` counts them)."""
-    by = {p["name"]: p for p in prof}
+    by = {}
+    for p in prof:      # (the D-only and the G-only profiled repeat may both hold a class: summed)
+        q = by.setdefault(p["name"], {"ms": 0.0})
+        q["ms"] += p["ms"]
 
     def us(name):
         return round(by[name]["ms"] * 1e3 / max(steps_profiled, 1), 2) if name in by else 0.0
@@ -441,10 +543,36 @@ def main():
     if e32 is not None:
         e32.close()
     # ---- profiled repeat (HIP events around every launch, on the library's stream) --------------
+    # ---- the two passes timed apart (D-steps/s, G-steps/s beside the whole-epoch rate): K/2 updates of one kind per repeat, as calls of
+    # their own over the same slices, same clock and protocol as the timed region
+    half = max(steps // 2, 1)
+    split_rate, split_samples = {}, {}
+    for kind in ("D", "G"):
+        evs = []
+        for _ in range(REPEATS):
+            sync()
+            eng.timer_start()
+            run_pass_steps(eng, perm, w["B"], half, kind)
+            ev = eng.timer_stop() * 1e-3
+            sync()
+            if world > 1:
+                t = torch.tensor([ev], dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                ev = float(t.item())
+            evs.append(ev)
+        split_rate[kind] = world * half / float(np.median(evs))
+        split_samples[kind] = [round(world * half / t, 2) for t in evs]
+    # ---- profiled repeats (HIP events around every launch, on the library's stream), D passes and G passes apart so that a launch class is a
+    # (step kind, class) pair -- the discriminator step's decode and the generator step's are different kernels
+    prof_steps = max(steps, 96) // 2      # (at least 48 launches per class: a short K alone averages over too few)
     eng.profile(True)
-    run_steps(eng, perm, w["B"], max(steps, 96))      # (at least 48 launches per class: a short K alone averages over too few)
-    prof = eng.profile_read()
+    run_pass_steps(eng, perm, w["B"], prof_steps, "D")
+    prof_d = eng.profile_read()
+    eng.profile(True)                     # (clears the records)
+    run_pass_steps(eng, perm, w["B"], prof_steps, "G")
+    prof_g = eng.profile_read()
     eng.profile(False)
+    prof = prof_d + prof_g
 
     # ---- data-parallel runs verify themselves: replicas bitwise equal after all of the above, RCCL's world = the launcher's ----
     check = replica_check(eng, world, dist) if (world > 1 or force_comm) else None
@@ -452,68 +580,19 @@ def main():
 
     out = None
     if rank == 0:
-        kernels = []
-        for p in prof:
-            avg_ms = p["ms"] / max(p["launches"], 1)
-            row = {"name": p["name"], "launches": p["launches"], "avg_us": round(avg_ms * 1e3, 2),
-                   "total_ms": round(p["ms"], 3)}
-            if p["flops"] > 0:
-                row["tflops"] = round(p["flops"] / max(p["ms"], 1e-9) / 1e9, 2)
-            if p["bytes"] > 0:
-                row["gbs"] = round(p["bytes"] / max(p["ms"], 1e-9) / 1e6, 1)
-            kernels.append(row)
-        # Dominant KERNEL of the step = the device function with the most time.  The library's profile rows are classes
-        # (one per GEMM of the step); the classes below all run the 16-wave split-bf16 GEMM (gemm_bf16k.hpp bf16k_mainloop,
-        # also inside the generator / dE combined launches; GANMF_X3KG=0: the fp32 ring GEMM of gemm_f32.hpp), the two weight-gradient products run the staged split-bf16
-        # kernel with the fused Adam epilogue (one launch: wgrad_pair_kernel).  `roofline` is the largest class of the
-        # dominant kernel; the fused-Adam launch, HBM-bound, gets its own object (`roofline_fused_adam`).
-        gemms = [p for p in prof if p["flops"] > 0]
-        ring = [p for p in gemms if not ("gWd" in p["name"] or "gWe" in p["name"] or "gV" in p["name"])]
-        fused = [p for p in gemms if "gWd" in p["name"] or "gWe" in p["name"]]
-        fam = ring if sum(p["ms"] for p in ring) >= sum(p["ms"] for p in fused) or not fused else fused
-        dom = max(fam, key=lambda p: p["ms"])
-        dom_tf = dom["flops"] / dom["ms"] / 1e9
-        roofline_fused = None
-        if fused:
-            fa_ms = sum(p["ms"] for p in fused)
-            fa_n = max(p["launches"] for p in fused)          # per discriminator step
-            fa_bytes = sum(p["bytes"] for p in fused)          # operands once + the six Adam streams (theta, m, v in and out)
-            roofline_fused = {"kernel": " + ".join(p["name"] for p in fused), "bound": "hbm",
-                              "achieved": round(fa_bytes / fa_ms / 1e6, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                              "frac": round(fa_bytes / fa_ms / 1e6 / PEAK_HBM_GBS, 4), "traffic": None,
-                              "algorithmic_bytes_per_step": round(fa_bytes / fa_n),
-                              "avg_us_per_step": round(fa_ms / fa_n * 1e3, 2)}
-        roofline = {"kernel": dom["name"], "bound": "mfma", "achieved": round(dom_tf, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(dom_tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-                    "flops_per_launch": dom["flops"] / dom["launches"],
-                    "avg_launch_us": round(dom["ms"] / dom["launches"] * 1e3, 2)}
-        # the same kernel over ALL of its classes (every launch of the family, combined launches included), time-weighted:
-        # sum of algorithmic FLOPs / sum of launch durations.  `frac` above is the family's largest class.
-        fam_tf = sum(p["flops"] for p in fam) / sum(p["ms"] for p in fam) / 1e9
-        roofline["frac_time_weighted"] = round(fam_tf / PEAK_F32_MFMA_TFLOPS, 4)
-        roofline["achieved_time_weighted"] = round(fam_tf, 2)
-        roofline["classes_time_weighted"] = [p["name"] for p in fam]
-        # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in
-        # separate runs, gfx950 read correction applied: tools/collect_traffic.py); null when no profile matches
+        # Dominant DEVICE FUNCTION of the step = the symbol with the most kernel time: gemm_bf16k_mfma<false, true, 3, false> (encode of both
+        # steps, decode of the discriminator step); `roofline.frac` covers all of its launches, `frac_best_class` the best class alone,
+        # `frac_time_weighted` every class of the 16-wave GEMM family.  The fused-Adam weight-gradient launch, HBM-bound, has its own object.
+        # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 read correction
+        # applied: tools/collect_traffic.py); null when no profile matches
+        traffic, traffic_source = None, None
         try:
             import glob
             tf = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))[-1]
-            cands = [v for k, v in json.load(open(tf)).items() if k.startswith(dom["name"])]
-            if cands:
-                best = max(cands, key=lambda v: v["hbm_bytes_per_launch"])
-                roofline["traffic"] = best["hbm_bytes_per_launch"]
-                roofline["traffic_source"] = os.path.basename(tf)
-                roofline["algorithmic_bytes_per_launch"] = best["algorithmic_bytes"]
-            if roofline_fused:
-                fc = [v for k, v in json.load(open(tf)).items() if any(k.startswith(p["name"].replace(" (one launch)", "")) for p in fused)]
-                if fc:
-                    roofline_fused["traffic"] = sum(v["hbm_bytes_per_launch"] for v in fc)
-                    roofline_fused["traffic_source"] = os.path.basename(tf)
+            traffic, traffic_source = json.load(open(tf)), os.path.basename(tf)
         except Exception:
             pass
-        step_flops = sum(p["flops"] for p in prof)
-        step_ms = sum(p["ms"] for p in prof)
-        roofline["whole_step_tflops_kernel_time"] = round(step_flops / step_ms / 1e9, 2)
+        roofline, roofline_fused, kernels = roofline_objects(prof_d, prof_g, traffic, traffic_source)
         # generator / scoring GEMM at the shape the north star quotes (6040 x 3706, k = 250).  The library runs it
         # on the bf16 matrix cores with every fp32 operand split EXACTLY into three bf16 pieces and the six piece
         # products of weight >= 2^-16 accumulated in fp32 (fp32-accurate: tests/test_gpu_mfma_modes.py); `achieved`
@@ -531,15 +610,22 @@ def main():
                                      "(3 exact bf16 pieces per operand, 6 piece products on v_mfma_f32_32x32x16_bf16, fp32 accumulate) in "
                                      "16-wave workgroups (gemm_bf16k.hpp) or, for the two fused-Adam weight-gradient GEMMs, 4-wave "
                                      "workgroups; gUb + gV on the fp32 MFMA",
-                       "launches": "D-step 6, G-step 10, plus per pass: two launches in front of a discriminator pass (the CSR rows of all its full minibatches -- that launch also writes lr_t of every step of the pass -- and their generated rows: the generator is frozen during the pass) and two around a generator pass (the embeddings of the scheduled rows advanced to their step, ONE all-rows Adam over U behind the pass instead of one per step: with g_reg = 0 a row is read once and has a gradient once per pass) (generator GEMM + CSR rows, dE + d_coef, gWd + gWe, gUb + gV share a launch)",
+                       "launches": "D-step 6, G-step 8, plus per pass: two launches in front of a discriminator pass (the CSR rows of all its full minibatches -- that launch also writes lr_t of every step of the pass -- and their generated rows: the generator is frozen during the pass) and two around a generator pass (the embeddings of the scheduled rows advanced to their step, ONE all-rows Adam over U behind the pass instead of one per step: with g_reg = 0 a row is read once and has a gradient once per pass) (dE + d_coef, gWd + gWe, gUb + gV share a launch; the generator step: generator GEMM + CSR rows, encode, its slab sum, decode on 64 x 32 tiles unsplit, dE, its slab sum, dF unsplit, gUb + gV)",
                        "global_steps_per_s": round(done / el, 2), "rows_per_s": round(world * done * w["B"] / el, 1),
                        "parallelism": "dp%d (users sharded row-wise; RCCL reduce-scatter of the D and V gradients, Adam on the rank's "
                                       "slice, all-gather of the parameters)" % world},
+            "d_steps_per_s": round(split_rate["D"], 2), "g_steps_per_s": round(split_rate["G"], 2),
+            "pass_rates": {"protocol": "K/2 = %d updates of one kind per repeat as D-only / G-only ganmf_train_epoch calls over the same slices, hipEvent-timed, "
+                                       "median of %d, right after the timed region (the reference's two loops, GANRec/GANMF.py:176-189 / 191-203)" % (half, REPEATS),
+                           "d_samples": split_samples["D"], "g_samples": split_samples["G"],
+                           "harmonic_mean_steps_per_s": round(2.0 / (1.0 / split_rate["D"] + 1.0 / split_rate["G"]), 2),
+                           "kernel_us_per_step": {"D": round(sum(p["ms"] for p in prof_d) * 1e3 / max(prof_steps, 1), 2),
+                                                  "G": round(sum(p["ms"] for p in prof_g) * 1e3 / max(prof_steps, 1), 2)}},
             "timing": timing, "roofline": roofline, "roofline_fused_adam": roofline_fused, "scoring_gemm": scoring, "kernels": kernels,
             "reference_derived_steps_per_s": 84.0,
         }
         if world > 1 or force_comm:
-            out["parallelism"] = parallelism_object(eng, prof, world, max(steps, 96), world * done * w["B"] / el)
+            out["parallelism"] = parallelism_object(eng, prof, world, 2 * prof_steps, world * done * w["B"] / el)
             out["parallelism"].update(check)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(urm, params, w, args.cpu_seconds)

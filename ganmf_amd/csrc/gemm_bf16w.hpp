@@ -202,9 +202,14 @@ __global__ __launch_bounds__(1024) void gemm_bf16w_mfma(const GemmP p) {
 
 // NT / NN products of plain fp32 matrices with nothing in the fetch path that the 64 x 64 kernels' items carry
 inline bool gemm_bf16w_eligible(const GemmP& p, bool akm, bool bkm) {
+  // leading dimensions: the kernel issues 16-byte loads at A + row * lda + 8 c and B + row * ldb + 4 c, and its K-tail logic reads up to the next
+  // multiple of 64 past K inside a row (zero pads, as every matrix of the library has them, handle.inc LD_ALIGN) -- anything else stays on 64 x 64
   return !akm && std::max(p.nbatch, 1) == 1 && !p.a_gather && !p.a_planes && !p.b_planes && !p.epi.csr_indptr && !p.epi.sp_rows &&
-         p.epi.kind != EPI_ADAM && p.K >= 1;
+         p.epi.kind != EPI_ADAM && p.K >= 1 && (p.lda % 64) == 0 && (p.ldb % 64) == 0;      // (the zero page is checked at dispatch: plans are drawn before it is filled in)
 }
+// out-of-range rows read zero_page + (tid & 255) * 8 + 0..7: the page must hold at least this many floats (the handle's: 2048 + 64, abi_core.inc)
+constexpr int BF16W_ZERO_PAGE_FLOATS = 255 * 8 + 8;
+static_assert(BF16W_ZERO_PAGE_FLOATS <= 2048 + 64, "gemm_bf16w reads past the library's zero page");
 
 // `force`: whenever eligible (tests); otherwise where the 64 x 64 plan spreads a few tiles over the chip as K slices + a slab-sum launch
 // and the 64 x 32 grid fits the chip in one round, by the two kernels' measured costs (one workgroup per CU):
@@ -231,6 +236,7 @@ inline hipError_t gemm_dispatch_bf16w(hipStream_t st, const GemmP& p, bool bkm) 
   const int grid = p.tiles_m * p.tiles_n * std::max(p.nbatch, 1);
   if (grid <= 0) return hipSuccess;
   if (p.nsplit != 1 || p.tiles_m != (p.M + BF16W_BM - 1) / BF16W_BM || p.tiles_n != (p.N + BF16W_BN - 1) / BF16W_BN) return hipErrorInvalidValue;
+  if (!p.zero_page || (p.lda % 64) != 0 || (p.ldb % 64) != 0) return hipErrorInvalidValue;      // (gemm_bf16w_eligible: never a silent out-of-bounds read)
   if (bkm) GANMF_LAUNCH(gemm_bf16w_mfma<true>, dim3(grid), dim3(1024), 0, st, p);
   else GANMF_LAUNCH(gemm_bf16w_mfma<false>, dim3(grid), dim3(1024), 0, st, p);
   return hipGetLastError();

@@ -89,6 +89,56 @@ def test_parallelism_object_shape():
     json.dumps(p)
 
 
+def test_roofline_is_the_dominant_device_function_over_all_its_classes():
+    """SURVEY 8(d) on the driver line: `roofline.frac` = sum of algorithmic FLOPs / sum of launch durations over EVERY launch class of the
+    dominant device function (gemm_bf16k_mfma<false, true, 3, false>: encode of both steps + the discriminator step's decode), the best class
+    beside it as `frac_best_class`; traffic launch-weighted from the PMC file; every `kernels` row says which step it belongs to."""
+    b = _bench()
+    enc, dec = "gemm_encode[2B,N]x[N,e]", "gemm_decode[2B,e]x[e,N]"
+    prof_d = [{"name": enc, "launches": 48, "ms": 48 * 0.018, "flops": 48 * 1.8828e9, "bytes": 1.0},
+              {"name": dec, "launches": 48, "ms": 48 * 0.0204, "flops": 48 * 1.8848e9, "bytes": 1.0},
+              {"name": "reduce_encode", "launches": 48, "ms": 0.24, "flops": 0, "bytes": 1.0},
+              {"name": "gemm_gWd + gemm_gWe, fused Adam (one launch)", "launches": 48, "ms": 48 * 0.045, "flops": 48 * 3.77e9, "bytes": 48 * 186.2e6}]
+    prof_g = [{"name": enc, "launches": 48, "ms": 48 * 0.0178, "flops": 48 * 1.8828e9, "bytes": 1.0},
+              {"name": dec, "launches": 48, "ms": 48 * 0.0148, "flops": 48 * 0.9424e9, "bytes": 1.0},      # (gemm_bf16w_mfma: not the dominant function)
+              {"name": "gemm_dF[B,e]x[N,e]^T", "launches": 48, "ms": 48 * 0.0146, "flops": 48 * 0.9414e9, "bytes": 1.0}]
+    traffic = {enc + " (D-step)": {"hbm_bytes_per_launch": 27.0e6, "algorithmic_bytes": 19.5e6},
+               enc + " (G-step)": {"hbm_bytes_per_launch": 27.0e6, "algorithmic_bytes": 19.5e6},
+               dec + " (D-step)": {"hbm_bytes_per_launch": 33.0e6, "algorithmic_bytes": 23.3e6},
+               "gemm_gWd + gemm_gWe, fused Adam (D-step)": {"hbm_bytes_per_launch": 210.7e6, "algorithmic_bytes": 186.2e6}}
+    r, rf, kernels = b.roofline_objects(prof_d, prof_g, traffic, "rXX_traffic.json")
+    fl = 2 * 1.8828e9 + 1.8848e9
+    us = 18.0 + 17.8 + 20.4
+    assert r["kernel"].startswith("gemm_bf16k_mfma<false, true, 3, false>") and r["bound"] == "mfma" and r["launches"] == 144
+    assert abs(r["achieved"] - fl / us / 1e6) < 0.05 and abs(r["frac"] - fl / us / 1e6 / b.PEAK_F32_MFMA_TFLOPS) < 1e-3
+    assert [(c["step"], c["name"]) for c in r["classes"]] == [("D", enc), ("D", dec), ("G", enc)]
+    assert r["best_class"] == "G:" + enc and r["frac_best_class"] > r["frac"] > min(c["frac"] for c in r["classes"])
+    assert r["frac_time_weighted"] < r["frac"]            # the generator step's M = 128 products pull the family down
+    assert r["traffic"] == round((27.0e6 * 2 + 33.0e6) / 3) and r["traffic_source"] == "rXX_traffic.json"
+    assert abs(r["avg_launch_us"] - us / 3) < 0.01
+    assert rf["bound"] == "hbm" and abs(rf["achieved"] - 186.2e6 / 45e-6 / 1e9) < 1.0 and rf["traffic"] == 210.7e6
+    assert {k["step"] for k in kernels} == {"D", "G"} and len(kernels) == 7
+    json.dumps([r, rf, kernels])
+    # another plan (none of the dominant function's classes present): the object falls back to the whole 16-wave family instead of vanishing
+    r2, _, _ = b.roofline_objects([], prof_g[1:], None, None)
+    assert r2["traffic"] is None and r2["launches"] == 96
+
+
+def test_cpu_baseline_reports_all_threads_and_one_thread(monkeypatch):
+    """`cpu_baseline` carries SURVEY 8(d)'s two CPU figures: `value` on the BLAS pool's threads (`cores`) and `value_1thread`."""
+    import numpy as np
+    import scipy.sparse as sps
+    b = _bench()
+    w = dict(U=64, N=96, k=8, e=16, B=16, hp=dict(d_lr=1e-4, g_lr=1e-4, d_reg=1e-4, g_reg=0.0, m=10.0, recon_coefficient=0.01))
+    rng = np.random.RandomState(0)
+    urm = sps.csr_matrix((rng.rand(w["U"], w["N"]) < 0.1).astype(np.float32))
+    from ganmf_amd.synthetic import glorot_params
+    out = b.cpu_baseline(urm, glorot_params(w["U"], w["N"], w["k"], w["e"], seed=1), w, 0.6)
+    assert out["kind"] == "port" and out["unit"] == "steps/s" and out["value"] > 0 and out["cores"] >= 1
+    assert out["value_1thread"] is not None and out["value_1thread"] > 0 and "one thread" in out["sample_1thread"]
+    json.dumps(out)
+
+
 class _ReplicaEng(object):
     """stand-in engine: five replicated tensors, what RCCL would report as its world size"""
 

@@ -172,12 +172,12 @@ def test_gemm_split_bf16_k_groups(akm, bkm, shape, nsplit, monkeypatch):
 
 
 @pytest.mark.parametrize("shape", [(128, 3706, 992), (128, 3706, 993), (64, 32, 128), (1, 1, 1), (65, 33, 129), (100, 70, 1030), (128, 2113, 748),
-                                   (37, 500, 384), (200, 100, 257), (64, 96, 2000)])
+                                   (37, 500, 384), (200, 100, 257), (64, 96, 2000), (70, 40, 100), (33, 64, 256)])
 @pytest.mark.parametrize("bkm", [False, True])
 def test_gemm_bf16w_64x32_tiles(shape, bkm, monkeypatch):
     """gemm_bf16w.hpp: the 16-wave split-bf16 loop on 64 x 32 tiles with 128-deep K-tiles (eight K groups), unsplit, B K-contiguous (dF of
-    the generator step) or K-major (its decode: [k][32 n] image, transposing fragment reads) -- the ML-1M and hetrec shapes, 1 .. 16 K-tiles (fewer than the three prefetch slots, tile counts that are no
-    multiple of three), K tails, a last K-tile that reaches past the leading dimension (K = 1030: ld 1088 < 1152), ragged rows and
+    the generator step) or K-major (its decode: [k][32 n] image, transposing fragment reads) -- the ML-1M and hetrec shapes, 1 .. 16 K-tiles (BF16W_PD = 2 K-tiles in flight: one K-tile, K <= 128, leaves the
+    second prologue slot past the range -- requested from the zero page --, two K-tiles, K = 129 .. 256, fill both; odd and even tile counts), K tails, a last K-tile that reaches past the leading dimension (K = 1030: ld 1088 < 1152), ragged rows and
     columns.  fp32-accurate like the 64 x 64 kernel, run-to-run identical, and another kernel than the default plan's."""
     from ganmf_amd.engine import gemm_f32
     M, N, K = shape
@@ -216,7 +216,7 @@ def test_gemm_skinny_k_stream(akm, bkm, shape, monkeypatch):
 
 @pytest.mark.parametrize("bkm", [False, True])
 @pytest.mark.parametrize("shape", [(256, 32, 50001), (128, 32, 50000), (100, 17, 42001), (300, 32, 14100), (257, 31, 16385), (2049, 5, 2050)])
-def test_gemm_skinny_n_stream(bkm, shape, monkeypatch):
+def test_gemm_skinny_n_stream(bkm, shape, monkeypatch, capfd):
     """gemm_skinny.hpp gemm_skinny_n_kernel: N <= 32 behind a long K (encode and dE at emb_dim 32: a [2B, 50 000] activation read once for
     a [2B, 32] result) as a stream on the fp32 MFMA, one 256-wide K slice per workgroup, slabs summed in split order -- the default for such
     shapes; against the fp64 product and the tiled kernels (GANMF_TUNE=skinny=0).  Ragged rows (more than one 256-row block too), fewer than
@@ -226,11 +226,14 @@ def test_gemm_skinny_n_stream(bkm, shape, monkeypatch):
     rng = np.random.RandomState(M + N + K)
     A, B, ref, bound = _mk(rng, M, N, K, False, bkm)
     monkeypatch.setenv("GANMF_DEBUG_PLAN", "1")
+    capfd.readouterr()
     out, _ = gemm_f32(A, B, False, bkm)
+    assert "skinny-N stream" in capfd.readouterr().err, "the planner did not select gemm_skinny_n_kernel for %r" % (shape,)
     err = np.abs(out - ref)
     assert np.all(err <= 4e-7 * bound * np.sqrt(K) + 1e-30), float((err / (bound + 1e-30)).max())
     again, _ = gemm_f32(A, B, False, bkm)
     assert np.array_equal(out, again)
     monkeypatch.setenv("GANMF_TUNE", "skinny=0")
     tiled, _ = gemm_f32(A, B, False, bkm)
+    assert "skinny-N stream" not in capfd.readouterr().err
     assert np.all(np.abs(tiled - out) <= 8e-7 * bound * np.sqrt(K) + 1e-30)

@@ -77,6 +77,29 @@ def test_wgrad_blocked_tile_order_bit_identical(shape, monkeypatch):
             np.testing.assert_array_equal(got[n], ref[n], err_msg="%s, wgrad_xb=%s" % (n, xb))
 
 
+@pytest.mark.parametrize("shape,d_steps", [
+    ((900, 3706, 32, 992, 128), 2),    # the ML-1M tile grid, staged discriminator passes (every step its own lr_t slot), two passes per call
+    ((230, 300, 16, 70, 64), 1),       # three full minibatches: no staged pass, the lr_t slot alternates; ragged last minibatch
+])
+def test_wd_on_the_side_lane_bit_identical(shape, d_steps, monkeypatch):
+    """GANMF_TUNE wd_lane (off by default: measured slower, profiles/r06_wd_lane.md): gWd_ext + Adam(Wd) of a discriminator step on the side
+    lane, under the next step's encode GEMM, joined in front of the next reader of Wd (the next decode GEMM, the generator pass, the end of
+    the call); gWe_ext + Adam(We) on the main lane.  The same kernel with an empty block range for the other product: every tensor, both
+    Adam moments and every loss bit for bit what the paired launch gives.  1: forked behind gWe_ext, 2: behind the slab sum of dE."""
+    U, N, k, e, B = shape
+    hp = dict(d_lr=1e-4, g_lr=2e-4, d_reg=1e-4, g_reg=0.0, m=10.0, recon_coefficient=0.05)
+    monkeypatch.setenv("GANMF_TUNE", "wd_lane=0")
+    ref, ref_l = _run(monkeypatch, 31, 1, U, N, k, e, B, hp, epochs=2, d_steps=d_steps)
+    for mode in ("1", "2"):
+        monkeypatch.setenv("GANMF_TUNE", "wd_lane=" + mode)
+        got, got_l = _run(monkeypatch, 31, 1, U, N, k, e, B, hp, epochs=2, d_steps=d_steps)
+        for (dl, gl), (dr, gr) in zip(got_l, ref_l):
+            np.testing.assert_array_equal(dl, dr, err_msg="D losses, wd_lane=" + mode)
+            np.testing.assert_array_equal(gl, gr, err_msg="G losses, wd_lane=" + mode)
+        for n in ref:
+            np.testing.assert_array_equal(got[n], ref[n], err_msg="%s, wd_lane=%s" % (n, mode))
+
+
 def test_second_item_buffer_survives_snapshot_and_restore(monkeypatch):
     """The fused gV update ping-pongs item_embeddings between two buffers: best-weights snapshot / restore and a tensor
     upload in the middle of training must act on the live one (an odd number of generator steps leaves it in the second)."""

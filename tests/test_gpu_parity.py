@@ -303,3 +303,30 @@ def test_stream_timer_and_comm_info():
     b.comm_init_local(4242)
     assert a.comm_info() == (2, 0) and b.comm_info() == (2, 1)
     a.close(); b.close()
+
+
+def test_rccl_comm_abort_stops_every_collective(monkeypatch):
+    """ganmf_comm_abort on an RCCL communicator (ncclCommAbort frees it): from then on every entry that would touch the communicator --
+    the collectives inside a training call (forced here on a one-rank communicator, so that the RCCL call sites execute) and
+    ganmf_comm_info -- returns an error instead of handing freed memory to RCCL; abort is idempotent and the handle still closes."""
+    from ganmf_amd._lib import GanmfError
+    from ganmf_amd.engine import Engine, comm_unique_id
+    monkeypatch.setenv("GANMF_FORCE_COLLECTIVES", "1")
+    rng = np.random.RandomState(9)
+    U, N, k, e, B = 150, 210, 9, 17, 32
+    urm = _rand_urm(rng, U, N, 0.08)
+    dp = Engine(U, N, k, e, B, world_size=1, rank=0, **HP)
+    dp.set_urm(urm)
+    dp.comm_init(comm_unique_id())
+    perm = rng.permutation(U)
+    steps = -(-U // B)
+    rows = np.minimum(B, U - np.arange(steps) * B).astype(np.int32)
+    dl, gl = dp.train_epoch(perm, 1, 1, steps_per_pass=steps, global_batch_rows=rows)
+    assert np.isfinite(dl).all() and np.isfinite(gl).all()
+    dp.comm_abort()
+    dp.comm_abort()
+    with pytest.raises(GanmfError, match="aborted"):
+        dp.train_epoch(perm, 1, 1, steps_per_pass=steps, global_batch_rows=rows)
+    with pytest.raises(GanmfError, match="aborted"):
+        dp.comm_info()
+    dp.close()

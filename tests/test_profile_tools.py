@@ -158,3 +158,38 @@ def test_asm_prefetch_lint_on_the_shipped_kernels():
     res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_asm_prefetch.py")], capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     assert "checked" in res.stdout and " 0 reads" in res.stdout
+
+
+def _make(*args, timeout=900):
+    import subprocess
+    return subprocess.run(["make", "-C", os.path.join(ROOT, "ganmf_amd", "csrc")] + list(args), capture_output=True, text=True, timeout=timeout)
+
+
+def test_build_runs_the_asm_prefetch_lint_and_fails_on_a_finding(tmp_path):
+    """csrc/Makefile: the default target runs tools/check_asm_prefetch.py in front of the compile (a hash comparison on an unchanged tree) and a
+    finding fails the build before anything is compiled or overwritten.  The lint command is the Makefile's ASM_LINT variable: a stand-in
+    that reports a finding (exit 1) must stop `make`; the real one on the shipped tree must pass and leave its stamp, after which a second
+    run is the hash comparison only."""
+    import time
+    bad = _make("ASM_LINT=echo seeded finding; exit 1", "OUT=" + str(tmp_path / "never.so"), "-B")
+    assert bad.returncode != 0 and "seeded finding" in bad.stdout and not (tmp_path / "never.so").exists(), bad.stdout[-500:] + bad.stderr[-500:]
+    good = _make("asm_lint")
+    assert good.returncode == 0, good.stdout[-2000:] + good.stderr[-2000:]
+    stamp = os.path.join(ROOT, "ganmf_amd", "csrc", ".asm_lint.stamp")
+    assert os.path.exists(stamp) and len(open(stamp).read().strip()) == 64
+    t0 = time.time()
+    assert _make("asm_lint").returncode == 0
+    assert time.time() - t0 < 10.0, "an unchanged tree must not pay for the lint again"
+
+
+def test_build_refuses_an_untested_hipcc():
+    """csrc/Makefile: another hipcc than the tested one fails the build; ALLOW_UNTESTED_HIPCC=1 builds with the inline-asm kernels off as the
+    compiled default (-DGANMF_ASM_PREFETCH_UNTESTED: GANMF_X3KG=0, bf16w=0 in abi_core.inc).  `make -n`: nothing is compiled here."""
+    res = _make("-n", "-B", "HIPCC_TESTED=0.0.0")
+    assert res.returncode != 0 and "is not the tested 0.0.0" in res.stderr, res.stderr[-500:]
+    res = _make("-n", "-B", "HIPCC_TESTED=0.0.0", "ALLOW_UNTESTED_HIPCC=1")
+    assert res.returncode == 0 and "-DGANMF_ASM_PREFETCH_UNTESTED" in res.stdout, res.stdout[-500:] + res.stderr[-500:]
+    res = _make("-n", "-B")
+    assert res.returncode == 0 and "GANMF_ASM_PREFETCH_UNTESTED" not in res.stdout
+    src = open(os.path.join(ROOT, "ganmf_amd", "csrc", "lib", "abi_core.inc")).read()
+    assert "GANMF_ASM_PREFETCH_UNTESTED" in src and 'env_int("GANMF_X3KG", kAsmPrefetchDefault ? 7 : 0)' in src

@@ -27,5 +27,5 @@ for rep in range(reps):
             continue
         extra = ""
         if cls:
-            extra = "  ".join("%s %.2f us" % (k["name"][:28], k["avg_us"]) for k in d["kernels"] if cls in k["name"])
-        print("%-50s %8.1f steps/s  tw %.3f  %s" % (spec or "(default)", d["value"], d["roofline"].get("frac_time_weighted", 0), extra), flush=True)
+            extra = "  ".join("%s:%s %.2f us" % (k.get("step", "?"), k["name"][:28], k["avg_us"]) for k in d["kernels"] if cls in k["name"])
+        print("%-50s %8.1f steps/s  D %8.1f  G %8.1f  fn %.3f  %s" % (spec or "(default)", d["value"], d.get("d_steps_per_s", 0), d.get("g_steps_per_s", 0), d["roofline"].get("frac", 0), extra), flush=True)
