@@ -191,17 +191,30 @@ def cpu_baseline(urm, params, w, seconds):
                 return n, el
     # two thirds of the budget on all threads of the BLAS pool (`value`, `cores`), one third on ONE thread (`value_1thread`: BASELINE.md section 2
     # quotes the reference's CPU path both ways)
-    n, el = sample(seconds * 2.0 / 3.0, 1)
-    threads = os.cpu_count()
+    # The pool never gets more threads than this process may run on (affinity mask and cgroup CPU quota: a 64-thread OpenBLAS pool on a 16-CPU share
+    # of the box ran this workload at 8 steps/s against 19 on ONE thread -- oversubscription, not the CPU's speed).
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            avail = max(1, min(avail, int(float(quota) / float(period))))
+    except Exception:
+        pass
+    threads = avail
     out1 = {}
     try:
         from threadpoolctl import threadpool_info, threadpool_limits
-        threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+        pool = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+        threads = max(1, min(pool, avail))
+        with threadpool_limits(limits=threads):
+            n, el = sample(seconds * 2.0 / 3.0, 1)
         with threadpool_limits(limits=1):
             n1, el1 = sample(seconds / 3.0, n + 1)
         out1 = {"value_1thread": round(2 * n1 / el1, 3),
                 "sample_1thread": "%d D + %d G updates, BLAS pool limited to one thread (threadpoolctl), %.1f s" % (n1, n1, el1)}
-    except Exception as ex:      # (no threadpoolctl: the all-threads figure stands alone)
+    except ImportError as ex:      # (no threadpoolctl: the pool's own thread count, no one-thread figure)
+        n, el = sample(seconds, 1)
+        threads = os.cpu_count() or 1
         out1 = {"value_1thread": None, "sample_1thread": "not measured: %s" % ex}
     out = {"value": round(2 * n / el, 3), "unit": "steps/s", "cores": int(threads), "kind": "port",
            "sample": "%d D + %d G updates (B=%d) of the same synthetic workload, numpy fp32 oracle incl. "
@@ -545,7 +558,8 @@ def main():
     # ---- profiled repeat (HIP events around every launch, on the library's stream) --------------
     # ---- the two passes timed apart (D-steps/s, G-steps/s beside the whole-epoch rate): K/2 updates of one kind per repeat, as calls of
     # their own over the same slices, same clock and protocol as the timed region
-    half = max(steps // 2, 1)
+    # (at least one whole pass over the shard per repeat, as the reference's loops run them: a 10-update call would mostly time its own set-up)
+    half = max(steps // 2, len(perm) // w["B"], 1)
     split_rate, split_samples = {}, {}
     for kind in ("D", "G"):
         evs = []
@@ -615,7 +629,7 @@ def main():
                        "parallelism": "dp%d (users sharded row-wise; RCCL reduce-scatter of the D and V gradients, Adam on the rank's "
                                       "slice, all-gather of the parameters)" % world},
             "d_steps_per_s": round(split_rate["D"], 2), "g_steps_per_s": round(split_rate["G"], 2),
-            "pass_rates": {"protocol": "K/2 = %d updates of one kind per repeat as D-only / G-only ganmf_train_epoch calls over the same slices, hipEvent-timed, "
+            "pass_rates": {"protocol": "max(K/2, one pass over the shard) = %d updates of one kind per repeat as D-only / G-only ganmf_train_epoch calls over the same slices, hipEvent-timed, "
                                        "median of %d, right after the timed region (the reference's two loops, GANRec/GANMF.py:176-189 / 191-203)" % (half, REPEATS),
                            "d_samples": split_samples["D"], "g_samples": split_samples["G"],
                            "harmonic_mean_steps_per_s": round(2.0 / (1.0 / split_rate["D"] + 1.0 / split_rate["G"]), 2),

@@ -93,6 +93,12 @@ struct SplitItemK {
 };
 
 constexpr int BF16K_OPER = 3 * (64 * 64 / 2) * 2;      // dwords of one plane buffer: three pieces x (A + B) = 48 KiB
+// ... of the loop with NPIECE pieces per operand: the one-piece forms (operands rounded to a single bf16 / fp16) file ONE plane per operand, 16 KiB
+// per buffer -- their workgroup then needs the 64 KiB of the epilogue's four staged partial tiles, not 96 KiB, and two of them share a CU
+// (round 6: the low-precision gUb + gV pair launch has more workgroups than CUs, as the fp32 pair_kernel<4, 2> does)
+template <int NPIECE> constexpr int bf16k_oper() { return NPIECE * (64 * 64 / 2) * 2; }
+template <int NPIECE> constexpr int bf16k_smem_dw() { return 2 * bf16k_oper<NPIECE>() > 4 * 64 * 64 ? 2 * bf16k_oper<NPIECE>() : 4 * 64 * 64; }
+static_assert(bf16k_oper<3>() == BF16K_OPER && bf16k_smem_dw<3>() == 2 * BF16K_OPER && bf16k_smem_dw<1>() == 4 * 64 * 64, "plane buffers");
 // K-tiles in flight in registers.  Three-piece loop (1.0 us per K-tile): TWO -- 2 us of fetch in flight cover the latency, and a launch that
 // opens with half the requests per CU leaves more of the fabric to its neighbours' tails: the step + 1.4-1.8 % on the slower boxes against
 // the four of rounds 3-4 (8 722 -> 8 875, 8 746 -> 8 868 in one-call alternations; three: + 1.0 %), + 2.7 % on a fast one (9 000-9 070 ->
@@ -150,7 +156,8 @@ __device__ __forceinline__ void bf16k_mainloop(const GemmP& p, const int tm, con
   if (stage_a) it.init(AKM, p.A + (size_t)bz * p.a_batch_stride, p.lda, m0, p.M, kbeg, p.zero_page, tid,
                        (AKM || !p.a_gather) ? nullptr : p.a_gather + (size_t)bz * p.a_gather_batch);
   else it.init(BKM, p.B, p.ldb, n0, p.N, kbeg, p.zero_page, tid - 512);
-  unsigned* const my_planes = buf + (stage_a ? 0 : 3 * FA::PLANE) + it.dst;      // this thread's 16 bytes of piece 0, buffer 0
+  constexpr int OPER = bf16k_oper<NPIECE>();      // dwords of one plane buffer: [A planes x NPIECE | B planes x NPIECE]
+  unsigned* const my_planes = buf + (stage_a ? 0 : NPIECE * FA::PLANE) + it.dst;      // this thread's 16 bytes of piece 0, buffer 0
   const float my_scale = stage_a ? sa : sb;
 
   f32x4k rg[PD][2];
@@ -183,7 +190,7 @@ __device__ __forceinline__ void bf16k_mainloop(const GemmP& p, const int tm, con
     } else
 #endif
     it.template split<NPIECE, F16>(v, pc, tok, my_scale);
-    unsigned* o = my_planes + b * BF16K_OPER;
+    unsigned* o = my_planes + b * OPER;
     if (it.km) {      // (wave-uniform) K-major image: the item's two k-rows are two 8-byte stores per piece
       typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
@@ -209,12 +216,12 @@ __device__ __forceinline__ void bf16k_mainloop(const GemmP& p, const int tm, con
 
   auto step = [&](auto ss, int t) {      // K-tile t, whose registers were slot s = t % PD (consumed in iteration t - 1)
     constexpr int s = decltype(ss)::value, s1 = (s + 1) % PD;
-    const unsigned* planes = buf + (t & 1) * BF16K_OPER;
+    const unsigned* planes = buf + (t & 1) * OPER;
     u32x4 pa[3], pb[3];
 #pragma unroll
     for (int q = 0; q < NPIECE; ++q) pa[q] = FA::frag(planes + q * FA::PLANE, wr * 32, kg, li, lh);
 #pragma unroll
-    for (int q = 0; q < NPIECE; ++q) pb[q] = FB::frag(planes + 3 * FA::PLANE + q * FB::PLANE, wc * 32, kg, li, lh);
+    for (int q = 0; q < NPIECE; ++q) pb[q] = FB::frag(planes + NPIECE * FA::PLANE + q * FB::PLANE, wc * 32, kg, li, lh);
     // the registers of tile t are free: request tile t + PD into them (before the MFMAs: the longer the fetch has)
 #ifdef GANMF_PERSIST_DIAG_BUILD
     if (p.diag & 16) { if (t + PD < nt) kleft -= BK; } else      // timing only: no operand fetches after the prologue
@@ -263,13 +270,13 @@ __device__ __forceinline__ void gemm_bf16k_body(const GemmP& p, const int bid, c
   tile_coords(p, bid, nblk, tm, tn, sp, bz);
   f32x16 acc[1][1];
   bf16k_mainloop<AKM, BKM, NPIECE, F16, 0>(p, tm, tn, sp, bz, smem, acc[0][0], [] {});
-  static_assert(4 * 64 * 64 <= 2 * BF16K_OPER, "the plane buffers must hold the four staged partial tiles");
+  static_assert(4 * 64 * 64 <= bf16k_smem_dw<NPIECE>(), "the workgroup's LDS must hold the four staged partial tiles");
   gemm_epilogue<64, 64, 1, 1, 4, AKM && BKM>(p, acc, smem, TileCoord{tm, tn, sp, bz, tm * 64, tn * 64});
 }
 
 template <bool AKM, bool BKM, int NPIECE = 3, bool F16 = false>
 __global__ __launch_bounds__(1024) void gemm_bf16k_mfma(const GemmP p) {
-  __shared__ __attribute__((aligned(16))) float smem[2 * BF16K_OPER];      // 96 KiB: one workgroup per CU
+  __shared__ __attribute__((aligned(16))) float smem[bf16k_smem_dw<NPIECE>()];      // three pieces: 96 KiB, one workgroup per CU; one piece: 64 KiB
   gemm_bf16k_body<AKM, BKM, NPIECE, F16>(p, (int)blockIdx.x, (int)gridDim.x, smem);
 }
 

@@ -41,9 +41,22 @@ __device__ __forceinline__ int bf16w_wait_vm(int n, const f32x4k& v0, const f32x
   return tok;
 }
 
-template <bool BKM>
+// dwords of one plane buffer of the loop with NPIECE pieces per operand, and of the workgroup's LDS (the eight K groups' partial tiles meet there)
+template <int NPIECE> constexpr int bf16w_oper() { return NPIECE * (BF16W_PA + BF16W_PB); }
+template <int NPIECE> constexpr int bf16w_smem_dw() {
+  return 2 * bf16w_oper<NPIECE>() > BF16W_KG * BF16W_BM * BF16W_BN ? 2 * bf16w_oper<NPIECE>() : BF16W_KG * BF16W_BM * BF16W_BN;
+}
+static_assert(bf16w_oper<3>() == BF16W_OPER && bf16w_smem_dw<3>() == 2 * BF16W_OPER && bf16w_smem_dw<1>() == BF16W_KG * BF16W_BM * BF16W_BN, "plane buffers");
+
+// NPIECE = 3: the exact three-way split (fp32-accurate).  NPIECE = 1 (round 6): every operand rounded to ONE bf16, or with F16 to one IEEE fp16 after
+// its power-of-two scale (GemmP::a_scale / b_scale, undone on the accumulator in fp32) -- the arithmetic of gemm_bf16k's one-piece loop: one MFMA per
+// wave and K-tile, one plane per operand (48 KiB of planes; the workgroup's 64 KiB are the epilogue's), same staging, prefetch and waits.
+template <bool BKM, int NPIECE = 3, bool F16 = false>
 __device__ __forceinline__ void bf16w_mainloop(const GemmP& p, const int tm, const int tn, const int bz, float* __restrict__ smem, f32x16& acc_out) {
-  constexpr int BM = BF16W_BM, BN = BF16W_BN, BK = BF16W_BK, PD = BF16W_PD, PA = BF16W_PA, PB = BF16W_PB;
+  static_assert(NPIECE == 3 || NPIECE == 1, "pieces per operand");
+  static_assert(!F16 || NPIECE == 1, "fp16 pieces only in the single-piece mode");
+  constexpr int BM = BF16W_BM, BN = BF16W_BN, BK = BF16W_BK, PD = BF16W_PD, PA = BF16W_PA, PB = BF16W_PB, OPER = bf16w_oper<NPIECE>();
+  const float sa = (F16 && p.a_scale != 0.f) ? p.a_scale : 1.f, sb = (F16 && p.b_scale != 0.f) ? p.b_scale : 1.f;
   typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
   unsigned* const buf = reinterpret_cast<unsigned*>(smem);      // [2][A planes x 3 | B planes x 3]
   const int tid = threadIdx.x;
@@ -106,18 +119,29 @@ __device__ __forceinline__ void bf16w_mainloop(const GemmP& p, const int tm, con
     constexpr int s = decltype(ss)::value;
     const f32x4k v0 = rg[s][0], v1 = rg[s][1], v2 = rg[s][2];
     const int tok = bf16w_wait_vm(nwait, v0, v1, v2);
-    unsigned* o = buf + b * BF16W_OPER + dsta;
-    unsigned h0, m0_, l0, h1, m1, l1, h2, m2, l2, h3, m3, l3;
-    split_bf16x3_tok(v0.x, v0.y, h0, m0_, l0, tok); split_bf16x3_tok(v0.z, v0.w, h1, m1, l1, tok);
-    split_bf16x3_tok(v1.x, v1.y, h2, m2, l2, tok); split_bf16x3_tok(v1.z, v1.w, h3, m3, l3, tok);
-    *reinterpret_cast<u32x4*>(o) = u32x4{h0, h1, h2, h3};
-    *reinterpret_cast<u32x4*>(o + PA) = u32x4{m0_, m1, m2, m3};
-    *reinterpret_cast<u32x4*>(o + 2 * PA) = u32x4{l0, l1, l2, l3};
-    split_bf16x3_tok(v2.x, v2.y, h0, m0_, l0, tok); split_bf16x3_tok(v2.z, v2.w, h1, m1, l1, tok);
-    unsigned* ob = buf + b * BF16W_OPER + 3 * PA + dstb;
-    *reinterpret_cast<u32x2*>(ob) = u32x2{h0, h1};
-    *reinterpret_cast<u32x2*>(ob + PB) = u32x2{m0_, m1};
-    *reinterpret_cast<u32x2*>(ob + 2 * PB) = u32x2{l0, l1};
+    unsigned* o = buf + b * OPER + dsta;
+    unsigned* ob = buf + b * OPER + NPIECE * PA + dstb;
+    if constexpr (NPIECE == 3) {
+      unsigned h0, m0_, l0, h1, m1, l1, h2, m2, l2, h3, m3, l3;
+      split_bf16x3_tok(v0.x, v0.y, h0, m0_, l0, tok); split_bf16x3_tok(v0.z, v0.w, h1, m1, l1, tok);
+      split_bf16x3_tok(v1.x, v1.y, h2, m2, l2, tok); split_bf16x3_tok(v1.z, v1.w, h3, m3, l3, tok);
+      *reinterpret_cast<u32x4*>(o) = u32x4{h0, h1, h2, h3};
+      *reinterpret_cast<u32x4*>(o + PA) = u32x4{m0_, m1, m2, m3};
+      *reinterpret_cast<u32x4*>(o + 2 * PA) = u32x4{l0, l1, l2, l3};
+      split_bf16x3_tok(v2.x, v2.y, h0, m0_, l0, tok); split_bf16x3_tok(v2.z, v2.w, h1, m1, l1, tok);
+      *reinterpret_cast<u32x2*>(ob) = u32x2{h0, h1};
+      *reinterpret_cast<u32x2*>(ob + PB) = u32x2{m0_, m1};
+      *reinterpret_cast<u32x2*>(ob + 2 * PB) = u32x2{l0, l1};
+    } else if constexpr (F16) {      // (every element is multiplied by its operand's scale before anything else reads it: the scale carries the token)
+      const float ca = __uint_as_float(__float_as_uint(sa) | (unsigned)tok), cb = __uint_as_float(__float_as_uint(sb) | (unsigned)tok);
+      *reinterpret_cast<u32x4*>(o) = u32x4{cvt_pk_f16(v0.x * ca, v0.y * ca), cvt_pk_f16(v0.z * ca, v0.w * ca),
+                                           cvt_pk_f16(v1.x * ca, v1.y * ca), cvt_pk_f16(v1.z * ca, v1.w * ca)};
+      *reinterpret_cast<u32x2*>(ob) = u32x2{cvt_pk_f16(v2.x * cb, v2.y * cb), cvt_pk_f16(v2.z * cb, v2.w * cb)};
+    } else {
+      *reinterpret_cast<u32x4*>(o) = u32x4{cvt_pk_bf16_tok(v0.x, v0.y, tok), cvt_pk_bf16_tok(v0.z, v0.w, tok),
+                                           cvt_pk_bf16_tok(v1.x, v1.y, tok), cvt_pk_bf16_tok(v1.z, v1.w, tok)};
+      *reinterpret_cast<u32x2*>(ob) = u32x2{cvt_pk_bf16_tok(v2.x, v2.y, tok), cvt_pk_bf16_tok(v2.z, v2.w, tok)};
+    }
   };
   // prologue: K-tiles 0 .. PD-1 requested, tile 0 split into buffer 0; everything requested lands before the loop is entered
   // (all PD slots without a branch: with the requests inside `if (slot < nt)` hipcc joins the paths with COPIES of registers whose loads
@@ -136,19 +160,19 @@ __device__ __forceinline__ void bf16w_mainloop(const GemmP& p, const int tm, con
   const int fbt = ((16 * kg + 8 * lh + ((li & 15) >> 2)) * (BN / 2) * 4) + 32 * (li >> 4) + 8 * (li & 3);      // bytes inside a B plane
   auto step = [&](auto ss, int t) {      // K-tile t, whose registers were slot s = t % PD (consumed in iteration t - 1)
     constexpr int s = decltype(ss)::value, s1_ = (s + 1) % PD;
-    const unsigned* planes = buf + (t & 1) * BF16W_OPER;
+    const unsigned* planes = buf + (t & 1) * OPER;
     u32x4 pa[3], pb[3];
 #pragma unroll
-    for (int q = 0; q < 3; ++q) pa[q] = *reinterpret_cast<const u32x4*>(planes + q * PA + fa);
+    for (int q = 0; q < NPIECE; ++q) pa[q] = *reinterpret_cast<const u32x4*>(planes + q * PA + fa);
     if constexpr (!BKM) {
 #pragma unroll
-      for (int q = 0; q < 3; ++q) pb[q] = *reinterpret_cast<const u32x4*>(planes + 3 * PA + q * PB + fb);
+      for (int q = 0; q < NPIECE; ++q) pb[q] = *reinterpret_cast<const u32x4*>(planes + NPIECE * PA + q * PB + fb);
     } else {
 #if defined(__HIP_DEVICE_COMPILE__)      // (LDS pointers are 32 bits wide in the device pass only)
       typedef __attribute__((address_space(3))) s16x4* lds_s16x4_p;
-      const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned*)(planes + 3 * PA) + (unsigned)fbt;
+      const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned*)(planes + NPIECE * PA) + (unsigned)fbt;
 #pragma unroll
-      for (int q = 0; q < 3; ++q) {
+      for (int q = 0; q < NPIECE; ++q) {
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(base + q * PB * 4));
         const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(base + q * PB * 4 + 4 * (BN / 2) * 4));
         pb[q] = __builtin_bit_cast(u32x4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
@@ -156,17 +180,23 @@ __device__ __forceinline__ void bf16w_mainloop(const GemmP& p, const int tm, con
 #else
       (void)fbt;
 #pragma unroll
-      for (int q = 0; q < 3; ++q) pb[q] = u32x4{0u, 0u, 0u, 0u};
+      for (int q = 0; q < NPIECE; ++q) pb[q] = u32x4{0u, 0u, 0u, 0u};
 #endif
     }
     if (t + PD < nt) load_tile(ss);
     constexpr int ta[6] = {1, 0, 2, 1, 0, 0}, tb[6] = {1, 2, 0, 0, 1, 0};   // (mid,mid) (hi,lo) (lo,hi) (mid,hi) (hi,mid) (hi,hi): gemm_bf16s_body
+    if constexpr (NPIECE == 3) {
 #pragma unroll
-    for (int t6 = 0; t6 < 6; ++t6) {
-      if (t6 < 5)
-        accl = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pa[ta[t6]]), __builtin_bit_cast(bf16x8, pb[tb[t6]]), accl, 0, 0, 0);
-      else
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pa[ta[t6]]), __builtin_bit_cast(bf16x8, pb[tb[t6]]), acc, 0, 0, 0);
+      for (int t6 = 0; t6 < 6; ++t6) {
+        if (t6 < 5)
+          accl = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pa[ta[t6]]), __builtin_bit_cast(bf16x8, pb[tb[t6]]), accl, 0, 0, 0);
+        else
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pa[ta[t6]]), __builtin_bit_cast(bf16x8, pb[tb[t6]]), acc, 0, 0, 0);
+      }
+    } else if constexpr (F16) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, pa[0]), __builtin_bit_cast(f16x8, pb[0]), acc, 0, 0, 0);
+    } else {
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pa[0]), __builtin_bit_cast(bf16x8, pb[0]), acc, 0, 0, 0);
     }
     // under the MFMAs: split K-tile t + 1 into the other buffer; behind its three loads went those of tiles t + 2 .. min(t + PD, nt - 1)
     if (t + 1 < nt) store_tile(std::integral_constant<int, s1_>{}, (t + 1) & 1, 3 * (min(t + PD, nt - 1) - (t + 1)));
@@ -175,17 +205,21 @@ __device__ __forceinline__ void bf16w_mainloop(const GemmP& p, const int tm, con
   for (int t = 0; t < nt; t += PD)
     static_for<0, PD>([&](auto ss) { if (t + decltype(ss)::value < nt) step(ss, t + decltype(ss)::value); });
 
-  acc_out = acc + accl;
+  if constexpr (NPIECE == 3) acc += accl;
+  if constexpr (F16) {
+    if (sa != 1.f || sb != 1.f) acc *= 1.f / (sa * sb);      // undo the operand scaling in fp32 (powers of two: exact)
+  }
+  acc_out = acc;
 }
 
-template <bool BKM>
+template <bool BKM, int NPIECE = 3, bool F16 = false>
 __device__ __forceinline__ void gemm_bf16w_body(const GemmP& p, const int bid, const int nblk, float* __restrict__ smem) {
   int tm, tn, sp, bz;
   tile_coords(p, bid, nblk, tm, tn, sp, bz);
   f32x16 acc[1][1];
-  bf16w_mainloop<BKM>(p, tm, tn, bz, smem, acc[0][0]);
+  bf16w_mainloop<BKM, NPIECE, F16>(p, tm, tn, bz, smem, acc[0][0]);
   // the eight K groups' 64 x 32 images (the loop's last barrier is behind every fragment read)
-  static_assert(BF16W_KG * BF16W_BM * BF16W_BN <= 2 * BF16W_OPER, "the plane buffers must hold the staged partial tiles");
+  static_assert(BF16W_KG * BF16W_BM * BF16W_BN <= bf16w_smem_dw<NPIECE>(), "the workgroup's LDS must hold the staged partial tiles");
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int kg = wave >> 1, wr = wave & 1, li = lane & 31, lh = lane >> 5;
   float* ct = smem + kg * (BF16W_BM * BF16W_BN);
@@ -194,10 +228,10 @@ __device__ __forceinline__ void gemm_bf16w_body(const GemmP& p, const int bid, c
   gemm_epilogue<BF16W_BM, BF16W_BN, 1, 1, 4, false, BF16W_KG, true>(p, acc, smem, TileCoord{tm, tn, sp, bz, tm * BF16W_BM, tn * BF16W_BN});
 }
 
-template <bool BKM>
+template <bool BKM, int NPIECE = 3, bool F16 = false>
 __global__ __launch_bounds__(1024) void gemm_bf16w_mfma(const GemmP p) {
-  __shared__ __attribute__((aligned(16))) float smem[2 * BF16W_OPER];      // 144 KiB: one workgroup per CU
-  gemm_bf16w_body<BKM>(p, (int)blockIdx.x, (int)gridDim.x, smem);
+  __shared__ __attribute__((aligned(16))) float smem[bf16w_smem_dw<NPIECE>()];      // three pieces: 144 KiB, one workgroup per CU; one piece: 64 KiB
+  gemm_bf16w_body<BKM, NPIECE, F16>(p, (int)blockIdx.x, (int)gridDim.x, smem);
 }
 
 // NT / NN products of plain fp32 matrices with nothing in the fetch path that the 64 x 64 kernels' items carry
@@ -217,28 +251,41 @@ static_assert(BF16W_ZERO_PAGE_FLOATS <= 2048 + 64, "gemm_bf16w reads past the li
 inline bool plan_bf16w(GemmPlan& pl, const GemmP& g, bool akm, bool bkm, bool force) {
   if (!gemm_bf16w_eligible(g, akm, bkm)) return false;
   const int tm = (g.M + BF16W_BM - 1) / BF16W_BM, tn = (g.N + BF16W_BN - 1) / BF16W_BN;
+  // one low-precision piece per operand (a forced bf16 / fp16 plan on the 16-wave kernel): the same tiles and K-tiles, one MFMA per wave and K-tile --
+  // measured on MI355X (round 6, tools/k_sweep.py): 64 x 64 about 0.45 us per 64-deep K-tile (fwd of configs[4]: 11.8 us for 14.5 K-tiles), 64 x 32 about 0.75 us per 128-deep K-tile (dF: 10.5 us for 8)
+  const bool lp = pl.mode == MFMA_F16 || pl.mode == MFMA_BF16;
+  const double k64 = lp ? 0.45 : 0.94, k32 = lp ? 0.75 : 1.3;
   if (!force) {
-    if (!(pl.mode == MFMA_BF16X3 && pl.tile == 64 && pl.kg == 4 && pl.nsplit >= 2 && !pl.persist && !pl.skinny && !pl.skinny_n)) return false;
+    if (!((pl.mode == MFMA_BF16X3 || lp) && pl.tile == 64 && pl.kg == 4 && pl.nsplit >= 2 && !pl.persist && !pl.skinny && !pl.skinny_n)) return false;
     if ((long long)tm * tn > GEMM_CUS) return false;
-    const double est64 = 5.3 + 0.94 * ((pl.kps + 63) / 64) + 4.7, est32 = 4.4 + 1.3 * ((g.K + BF16W_BK - 1) / BF16W_BK);
+    const double est64 = 5.3 + k64 * ((pl.kps + 63) / 64) + 4.7, est32 = 4.4 + k32 * ((g.K + BF16W_BK - 1) / BF16W_BK);
     if (est32 > est64 - 0.5) return false;
   }
   const bool wants_sq = pl.sq_count > 0 || g.epi.sq_partials != nullptr;
-  pl.est_us = 4.4 + 1.3 * ((g.K + BF16W_BK - 1) / BF16W_BK);
+  pl.est_us = 4.4 + k32 * ((g.K + BF16W_BK - 1) / BF16W_BK);
   pl.wide32 = 1; pl.skinny = 0; pl.skinny_n = 0; pl.persist = 0;
-  pl.mode = MFMA_BF16X3; pl.tile = 64; pl.kg = BF16W_KG; pl.ring = 2; pl.bk = BF16W_BK;
+  if (!lp) pl.mode = MFMA_BF16X3;
+  pl.tile = 64; pl.kg = BF16W_KG; pl.ring = 2; pl.bk = BF16W_BK;
   pl.tiles_m = tm; pl.tiles_n = tn; pl.nsplit = 1; pl.kps = g.K;
   pl.sq_count = wants_sq ? tm * tn : 0;
   return true;
 }
 
-inline hipError_t gemm_dispatch_bf16w(hipStream_t st, const GemmP& p, bool bkm) {      // (tiles / split of the plan: gemm_run)
+inline hipError_t gemm_dispatch_bf16w(hipStream_t st, const GemmP& p, bool bkm, int mode) {      // (tiles / split of the plan: gemm_run)
   const int grid = p.tiles_m * p.tiles_n * std::max(p.nbatch, 1);
   if (grid <= 0) return hipSuccess;
   if (p.nsplit != 1 || p.tiles_m != (p.M + BF16W_BM - 1) / BF16W_BM || p.tiles_n != (p.N + BF16W_BN - 1) / BF16W_BN) return hipErrorInvalidValue;
   if (!p.zero_page || (p.lda % 64) != 0 || (p.ldb % 64) != 0) return hipErrorInvalidValue;      // (gemm_bf16w_eligible: never a silent out-of-bounds read)
-  if (bkm) GANMF_LAUNCH(gemm_bf16w_mfma<true>, dim3(grid), dim3(1024), 0, st, p);
-  else GANMF_LAUNCH(gemm_bf16w_mfma<false>, dim3(grid), dim3(1024), 0, st, p);
+  if (mode == MFMA_F16) {
+    if (bkm) GANMF_LAUNCH((gemm_bf16w_mfma<true, 1, true>), dim3(grid), dim3(1024), 0, st, p);
+    else GANMF_LAUNCH((gemm_bf16w_mfma<false, 1, true>), dim3(grid), dim3(1024), 0, st, p);
+  } else if (mode == MFMA_BF16) {
+    if (bkm) GANMF_LAUNCH((gemm_bf16w_mfma<true, 1, false>), dim3(grid), dim3(1024), 0, st, p);
+    else GANMF_LAUNCH((gemm_bf16w_mfma<false, 1, false>), dim3(grid), dim3(1024), 0, st, p);
+  } else {
+    if (bkm) GANMF_LAUNCH(gemm_bf16w_mfma<true>, dim3(grid), dim3(1024), 0, st, p);
+    else GANMF_LAUNCH(gemm_bf16w_mfma<false>, dim3(grid), dim3(1024), 0, st, p);
+  }
   return hipGetLastError();
 }
 

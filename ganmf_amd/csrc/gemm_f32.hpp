@@ -1287,13 +1287,13 @@ inline void choose_tile_order(GemmP& p, const GemmPlan& pl) {
 
 inline hipError_t gemm_dispatch_skinny(hipStream_t st, const GemmP& p0, bool bkm, int rt);
 inline hipError_t gemm_dispatch_skinny_n(hipStream_t st, const GemmP& p0, bool bkm);
-inline hipError_t gemm_dispatch_bf16w(hipStream_t st, const GemmP& p, bool bkm);
+inline hipError_t gemm_dispatch_bf16w(hipStream_t st, const GemmP& p, bool bkm, int mode);
 
 inline hipError_t gemm_dispatch(hipStream_t st, const GemmP& p0, bool akm, bool bkm, const GemmPlan& pl) {
   if (p0.epi.kind == EPI_ADAM && !(akm && bkm)) return hipErrorInvalidValue;      // (the fused Adam row pass exists in the TN kernels only)
   if (pl.skinny) return gemm_dispatch_skinny(st, p0, bkm, pl.skinny);
   if (pl.skinny_n) return gemm_dispatch_skinny_n(st, p0, bkm);
-  if (pl.wide32) return gemm_dispatch_bf16w(st, p0, bkm);
+  if (pl.wide32) return gemm_dispatch_bf16w(st, p0, bkm, pl.mode);
   if (pl.persist) return gemm_dispatch_persist(st, p0, akm, bkm, pl);
   GemmP p = p0;
   choose_tile_order(p, pl);

@@ -44,6 +44,15 @@ __global__ __launch_bounds__(256 * KG) void front_kernel(const GemmP g, const De
     else gemm_f32_body<64, 64, 64, 3, false, false, KG>(g, (int)blockIdx.x, ng, smem);
   } else densify_row_body(d, (int)blockIdx.x - ng);
 }
+// ... and on a handle whose products run in ONE low-precision piece (mfma = "f16" | "bf16": BASELINE configs[4] as written): the 16-wave
+// one-piece loop the stand-alone generator product runs (gemm_bf16k_mfma<false, false, 1, F16>), 64 KiB of LDS
+template <bool F16>
+__global__ __launch_bounds__(1024) void front_lp_kernel(const GemmP g, const DensP d) {
+  __shared__ __attribute__((aligned(16))) float smem[bf16k_smem_dw<1>()];
+  const int ng = g.tiles_m * g.tiles_n * g.nsplit * g.nbatch;
+  if ((int)blockIdx.x < ng) gemm_bf16k_body<false, false, 1, F16>(g, (int)blockIdx.x, ng, smem);
+  else densify_row_body(d, (int)blockIdx.x - ng);
+}
 
 // blocks [0, ng): 64 x 64 tiles of the NT GEMM dE = Delta . Wd^T, which here only writes its split-K slabs; blocks [ng, ng + nd):
 // the discriminator scalars and Es = rs (.) E (kernels.hpp d_coef_body), whose outputs the GEMM does not read -- the row scale
@@ -81,6 +90,17 @@ __global__ __launch_bounds__(256 * KG) void pair_kernel(const GemmP g0, const Ge
   else gemm_f32_body<64, 64, 64, NS, true, true, KG>(g1, (int)blockIdx.x - n0, n1, smem);
 }
 
+// the same pair on a low-precision handle: gUb (NN, split-K slabs) and gV (TN, fused Adam into the second V buffer) on the 16-wave one-piece
+// loop each of them runs stand-alone (gemm_bf16k_mfma<.., 1, F16>: bit-identical); 64 KiB of LDS, two workgroups per CU
+template <bool F16>
+__global__ __launch_bounds__(1024) void pair_lp_kernel(const GemmP g0, const GemmP g1) {
+  __shared__ __attribute__((aligned(16))) float smem[bf16k_smem_dw<1>()];
+  const int n0 = g0.tiles_m * g0.tiles_n * g0.nsplit * g0.nbatch;
+  const int n1 = g1.tiles_m * g1.tiles_n * g1.nsplit * g1.nbatch;
+  if ((int)blockIdx.x < n0) gemm_bf16k_body<false, true, 1, F16>(g0, (int)blockIdx.x, n0, smem);
+  else gemm_bf16k_body<true, true, 1, F16>(g1, (int)blockIdx.x - n0, n1, smem);
+}
+
 // blocks [0, ng): 64 x 64 x 32 tiles of the TN split-bf16 GEMM; blocks [ng, ng + nred): slab reduce of ANOTHER product
 __global__ __launch_bounds__(256, 2) void gemm_bf16s_red(const GemmP g, const RedP r, const int nred) {
   __shared__ __attribute__((aligned(16))) float smem[Bf16sLds<64, 64, 32, 3>::DW];
@@ -103,6 +123,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_pair_kernel(const GemmP g0, cons
 // ---- host side: can this plan ride in the combined launch?
 inline bool plan_is_f32_64_kg(const GemmPlan& pl, int kg) {
   return pl.mode == MFMA_F32 && pl.tile == 64 && pl.ring == 3 && pl.kg == kg && !pl.persist;
+}
+// ... or would the stand-alone product run the 16-wave ONE-piece loop (a forced bf16 / fp16 handle, GANMF_X3KG bit 2: plan_gemm)?
+inline bool plan_is_lp_64(const GemmPlan& pl) {
+  return (pl.mode == MFMA_F16 || pl.mode == MFMA_BF16) && pl.tile == 64 && pl.ring == 3 && pl.bk != 32 && !pl.persist;
 }
 
 inline void fill_plan(GemmP& p, const GemmPlan& pl) {

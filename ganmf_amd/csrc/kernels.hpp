@@ -771,13 +771,20 @@ __global__ __launch_bounds__(DZ_COLS * DZ_GROUPS) void dis_dz_top_kernel(const f
                                                                           float* __restrict__ gwo, float* __restrict__ fm_partials,
                                                                           float* th, float* __restrict__ mo,
                                                                           float* __restrict__ vo, const float* __restrict__ scal,
-                                                                          int alpha_idx, float reg, float* __restrict__ sq_partials) {
+                                                                          int alpha_idx, float reg, float* __restrict__ sq_partials,
+                                                                          const float* __restrict__ uid = nullptr, int ldu = 0,
+                                                                          float* __restrict__ uth = nullptr, float* __restrict__ umo = nullptr,
+                                                                          float* __restrict__ uvo = nullptr, float* __restrict__ usq = nullptr) {
   // th != nullptr (D-step, single GPU): gwo is not stored -- TF-Adam on the output layer's column right here (this block is the
   // only reader of wo[c], and the logits were formed by the previous kernel); sum(theta_old^2) of the block -> sq_partials[block]
+  // uid != nullptr (round 6; D-step of a ONE-layer discriminator in a low-precision mode, single GPU): dz written here IS dz_0, so the
+  // gradient of the fp32 float(uid) row of W_0_ext, sum_m uid[m] dz[m, c] (dis_uid_grad_kernel's job), is formed in the same pass over the rows
+  // and TF-Adam applied to that row's column c right here (uth / umo / uvo; nothing reads the row between the forward product and this point);
+  // sum(theta_old^2) of the block -> usq[block].  dis_uid_grad_kernel's launch leaves the step.
   __shared__ float red[DZ_GROUPS][DZ_COLS];
   const int cl = threadIdx.x % DZ_COLS, g = threadIdx.x / DZ_COLS;
   const int c = blockIdx.x * DZ_COLS + cl;
-  float acc = 0.f, fm = 0.f;
+  float acc = 0.f, fm = 0.f, uacc = 0.f;
   if (c <= e) {
     const float w = wo[c];
     for (int r = row0 + g; r < row0 + nrows; r += DZ_GROUPS) {
@@ -791,7 +798,9 @@ __global__ __launch_bounds__(DZ_COLS * DZ_GROUPS) void dis_dz_top_kernel(const f
           dh += fmc * d;
           fm += d * d;
         }
-        dz[(size_t)r * ld + c] = dh * act_grad_out(act, a);
+        const float dzv = dh * act_grad_out(act, a);
+        dz[(size_t)r * ld + c] = dzv;
+        if (uid) uacc += uid[(size_t)r * ldu] * dzv;
       }
     }
   }
@@ -818,6 +827,29 @@ __global__ __launch_bounds__(DZ_COLS * DZ_GROUPS) void dis_dz_top_kernel(const f
   if (th && sq_partials && threadIdx.x < 64) {
     sqv = wave_sum(sqv);
     if (threadIdx.x == 0) sq_partials[blockIdx.x] = sqv;
+  }
+  if (uid) {      // (uniform) the float(uid) row's gradient: group partials meet in LDS, added in group order
+    __syncthreads();
+    red[g][cl] = uacc;
+    __syncthreads();
+    float usv = 0.f;
+    if (g == 0 && c < e) {
+      float t = red[0][cl];
+#pragma unroll 8
+      for (int q = 1; q < DZ_GROUPS; ++q) t += red[q][cl];
+      const float x = uth[c];
+      usv = x * x;
+      const float gr = t + reg * x;
+      float mm = umo[c], vv = uvo[c];
+      mm += (gr - mm) * (1.f - ADAM_B1);
+      vv += (gr * gr - vv) * (1.f - ADAM_B2);
+      umo[c] = mm; uvo[c] = vv;
+      uth[c] = adam_step(x, mm * scal[alpha_idx], vv);
+    }
+    if (usq && threadIdx.x < 64) {
+      usv = wave_sum(usv);
+      if (threadIdx.x == 0) usq[blockIdx.x] = usv;
+    }
   }
   if (fm_partials) {
     __syncthreads();

@@ -174,7 +174,7 @@ def test_gemm_split_bf16_k_groups(akm, bkm, shape, nsplit, monkeypatch):
 @pytest.mark.parametrize("shape", [(128, 3706, 992), (128, 3706, 993), (64, 32, 128), (1, 1, 1), (65, 33, 129), (100, 70, 1030), (128, 2113, 748),
                                    (37, 500, 384), (200, 100, 257), (64, 96, 2000), (70, 40, 100), (33, 64, 256)])
 @pytest.mark.parametrize("bkm", [False, True])
-def test_gemm_bf16w_64x32_tiles(shape, bkm, monkeypatch):
+def test_gemm_bf16w_64x32_tiles(shape, bkm, monkeypatch, capfd):
     """gemm_bf16w.hpp: the 16-wave split-bf16 loop on 64 x 32 tiles with 128-deep K-tiles (eight K groups), unsplit, B K-contiguous (dF of
     the generator step) or K-major (its decode: [k][32 n] image, transposing fragment reads) -- the ML-1M and hetrec shapes, 1 .. 16 K-tiles (BF16W_PD = 2 K-tiles in flight: one K-tile, K <= 128, leaves the
     second prologue slot past the range -- requested from the zero page --, two K-tiles, K = 129 .. 256, fill both; odd and even tile counts), K tails, a last K-tile that reaches past the leading dimension (K = 1030: ld 1088 < 1152), ragged rows and
@@ -184,7 +184,10 @@ def test_gemm_bf16w_64x32_tiles(shape, bkm, monkeypatch):
     rng = np.random.RandomState(M + 3 * N + 7 * K)
     A, B, ref, bound = _mk(rng, M, N, K, False, bkm)
     monkeypatch.setenv("GANMF_TUNE", "bf16w=2")
+    monkeypatch.setenv("GANMF_DEBUG_PLAN", "1")
+    capfd.readouterr()
     out, _ = gemm_f32(A, B, False, bkm)
+    assert "64 x 32 tiles" in capfd.readouterr().err
     err = np.abs(out - ref)
     assert np.all(err <= 4e-7 * bound * np.sqrt(K) + 1e-30), float((err / (bound + 1e-30)).max())
     again, _ = gemm_f32(A, B, False, bkm)
@@ -193,6 +196,32 @@ def test_gemm_bf16w_64x32_tiles(shape, bkm, monkeypatch):
     plain, _ = gemm_f32(A, B, False, bkm)
     assert np.all(np.abs(plain - out) <= 8e-7 * bound * np.sqrt(K) + 1e-30)
     assert not np.array_equal(plain, out) or K == 1
+
+
+@pytest.mark.parametrize("mode,bound", [("f16", 1.5e-3), ("bf16", 1.2e-2)])
+@pytest.mark.parametrize("bkm", [False, True])
+@pytest.mark.parametrize("shape", [(128, 3706, 1024), (65, 33, 129), (100, 70, 1030), (37, 500, 100), (64, 96, 2000)])
+def test_gemm_bf16w_one_piece_forms(shape, bkm, mode, bound, monkeypatch, capfd):
+    """gemm_bf16w.hpp with ONE low-precision piece per operand (round 6: dF / decode of a handle created with mfma = "f16" | "bf16", unsplit on
+    64 x 32 tiles): operands rounded once to fp16 / bf16, fp32 accumulate -- the error of a single rounding per operand (2^-11 / 2^-8 relative,
+    times sqrt(K) in the sum), the same numbers on every run, and within that bound of the 64 x 64 one-piece kernel."""
+    from ganmf_amd.engine import gemm_f32
+    M, N, K = shape
+    rng = np.random.RandomState(M + 3 * N + 7 * K)
+    A, B, ref, bound_abs = _mk(rng, M, N, K, False, bkm)
+    monkeypatch.setenv("GANMF_MFMA", mode)
+    monkeypatch.setenv("GANMF_TUNE", "bf16w=2")
+    monkeypatch.setenv("GANMF_DEBUG_PLAN", "1")
+    capfd.readouterr()
+    out, _ = gemm_f32(A, B, False, bkm)
+    line = capfd.readouterr().err
+    assert "64 x 32 tiles" in line and ("mfma " + mode) in line, line
+    assert np.all(np.abs(out - ref) <= bound * bound_abs + 1e-30), float((np.abs(out - ref) / (bound_abs + 1e-30)).max())
+    again, _ = gemm_f32(A, B, False, bkm)
+    np.testing.assert_array_equal(out, again)
+    monkeypatch.setenv("GANMF_TUNE", "bf16w=0")
+    tiled, _ = gemm_f32(A, B, False, bkm)
+    assert np.all(np.abs(tiled - out) <= 2 * bound * bound_abs + 1e-30)
 
 
 @pytest.mark.parametrize("akm,bkm", [(False, False), (False, True)])
@@ -234,6 +263,7 @@ def test_gemm_skinny_n_stream(bkm, shape, monkeypatch, capfd):
     again, _ = gemm_f32(A, B, False, bkm)
     assert np.array_equal(out, again)
     monkeypatch.setenv("GANMF_TUNE", "skinny=0")
+    capfd.readouterr()
     tiled, _ = gemm_f32(A, B, False, bkm)
     assert "skinny-N stream" not in capfd.readouterr().err
     assert np.all(np.abs(tiled - out) <= 8e-7 * bound * np.sqrt(K) + 1e-30)

@@ -14,13 +14,13 @@ pytestmark = pytest.mark.gpu
 IDS = {"We": 0, "be": 1, "Wd": 2, "bd": 3, "U": 100, "V": 101}
 
 
-def _run(monkeypatch, multi, defer, U, N, k, e, B, hp, epochs, d_steps=1, g_steps=1):
+def _run(monkeypatch, multi, defer, U, N, k, e, B, hp, epochs, d_steps=1, g_steps=1, mfma=None):
     from ganmf_amd import _lib as L
     from ganmf_amd.engine import Engine
     monkeypatch.setenv("GANMF_MULTI", str(multi + 32 * defer + 64))
     urm = synthetic_urm(U, N, 0.04, seed=21)
     w = glorot_params(U, N, k, e, seed=9)
-    eng = Engine(U, N, k, e, B, **hp)
+    eng = Engine(U, N, k, e, B, mfma=mfma, **hp)
     eng.set_urm(urm)
     for n, tid in IDS.items():
         eng.set_tensor(tid, w[n])
@@ -75,6 +75,30 @@ def test_wgrad_blocked_tile_order_bit_identical(shape, monkeypatch):
             np.testing.assert_array_equal(gl, gr, err_msg="G losses, wgrad_xb=" + xb)
         for n in ref:
             np.testing.assert_array_equal(got[n], ref[n], err_msg="%s, wgrad_xb=%s" % (n, xb))
+
+
+@pytest.mark.parametrize("mfma", ["f16", "bf16"])
+@pytest.mark.parametrize("shape", [
+    (1500, 3706, 250, 992, 128),       # C2-shaped: front and pair are taken on the one-piece 16-wave loop (staged discriminator passes too)
+    (330, 1100, 64, 200, 96),          # three full minibatches + a ragged one: per-step front launches
+])
+def test_low_precision_combined_launches_bit_identical(shape, mfma, monkeypatch):
+    """A handle created with mfma = "f16" | "bf16" (BASELINE configs[4] as written) takes the combined launches as well (round 6): generator GEMM +
+    CSR rows (front_lp_kernel) and gUb + gV with Adam (pair_lp_kernel) run the 16-wave ONE-piece loop their products run stand-alone
+    (gemm_bf16k_mfma<.., 1, F16>), so tensors, moments and losses equal the one-kernel-per-piece path bit for bit.  (bf16w = 0 on both sides: the
+    unsplit 64 x 32 form of dF / decode sums in another order than two K slices + a slab sum; tests/test_gpu_gemm.py holds it to the fp64 product.)"""
+    U, N, k, e, B = shape
+    hp = dict(d_lr=1e-4, g_lr=2e-4, d_reg=1e-4, g_reg=0.0, m=10.0, recon_coefficient=0.05)
+    monkeypatch.setenv("GANMF_TUNE", "bf16w=0")
+    monkeypatch.setenv("GANMF_DEBUG_PLAN", "1")
+    ref, ref_l = _run(monkeypatch, 0, 0, U, N, k, e, B, hp, epochs=2, mfma=mfma)
+    for multi, defer in ((31, 1), (1, 1), (2, 1)):
+        got, got_l = _run(monkeypatch, multi, defer, U, N, k, e, B, hp, epochs=2, mfma=mfma)
+        for (dl, gl), (dr, gr) in zip(got_l, ref_l):
+            np.testing.assert_array_equal(dl, dr, err_msg="D losses, %s GANMF_MULTI=%d" % (mfma, multi))
+            np.testing.assert_array_equal(gl, gr, err_msg="G losses, %s GANMF_MULTI=%d" % (mfma, multi))
+        for n in ref:
+            np.testing.assert_array_equal(got[n], ref[n], err_msg="%s, %s GANMF_MULTI=%d" % (n, mfma, multi + 32 * defer + 64))
 
 
 @pytest.mark.parametrize("shape,d_steps", [

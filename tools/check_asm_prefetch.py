@@ -37,6 +37,13 @@ template __global__ void gemm_bf16k_mfma<false, true, 1, true>(const GemmP);
 template __global__ void front_kernel<4, true>(const GemmP, const DensP);
 template __global__ void gemm_bf16w_mfma<false>(const GemmP);
 template __global__ void gemm_bf16w_mfma<true>(const GemmP);
+template __global__ void gemm_bf16w_mfma<false, 1, true>(const GemmP);
+template __global__ void gemm_bf16w_mfma<true, 1, true>(const GemmP);
+template __global__ void gemm_bf16w_mfma<false, 1, false>(const GemmP);
+template __global__ void front_lp_kernel<true>(const GemmP, const DensP);
+template __global__ void front_lp_kernel<false>(const GemmP, const DensP);
+template __global__ void pair_lp_kernel<true>(const GemmP, const GemmP);
+template __global__ void pair_lp_kernel<false>(const GemmP, const GemmP);
 template __global__ void de_dcoef_kernel<4, true>(const GemmP, const DCoefP, const int);
 }
 """ % ROOT
@@ -154,7 +161,7 @@ def run_lint():
                 cur = None
     problems, checked, asm_loads = [], 0, 0
     for name, lines in kernels.items():
-        if "bf16k" not in name and "bf16w" not in name and "front_kernel" not in name and "de_dcoef" not in name:
+        if not any(k in name for k in ("bf16k", "bf16w", "front_kernel", "de_dcoef", "front_lp", "pair_lp")):
             continue
         n_asm = sum(1 for _, l in lines if "global_load_dwordx4" in l)
         if n_asm == 0:
