@@ -759,7 +759,7 @@ __global__ __launch_bounds__(256) void reduce_rows_head_kernel(const RedP p, con
 //   fm partial = sum (feat_f - feat_r)^2             (G-step)
 // A block takes DZ_COLS columns and splits the rows over DZ_GROUPS row groups (thread = (group, column)): 65 blocks of 1024
 // threads at d_nodes = 1024 with two to four rows per thread, where round 1's 64-column blocks left 17 workgroups walking 64
-// rows each (30 us of a 127 us step).  The column sums add the groups in group order, the feature-matching partial the
+// rows each (30 us of a 127 us step).  The column sums add the groups in a fixed two-level order (four consecutive groups, then the sixteen sums), the feature-matching partial the
 // waves in wave order: fixed, reproducible.
 constexpr int DZ_COLS = 16, DZ_GROUPS = 64;
 inline int dis_dz_top_blocks(int e) { return (e + 1 + DZ_COLS - 1) / DZ_COLS; }
@@ -781,7 +781,8 @@ __global__ __launch_bounds__(DZ_COLS * DZ_GROUPS) void dis_dz_top_kernel(const f
   // gradient of the fp32 float(uid) row of W_0_ext, sum_m uid[m] dz[m, c] (dis_uid_grad_kernel's job), is formed in the same pass over the rows
   // and TF-Adam applied to that row's column c right here (uth / umo / uvo; nothing reads the row between the forward product and this point);
   // sum(theta_old^2) of the block -> usq[block].  dis_uid_grad_kernel's launch leaves the step.
-  __shared__ float red[DZ_GROUPS][DZ_COLS];
+  __shared__ float red[DZ_GROUPS][DZ_COLS], red2[DZ_GROUPS][DZ_COLS];
+  static_assert(DZ_GROUPS == 64 && DZ_COLS * DZ_GROUPS >= 16 * DZ_COLS, "the two-level column sums below: 64 groups = 16 x 4");
   const int cl = threadIdx.x % DZ_COLS, g = threadIdx.x / DZ_COLS;
   const int c = blockIdx.x * DZ_COLS + cl;
   float acc = 0.f, fm = 0.f, uacc = 0.f;
@@ -804,13 +805,30 @@ __global__ __launch_bounds__(DZ_COLS * DZ_GROUPS) void dis_dz_top_kernel(const f
       }
     }
   }
+  // The 64 group partials of a column meet in LDS and are added in a FIXED two-level order (round 6): sixteen threads per column add four
+  // consecutive groups each, then one thread adds the sixteen sums in order -- depth 4 + 16 instead of one thread walking 64 LDS reads (3 us of
+  // a 5 us launch).  Both sums of the launch go through together: the output layer's gradient (thread group 0 finishes it) and, with `uid`, the
+  // float(uid) row's (thread group 1).
   red[g][cl] = acc;
+  if (uid) red2[g][cl] = uacc;
   __syncthreads();
-  float sqv = 0.f;
+  const bool lvl1 = g < 16;      // thread group g < 16 adds groups 4 g .. 4 g + 3 of its column
+  float a4 = 0.f, u4 = 0.f;
+  if (lvl1) {
+    a4 = ((red[4 * g][cl] + red[4 * g + 1][cl]) + red[4 * g + 2][cl]) + red[4 * g + 3][cl];
+    if (uid) u4 = ((red2[4 * g][cl] + red2[4 * g + 1][cl]) + red2[4 * g + 2][cl]) + red2[4 * g + 3][cl];
+  }
+  __syncthreads();
+  if (lvl1) {
+    red[g][cl] = a4;
+    if (uid) red2[g][cl] = u4;
+  }
+  __syncthreads();
+  float sqv = 0.f, usv = 0.f;
   if (g == 0 && c <= e && (gwo || th)) {
     float t = red[0][cl];
-#pragma unroll 8
-    for (int q = 1; q < DZ_GROUPS; ++q) t += red[q][cl];
+#pragma unroll
+    for (int q = 1; q < 16; ++q) t += red[q][cl];
     if (th) {
       const float x = th[c];
       sqv = x * x;
@@ -824,32 +842,22 @@ __global__ __launch_bounds__(DZ_COLS * DZ_GROUPS) void dis_dz_top_kernel(const f
       gwo[c] = t;
     }
   }
-  if (th && sq_partials && threadIdx.x < 64) {
-    sqv = wave_sum(sqv);
-    if (threadIdx.x == 0) sq_partials[blockIdx.x] = sqv;
+  if (uid && g == 1 && c < e) {      // the float(uid) row of W_0_ext: gradient -> TF-Adam in place
+    float t = red2[0][cl];
+#pragma unroll
+    for (int q = 1; q < 16; ++q) t += red2[q][cl];
+    const float x = uth[c];
+    usv = x * x;
+    const float gr = t + reg * x;
+    float mm = umo[c], vv = uvo[c];
+    mm += (gr - mm) * (1.f - ADAM_B1);
+    vv += (gr * gr - vv) * (1.f - ADAM_B2);
+    umo[c] = mm; uvo[c] = vv;
+    uth[c] = adam_step(x, mm * scal[alpha_idx], vv);
   }
-  if (uid) {      // (uniform) the float(uid) row's gradient: group partials meet in LDS, added in group order
-    __syncthreads();
-    red[g][cl] = uacc;
-    __syncthreads();
-    float usv = 0.f;
-    if (g == 0 && c < e) {
-      float t = red[0][cl];
-#pragma unroll 8
-      for (int q = 1; q < DZ_GROUPS; ++q) t += red[q][cl];
-      const float x = uth[c];
-      usv = x * x;
-      const float gr = t + reg * x;
-      float mm = umo[c], vv = uvo[c];
-      mm += (gr - mm) * (1.f - ADAM_B1);
-      vv += (gr * gr - vv) * (1.f - ADAM_B2);
-      umo[c] = mm; uvo[c] = vv;
-      uth[c] = adam_step(x, mm * scal[alpha_idx], vv);
-    }
-    if (usq && threadIdx.x < 64) {
-      usv = wave_sum(usv);
-      if (threadIdx.x == 0) usq[blockIdx.x] = usv;
-    }
+  if (threadIdx.x < 64) {      // (wave 0 holds thread groups 0 .. 3: sqv lives in group 0's lanes, usv in group 1's)
+    if (th && sq_partials) { sqv = wave_sum(sqv); if (threadIdx.x == 0) sq_partials[blockIdx.x] = sqv; }
+    if (uid && usq) { usv = wave_sum(usv); if (threadIdx.x == 0) usq[blockIdx.x] = usv; }
   }
   if (fm_partials) {
     __syncthreads();
