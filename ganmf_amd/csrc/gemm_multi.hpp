@@ -109,6 +109,19 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16s_red(const GemmP g, const Re
   else splitk_reduce_body(r, (int)blockIdx.x - ng, nred, 0, smem);
 }
 
+// blocks [0, ng): 64 x 64 tiles of the TN staged GEMM with the fused Adam epilogue (DisGANMF: gW_0_ext = [X;F | 1 (| uid)]^T . dz_0 + Adam(W_0));
+// blocks [ng, ng + ncs): the column sums of the top of the backward pass -- output-layer gradient + Adam(w_o), and in the low-precision modes the
+// fp32 float(uid) row of W_0_ext (kernels.hpp dis_colsum_body) -- which read only what the launch in front wrote (layer output, dlogit, dz_0)
+// and write tensors the GEMM does not touch: dis_dz_top_kernel's launch (7 us of a 46 us discriminator step at configs[4]) leaves the step.
+template <int BK, int NPIECE, bool F16>
+__global__ __launch_bounds__(256, 2) void gemm_bf16s_colsum(const GemmP g, const ColSumP q, const int ncs) {
+  __shared__ __attribute__((aligned(16))) float smem[Bf16sLds<64, 64, BK, NPIECE>::DW];
+  static_assert(Bf16sLds<64, 64, BK, NPIECE>::DW >= 2 * CS_GROUPS * CS_COLS, "the column sums' two LDS images");
+  const int ng = g.tiles_m * g.tiles_n * g.nsplit * g.nbatch;
+  if ((int)blockIdx.x < ng) gemm_bf16s_body<64, 64, BK, true, true, NPIECE, F16>(g, (int)blockIdx.x, ng, smem);
+  else dis_colsum_body(q, (int)blockIdx.x - ng, smem);
+}
+
 // blocks [0, n0): g0; blocks [n0, n0 + n1): g1 -- two independent 64 x 64 x 32 TN split-bf16 products with the fused Adam
 // epilogue (gWd_ext and gWe_ext of the discriminator step).  The launch has more workgroups than the chip holds at once, so
 // the K phase of the later workgroups runs under the Adam streams of the earlier ones.

@@ -654,7 +654,77 @@ struct HeadP {
   int act;
   float* dz;             // [.., ld] top-of-backward output (generated rows)
   float* fm_partials;
+  // discriminator step (round 6, pair_off == 0): dz_rows != 0 -> the workgroup of row r also writes the row-local part of the top of the
+  // backward pass, dz[r, c] = dlogit[r] . wo[c] . act'(a[r, c]); the column sums over all rows (output-layer gradient, float(uid) row) ride in
+  // the gradient GEMM's launch (dis_colsum_body, gemm_multi.hpp gemm_bf16s_colsum) and dis_dz_top_kernel's launch leaves the step
+  int dz_rows = 0;
 };
+
+// The column part of the top of the discriminator's backward pass (dis_dz_top_kernel without the row-local dz): for 16 columns per block,
+//   g_wo[c] = sum_r feat[r, c] . dlogit[r]  (c <= e; column e = the ones column: the output bias)   -> TF-Adam on wo[c] in place
+//   g_u[c]  = sum_r uid[r] . dz[r, c]       (c < e; low-precision modes: the fp32 float(uid) row of W_0_ext) -> TF-Adam on that row's column c
+// 256 threads = 16 columns x 16 row groups; the group partials meet in LDS and are added in group order (fixed, reproducible).
+struct ColSumP {
+  const float* feat; int ld; int e;
+  const float* dlogit; int nrows;
+  const float* dz;
+  float *th, *mo, *vo;              // output layer (e + 1 values)
+  const float* scal; int alpha_idx; float reg;
+  float* sq_partials;               // [blocks] sum(theta_old^2), or nullptr
+  const float* uid; int ldu;        // nullptr: no float(uid) part
+  float *uth, *umo, *uvo, *usq;
+};
+constexpr int CS_COLS = 16, CS_GROUPS = 16;
+inline int dis_colsum_blocks(int e) { return (e + 1 + CS_COLS - 1) / CS_COLS; }
+
+__device__ __forceinline__ void dis_colsum_body(const ColSumP& q, const int blk, float* __restrict__ smem) {
+  float (*red)[CS_COLS] = reinterpret_cast<float (*)[CS_COLS]>(smem);
+  float (*red2)[CS_COLS] = reinterpret_cast<float (*)[CS_COLS]>(smem + CS_GROUPS * CS_COLS);
+  const int cl = threadIdx.x % CS_COLS, g = threadIdx.x / CS_COLS;
+  const int c = blk * CS_COLS + cl;
+  float acc = 0.f, uacc = 0.f;
+  if (c <= q.e) {
+#pragma unroll 4
+    for (int r = g; r < q.nrows; r += CS_GROUPS) {
+      acc += q.feat[(size_t)r * q.ld + c] * q.dlogit[r];
+      if (q.uid && c < q.e) uacc += q.uid[(size_t)r * q.ldu] * q.dz[(size_t)r * q.ld + c];
+    }
+  }
+  red[g][cl] = acc;
+  red2[g][cl] = uacc;
+  __syncthreads();
+  float sqv = 0.f, usv = 0.f;
+  if (g == 0 && c <= q.e) {
+    float t = red[0][cl];
+#pragma unroll
+    for (int k = 1; k < CS_GROUPS; ++k) t += red[k][cl];
+    const float x = q.th[c];
+    sqv = x * x;
+    const float gr = t + q.reg * x;
+    float mm = q.mo[c], vv = q.vo[c];
+    mm += (gr - mm) * (1.f - ADAM_B1);
+    vv += (gr * gr - vv) * (1.f - ADAM_B2);
+    q.mo[c] = mm; q.vo[c] = vv;
+    q.th[c] = adam_step(x, mm * q.scal[q.alpha_idx], vv);
+  }
+  if (q.uid && g == 1 && c < q.e) {
+    float t = red2[0][cl];
+#pragma unroll
+    for (int k = 1; k < CS_GROUPS; ++k) t += red2[k][cl];
+    const float x = q.uth[c];
+    usv = x * x;
+    const float gr = t + q.reg * x;
+    float mm = q.umo[c], vv = q.uvo[c];
+    mm += (gr - mm) * (1.f - ADAM_B1);
+    vv += (gr * gr - vv) * (1.f - ADAM_B2);
+    q.umo[c] = mm; q.uvo[c] = vv;
+    q.uth[c] = adam_step(x, mm * q.scal[q.alpha_idx], vv);
+  }
+  if (threadIdx.x < 64) {      // (wave 0 = row groups 0 .. 3: sqv lives in group 0's lanes, usv in group 1's)
+    if (q.sq_partials) { sqv = wave_sum(sqv); if (threadIdx.x == 0) q.sq_partials[blk] = sqv; }
+    if (q.uid && q.usq) { usv = wave_sum(usv); if (threadIdx.x == 0) q.usq[blk] = usv; }
+  }
+}
 
 // one row's slab sum + epilogue; returns the row's partial dot with wo over this thread's columns
 __device__ __forceinline__ float reduce_row_dot(const RedP& p, const float* __restrict__ wo, int r) {
@@ -723,6 +793,24 @@ __global__ __launch_bounds__(256) void reduce_rows_head_kernel(const RedP p, con
     const float dl = (1.f / (1.f + expf(-sl)) - z) * hd.inv_b;
     hd.dlogit[r] = dl;
     red[4] = dl;
+  }
+  if (hd.pair_off <= 0 && hd.dz_rows) {      // discriminator step: the row-local part of the top of the backward pass (HeadP::dz_rows)
+    __syncthreads();      // red[4]; this thread re-reads the layer outputs it stored itself (reduce_row_dot walks the same columns)
+    const float dl = red[4];
+    const int n4 = (p.N + 3) >> 2;
+    for (int c4 = threadIdx.x; c4 < n4; c4 += 256) {
+      const int c = 4 * c4;
+      const size_t off = (size_t)r * p.ld + c;
+      if (c + 3 < p.N) {
+        const float4 a = *reinterpret_cast<const float4*>(p.out + off);
+        const float4 w = *reinterpret_cast<const float4*>(hd.wo + c);
+        *reinterpret_cast<float4*>(hd.dz + off) = make_float4(dl * w.x * act_grad_out(hd.act, a.x), dl * w.y * act_grad_out(hd.act, a.y),
+                                                             dl * w.z * act_grad_out(hd.act, a.z), dl * w.w * act_grad_out(hd.act, a.w));
+      } else {
+        for (int j = 0; j < 4 && c + j < p.N; ++j) hd.dz[off + j] = dl * hd.wo[c + j] * act_grad_out(hd.act, p.out[off + j]);
+      }
+    }
+    return;
   }
   if (hd.pair_off <= 0) return;
   // generator step: the top of the backward pass for this (generated) row.  Its paired real row's output belongs to ANOTHER

@@ -135,7 +135,9 @@ def test_head_inside_the_slab_sum_launch_matches_the_separate_head(layers, act, 
     o.p["W0"][0, :] *= 1.0 / U
     perm = rng.permutation(U)
     outs = {}
-    for fuse in ("1", "0"):
+    # "1": head in the slab sum and (one layer, round 6) dz_0 rows written there too, the column sums of the backward top inside the gradient
+    # GEMM's launch (gemm_bf16s_colsum); "1,dis_top_gw=0": head in the slab sum, dis_dz_top_kernel as its own launch; "0": every piece its own kernel
+    for fuse in ("1", "1,dis_top_gw=0", "0"):
         monkeypatch.setenv("GANMF_TUNE", "dis_head_fuse=" + fuse)
         eng = _engine(o, urm, B, hp, layers, e, act)
         dl, gl = eng.train_epoch(perm, 1, 1)
@@ -144,12 +146,13 @@ def test_head_inside_the_slab_sum_launch_matches_the_separate_head(layers, act, 
     # both forms against the fp64 oracle at the per-epoch bound of this file; against each other within twice that (TF-Adam turns the
     # last bit of a logit into a visible change of a bias that has barely left zero: b1 differs by 8e-5 of its own 4e-4 scale)
     dl_ref, gl_ref = o.train_epoch(urm, perm, B)
-    for fuse in ("1", "0"):
+    for fuse in ("1", "1,dis_top_gw=0", "0"):
         for n in outs[fuse][0]:
             _close(outs[fuse][0][n], o.p[n], 1e-4, "head fused=%s vs fp64 oracle: %s" % (fuse, n))
         np.testing.assert_allclose(outs[fuse][1], dl_ref, rtol=2e-4)
         np.testing.assert_allclose(outs[fuse][2], gl_ref, rtol=2e-4)
-    for n in outs["1"][0]:
-        _close(outs["1"][0][n], outs["0"][0][n], 2e-4, "fused vs separate head: " + n)
-    np.testing.assert_allclose(outs["1"][1], outs["0"][1], rtol=2e-5)
-    np.testing.assert_allclose(outs["1"][2], outs["0"][2], rtol=2e-5)
+    for other in ("1,dis_top_gw=0", "0"):
+        for n in outs["1"][0]:
+            _close(outs["1"][0][n], outs[other][0][n], 2e-4, "fused vs %s: %s" % (other, n))
+        np.testing.assert_allclose(outs["1"][1], outs[other][1], rtol=2e-5)
+        np.testing.assert_allclose(outs["1"][2], outs[other][2], rtol=2e-5)

@@ -109,8 +109,9 @@ def test_ganmf_steps_all_modes_vs_oracle():
         eng.close()
 
 
+@pytest.mark.parametrize("tune", ["", "dis_top_gw=0", "dis_top_gw=0,dis_uid_top=0"])
 @pytest.mark.parametrize("mfma,loss_tol,m_tol", [("f16", 2e-5, 2e-3), ("bf16", 2e-5, 1.2e-2)])
-def test_c5_disganmf_mixed_precision(mfma, loss_tol, m_tol):
+def test_c5_disganmf_mixed_precision(mfma, loss_tol, m_tol, tune, monkeypatch):
     """BASELINE configs[4]: DisGANMF at ML-1M shape, k = 250, fp16 MFMA inputs (v_mfma_f32_32x32x16_f16) with fp32
     accumulation, fp32 master weights and fp32 Adam accumulators.  fp16 carries 11 significant bits; operands that carry
     the 1/B of the loss gradient are scaled by a power of two at conversion (static loss scaling per GEMM).  The raw
@@ -118,7 +119,12 @@ def test_c5_disganmf_mixed_precision(mfma, loss_tol, m_tol):
     SURVEY 7 prescribes: rank-1 epilogue term forward, fp32 reduction for its weight-row gradient.  Losses agree with
     the fp64 oracle to 2e-5 (measured 3e-8 / 7e-7: the logits are dominated by the fp32 uid term), first-moment
     (= gradient) tensors to 2e-3 of their scale (measured <= 6.4e-4).  The bf16 variant (8 significant bits, same uid
-    handling) is held to 2e-5 / 1.2e-2 (measured 8e-7 / 5.5e-3).  Round 1 rounded the uid column too: 3e-2 / 5e-2."""
+    handling) is held to 2e-5 / 1.2e-2 (measured 8e-7 / 5.5e-3).  Round 1 rounded the uid column too: 3e-2 / 5e-2.
+    tune: "" = the round-6 step (dz_0 rows written by the slab-sum launch, output-layer and float(uid)-row column sums + their Adam updates
+    inside the gradient GEMM's launch, gemm_bf16s_colsum); dis_top_gw=0 = dis_dz_top_kernel as its own launch (with the uid row in it);
+    + dis_uid_top=0 = dis_uid_grad_kernel as well (round 5)."""
+    if tune:
+        monkeypatch.setenv("GANMF_TUNE", tune)
     from ganmf_amd import _lib as L
     from ganmf_amd.engine import Engine
     U, N, k, e, B = 6040, 3706, 250, 1024, 128
