@@ -197,6 +197,8 @@ def _run_staged(monkeypatch, tune, model, U, N, k, e, B, hp, epochs, d_steps, g_
     ("ganmf", 700, 1100, 20, 64, 32, 2, 3, 0.0),         # stand-alone row expansion, generator product, gUb, gV; two D and three G passes per call
     ("ganmf", 700, 1100, 20, 64, 32, 1, 1, 1e-3),        # g_reg != 0: the all-rows update stays per step (every row has a gradient every step)
     ("disganmf", 900, 1100, 64, 128, 64, 1, 2, 0.0),     # float(uid) column in the staged rows
+    ("ganmf", 1500, 3706, 250, 992, 128, 0, 2, 0.0),     # generator passes only: the CSR rows alone are staged in front of the call (round 6)
+    ("disganmf", 900, 1100, 64, 128, 64, 0, 1, 0.0),
 ])
 def test_per_pass_forms_are_bit_identical(case, monkeypatch):
     """Work that a pass's frozen half of the model makes independent of the steps before it, done once per pass:
@@ -204,13 +206,16 @@ def test_per_pass_forms_are_bit_identical(case, monkeypatch):
       formed in front of it -- same tiles, same K order, lr_t from open_steps_kernel;
     * lazy_pass_begin / lazy_pass_end: the all-rows Adam over user_embeddings of a GENERATOR pass (g_reg == 0: a row is read once and has
       a gradient once per pass) as one advance launch in front of the pass and one flush launch behind it;
+    * (round 6) the generator passes read their real rows from the staged blocks -- the reference walks the same slices of one shuffle in both
+      loops (GANMF.py:175-203) -- so a generator step launches no row expansion (g_rows_staged = 2: wherever possible; the default 1: only where that expansion is a launch of its own, i.e. not inside front_kernel; 0: never);
     against every step doing its own (GANMF_TUNE=pass_stage=0,lazy_rows=0)."""
     model, U, N, k, e, B, d_steps, g_steps, g_reg = case
     hp = dict(d_lr=1e-4, g_lr=2e-4, d_reg=1e-4, g_reg=g_reg, recon_coefficient=0.05)
     if model == "ganmf":
         hp.update(m=10.0)
     ref, ref_l = _run_staged(monkeypatch, "pass_stage=0,lazy_rows=0", model, U, N, k, e, B, hp, 2, d_steps, g_steps)
-    for tune in ("pass_stage=1,lazy_rows=0", "pass_stage=0,lazy_rows=1", "pass_stage=1,lazy_rows=1"):
+    for tune in ("pass_stage=1,lazy_rows=0", "pass_stage=0,lazy_rows=1", "pass_stage=1,lazy_rows=1", "pass_stage=1,lazy_rows=1,g_rows_staged=0",
+                 "pass_stage=1,lazy_rows=1,g_rows_staged=2"):
         got, got_l = _run_staged(monkeypatch, tune, model, U, N, k, e, B, hp, 2, d_steps, g_steps)
         for (dl, gl), (dr, gr) in zip(got_l, ref_l):
             np.testing.assert_array_equal(dl, dr, err_msg="D losses, " + tune)
