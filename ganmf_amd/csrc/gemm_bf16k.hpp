@@ -213,6 +213,9 @@ __device__ __forceinline__ void bf16k_mainloop(const GemmP& p, const int tm, con
   static_assert(PD == 4 || PD == 2, "the wait above names every prefetch register");
   at_entry();
   __syncthreads();
+#ifdef GANMF_PERSIST_DIAG_BUILD
+  if (p.stamps && tid == 0) p.stamps[(size_t)blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();      // first K-tile split into LDS
+#endif
 
   auto step = [&](auto ss, int t) {      // K-tile t, whose registers were slot s = t % PD (consumed in iteration t - 1)
     constexpr int s = decltype(ss)::value, s1 = (s + 1) % PD;
@@ -269,9 +272,18 @@ __device__ __forceinline__ void gemm_bf16k_body(const GemmP& p, const int bid, c
   int tm, tn, sp, bz;
   tile_coords(p, bid, nblk, tm, tn, sp, bz);
   f32x16 acc[1][1];
+#ifdef GANMF_PERSIST_DIAG_BUILD      // (GANMF_GEMM_STAMPS: only stand-alone launches hand out a stamp buffer, one slot per block of the grid)
+  if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memrealtime();
+#endif
   bf16k_mainloop<AKM, BKM, NPIECE, F16, 0>(p, tm, tn, sp, bz, smem, acc[0][0], [] {});
+#ifdef GANMF_PERSIST_DIAG_BUILD
+  if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memrealtime();
+#endif
   static_assert(4 * 64 * 64 <= bf16k_smem_dw<NPIECE>(), "the workgroup's LDS must hold the four staged partial tiles");
   gemm_epilogue<64, 64, 1, 1, 4, AKM && BKM>(p, acc, smem, TileCoord{tm, tn, sp, bz, tm * 64, tn * 64});
+#ifdef GANMF_PERSIST_DIAG_BUILD
+  if (p.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); if (threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime(); }
+#endif
 }
 
 template <bool AKM, bool BKM, int NPIECE = 3, bool F16 = false>
@@ -288,6 +300,10 @@ inline hipError_t gemm_bf16k_launch(hipStream_t st, const GemmP& p0, bool akm, b
 #endif
   const int grid = p.tiles_m * p.tiles_n * p.nsplit * p.nbatch;
   if (grid <= 0) return hipSuccess;
+#ifdef GANMF_PERSIST_DIAG_BUILD
+  const bool stamping = gemm_stamps_on() && gemm_stamps_begin(p, grid, st);
+  struct Report { const GemmP& p; int grid; hipStream_t st; bool akm, bkm, on; ~Report() { if (on) gemm_stamps_report(p, grid, st, akm, bkm, NPIECE == 3 ? "gemm_bf16k_mfma (split-bf16, 16 waves)" : "gemm_bf16k_mfma (one piece)"); } } report{p, grid, st, akm, bkm, stamping};
+#endif
   if (!akm && !bkm) GANMF_LAUNCH((gemm_bf16k_mfma<false, false, NPIECE, F16>), dim3(grid), dim3(1024), 0, st, p);
   else if (!akm && bkm) GANMF_LAUNCH((gemm_bf16k_mfma<false, true, NPIECE, F16>), dim3(grid), dim3(1024), 0, st, p);
   else if (akm && bkm) GANMF_LAUNCH((gemm_bf16k_mfma<true, true, NPIECE, F16>), dim3(grid), dim3(1024), 0, st, p);

@@ -151,6 +151,9 @@ __device__ __forceinline__ void bf16w_mainloop(const GemmP& p, const int tm, con
   asm volatile("s_waitcnt vmcnt(0)" :: "v"(rg[0][0]), "v"(rg[0][1]), "v"(rg[0][2]), "v"(rg[1][0]), "v"(rg[1][1]), "v"(rg[1][2]));
   static_assert(PD == 2, "the wait above names every prefetch register");
   __syncthreads();
+#ifdef GANMF_PERSIST_DIAG_BUILD
+  if (p.stamps && tid == 0) p.stamps[(size_t)blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();      // first K-tile split into LDS
+#endif
 
   const int fa = (wr * 32 + li) * (BK / 2) + (((2 * kg + lh) ^ (li & 15)) << 2);      // this lane's fragment of an A plane / of a B plane
   const int fb = li * (BK / 2) + (((2 * kg + lh) ^ (li & 15)) << 2);
@@ -217,7 +220,13 @@ __device__ __forceinline__ void gemm_bf16w_body(const GemmP& p, const int bid, c
   int tm, tn, sp, bz;
   tile_coords(p, bid, nblk, tm, tn, sp, bz);
   f32x16 acc[1][1];
+#ifdef GANMF_PERSIST_DIAG_BUILD
+  if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memrealtime();
+#endif
   bf16w_mainloop<BKM, NPIECE, F16>(p, tm, tn, bz, smem, acc[0][0]);
+#ifdef GANMF_PERSIST_DIAG_BUILD
+  if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memrealtime();
+#endif
   // the eight K groups' 64 x 32 images (the loop's last barrier is behind every fragment read)
   static_assert(BF16W_KG * BF16W_BM * BF16W_BN <= bf16w_smem_dw<NPIECE>(), "the workgroup's LDS must hold the staged partial tiles");
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -226,6 +235,9 @@ __device__ __forceinline__ void gemm_bf16w_body(const GemmP& p, const int bid, c
 #pragma unroll
   for (int r = 0; r < 16; ++r) ct[(wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * BF16W_BN + li] = acc[0][0][r];
   gemm_epilogue<BF16W_BM, BF16W_BN, 1, 1, 4, false, BF16W_KG, true>(p, acc, smem, TileCoord{tm, tn, sp, bz, tm * BF16W_BM, tn * BF16W_BN});
+#ifdef GANMF_PERSIST_DIAG_BUILD
+  if (p.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); if (threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime(); }
+#endif
 }
 
 template <bool BKM, int NPIECE = 3, bool F16 = false>
@@ -271,9 +283,14 @@ inline bool plan_bf16w(GemmPlan& pl, const GemmP& g, bool akm, bool bkm, bool fo
   return true;
 }
 
-inline hipError_t gemm_dispatch_bf16w(hipStream_t st, const GemmP& p, bool bkm, int mode) {      // (tiles / split of the plan: gemm_run)
+inline hipError_t gemm_dispatch_bf16w(hipStream_t st, const GemmP& p0, bool bkm, int mode) {      // (tiles / split of the plan: gemm_run)
+  GemmP p = p0;
   const int grid = p.tiles_m * p.tiles_n * std::max(p.nbatch, 1);
   if (grid <= 0) return hipSuccess;
+#ifdef GANMF_PERSIST_DIAG_BUILD
+  const bool stamping = gemm_stamps_on() && gemm_stamps_begin(p, grid, st);
+  struct Report { const GemmP& p; int grid; hipStream_t st; bool bkm, on; ~Report() { if (on) gemm_stamps_report(p, grid, st, false, bkm, "gemm_bf16w_mfma (64 x 32 tiles, 128-deep K-tiles)"); } } report{p, grid, st, bkm, stamping};
+#endif
   if (p.nsplit != 1 || p.tiles_m != (p.M + BF16W_BM - 1) / BF16W_BM || p.tiles_n != (p.N + BF16W_BN - 1) / BF16W_BN) return hipErrorInvalidValue;
   if (!p.zero_page || (p.lda % 64) != 0 || (p.ldb % 64) != 0) return hipErrorInvalidValue;      // (gemm_bf16w_eligible: never a silent out-of-bounds read)
   if (mode == MFMA_F16) {

@@ -548,6 +548,30 @@ __device__ inline void gemm_epilogue(const GemmP& p, const f32x16 (&acc)[TM][TN]
   // instruction (measured ~2 TB/s chip-wide on 15-90 MB outputs); instead the tile is staged
   // through the now idle ring as a natural [BM][BN] image and written as whole rows, 16 B per lane.
   float* __restrict__ ct = smem + kg * (BM * BN);
+  const bool deferred = p.nsplit > 1;
+  const EpiD& e = p.epi;
+  const bool csr0 = e.csr_indptr != nullptr && bz == 0 && e.kind == EPI_SUB_AUX_SQ;      // the real path's X stays CSR
+  const float* __restrict__ aux = (e.aux && !csr0) ? e.aux + (size_t)bz * e.aux_batch_stride : nullptr;
+  constexpr int C4 = BN / 4, RPP = NTHR / C4 < BM ? NTHR / C4 : BM;
+  constexpr bool SPARE = NTHR / C4 > BM;      // more threads than float4 in the tile: rows past BM are nobody's
+  static_assert(BM % RPP == 0, "row pass must cover the tile in whole steps");
+  static_assert(!SPARE || !ADAM_OK, "the hoisted Adam streams assume every thread owns a row");
+  const int tc = tid % C4, tr = tid / C4;
+  const int col = n0 + tc * 4;
+  // (round 6) A workgroup whose row pass is ONE step (the 16-wave kernels: 1024 threads on a 64 x 64 or 64 x 32 tile) requests its float4 of
+  // the auxiliary matrix (decode: the input it subtracts; dF: Delta; DisGANMF's backward: the layer output) HERE, in front of the exchange of
+  // the K groups' partial tiles through LDS and its barrier, instead of behind them: the in-kernel stamps show 1.5-2 us of a 3 us epilogue
+  // waiting for that dependent fetch (profiles/r06_launch_fixed_part.md).  Same values, same arithmetic.
+  float4 auxv = make_float4(0.f, 0.f, 0.f, 0.f);
+  bool aux_pre = false;
+  if constexpr (BM == RPP) {
+    const int row = m0 + tr;
+    if (!deferred && aux && (e.kind == EPI_SUB_AUX_SQ || e.kind == EPI_SUB_SCALED_AUX || e.kind == EPI_MUL_ACTGRAD) && row < p.M && col + 3 < p.N &&
+        (!SPARE || tr < BM)) {
+      auxv = *reinterpret_cast<const float4*>(aux + (size_t)row * e.ldaux + col);
+      aux_pre = true;
+    }
+  }
   if constexpr (!STAGED) {
 #pragma unroll
     for (int a = 0; a < TM; ++a)
@@ -560,19 +584,9 @@ __device__ inline void gemm_epilogue(const GemmP& p, const f32x16 (&acc)[TM][TN]
   __syncthreads();
 
   float* __restrict__ C = p.C + (size_t)sp * p.c_split_stride + (size_t)bz * p.c_batch_stride;
-  const bool deferred = p.nsplit > 1;
-  const EpiD& e = p.epi;
-  const bool csr0 = e.csr_indptr != nullptr && bz == 0 && e.kind == EPI_SUB_AUX_SQ;      // the real path's X stays CSR
-  const float* __restrict__ aux = (e.aux && !csr0) ? e.aux + (size_t)bz * e.aux_batch_stride : nullptr;
   const bool sp_add = !(p.nsplit > 1) && e.sp_rows != nullptr;      // gWe_ext: the real rows' share comes from the CSC matrix
   float sq = 0.f;
-  constexpr int C4 = BN / 4, RPP = NTHR / C4 < BM ? NTHR / C4 : BM;
-  constexpr bool SPARE = NTHR / C4 > BM;      // more threads than float4 in the tile: rows past BM are nobody's
-  static_assert(BM % RPP == 0, "row pass must cover the tile in whole steps");
-  static_assert(!SPARE || !ADAM_OK, "the hoisted Adam streams assume every thread owns a row");
   ct = smem;
-  const int tc = tid % C4, tr = tid / C4;
-  const int col = n0 + tc * 4;
   const bool adam = ADAM_OK && !deferred && e.kind == EPI_ADAM;
   const float alpha = adam ? *e.adam_alpha : 0.f;
   float* __restrict__ theta_out = e.adam_theta_out ? e.adam_theta_out : e.adam_theta;
@@ -699,7 +713,15 @@ __device__ inline void gemm_epilogue(const GemmP& p, const f32x16 (&acc)[TM][TN]
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o[q]), slab_rsrc, boff + 4 * q, 0, 16);
         }
       } else if (col + 3 < p.N) {
-        if (!deferred) {
+        if (aux_pre) {      // (the auxiliary values arrived while the partial tiles met in LDS: epi_apply's three cases on them)
+          const float a4[4] = {auxv.x, auxv.y, auxv.z, auxv.w};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            if (e.kind == EPI_SUB_AUX_SQ) { o[q] -= a4[q]; sq += o[q] * o[q]; }
+            else if (e.kind == EPI_SUB_SCALED_AUX) o[q] -= e.c * a4[q];
+            else o[q] *= act_grad_out(e.act, a4[q]);
+          }
+        } else if (!deferred) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) o[q] = epi_apply(e, o[q], row, col + q, p.ldc, aux, sq);
         }
@@ -1285,6 +1307,45 @@ inline void choose_tile_order(GemmP& p, const GemmPlan& pl) {
   p.xb_band = band;
 }
 
+#ifdef GANMF_PERSIST_DIAG_BUILD
+// (make DIAG=1, GANMF_GEMM_STAMPS=1) four s_memrealtime stamps per workgroup of a 16-wave GEMM launch -- entry, first K-tile landed, K loop done,
+// stores drained -- and their distribution over the launch's workgroups, for the first three launches of every shape: gemm_f32_mfma<.., 4>,
+// gemm_bf16k_mfma and gemm_bf16w_mfma (profiles/r03_gemm_stamps.md, profiles/r06_launch_fixed_part.md)
+inline bool gemm_stamps_on() { const char* v = getenv("GANMF_GEMM_STAMPS"); return v && atoi(v) != 0; }
+inline bool gemm_stamps_begin(GemmP& p, int grid, hipStream_t st) {
+  static unsigned long long* dbg = nullptr;
+  static int cap = 0;
+  if (grid > cap) { if (dbg) (void)hipFree(dbg); if (hipMalloc((void**)&dbg, (size_t)grid * 32) != hipSuccess) return false; cap = grid; }
+  (void)hipMemsetAsync(dbg, 0, (size_t)grid * 32, st);
+  p.stamps = dbg;
+  return true;
+}
+inline void gemm_stamps_report(const GemmP& p, int grid, hipStream_t st, bool akm, bool bkm, const char* kernel) {
+  (void)hipStreamSynchronize(st);
+  static std::vector<long long> seen;
+  const long long key = ((long long)p.M << 40) ^ ((long long)p.N << 20) ^ p.K ^ ((long long)akm << 62) ^ ((long long)bkm << 61) ^ ((long long)p.epi.kind << 56);
+  if (std::count(seen.begin(), seen.end(), key) >= 3) return;
+  seen.push_back(key);
+  std::vector<unsigned long long> hs((size_t)grid * 4);
+  (void)hipMemcpy(hs.data(), p.stamps, hs.size() * 8, hipMemcpyDeviceToHost);
+  unsigned long long t_min = ~0ull, t_max = 0;
+  for (int b = 0; b < grid; ++b) { t_min = std::min(t_min, hs[4 * b]); t_max = std::max(t_max, hs[4 * b + 3]); }
+  auto stat = [&](auto f, const char* name) {
+    std::vector<double> v(grid);
+    for (int b = 0; b < grid; ++b) v[b] = f(b) * 0.01;      // 100 MHz ticks -> us
+    std::sort(v.begin(), v.end());
+    fprintf(stderr, "  %-34s min %6.2f  median %6.2f  p90 %6.2f  max %6.2f us\n", name, v[0], v[grid / 2], v[(size_t)(grid * 0.9)], v[grid - 1]);
+  };
+  fprintf(stderr, "[gemm stamps] %s M=%d N=%d K=%d nsplit %d epi %d akm %d bkm %d: %d workgroups, first entry -> last exit %.2f us\n", kernel, p.M, p.N, p.K, p.nsplit,
+          (int)p.epi.kind, (int)akm, (int)bkm, grid, (t_max - t_min) * 0.01);
+  stat([&](int b) { return (double)(hs[4 * b] - t_min); }, "entry after the first entry");
+  stat([&](int b) { return (double)(hs[4 * b + 1] - hs[4 * b]); }, "entry -> first K-tile in LDS");
+  stat([&](int b) { return (double)(hs[4 * b + 2] - hs[4 * b + 1]); }, "K loop");
+  stat([&](int b) { return (double)(hs[4 * b + 3] - hs[4 * b + 2]); }, "epilogue + store drain");
+  stat([&](int b) { return (double)(t_max - hs[4 * b + 3]); }, "exit before the last exit");
+}
+#endif
+
 inline hipError_t gemm_dispatch_skinny(hipStream_t st, const GemmP& p0, bool bkm, int rt);
 inline hipError_t gemm_dispatch_skinny_n(hipStream_t st, const GemmP& p0, bool bkm);
 inline hipError_t gemm_dispatch_bf16w(hipStream_t st, const GemmP& p, bool bkm, int mode);
@@ -1305,37 +1366,11 @@ inline hipError_t gemm_dispatch(hipStream_t st, const GemmP& p0, bool akm, bool 
 #ifdef GANMF_PERSIST_DIAG_BUILD
   // diagnostic build (make DIAG=1), GANMF_GEMM_STAMPS=1: where the time of a 16-wave launch goes -- dispatch ramp, first K-tile,
   // K loop, epilogue + store drain -- from four 100 MHz stamps per workgroup, printed for the first launches of every shape
-  if (pl.kg == 4 && getenv("GANMF_GEMM_STAMPS") && atoi(getenv("GANMF_GEMM_STAMPS"))) {
+  if (pl.kg == 4 && gemm_stamps_on()) {
     const int grid = p.tiles_m * p.tiles_n * p.nsplit * p.nbatch;
-    static unsigned long long* dbg = nullptr;
-    static int cap = 0;
-    if (grid > cap) { if (dbg) (void)hipFree(dbg); if (hipMalloc((void**)&dbg, (size_t)grid * 32) != hipSuccess) return hipErrorOutOfMemory; cap = grid; }
-    (void)hipMemsetAsync(dbg, 0, (size_t)grid * 32, st);
-    p.stamps = dbg;
+    if (!gemm_stamps_begin(p, grid, st)) return hipErrorOutOfMemory;
     const hipError_t e = gemm_launch_t<64, 64, 64, 3, 4>(st, p, akm, bkm);
-    (void)hipStreamSynchronize(st);
-    static std::vector<long long> seen;
-    const long long key = ((long long)p.M << 40) ^ ((long long)p.N << 20) ^ p.K ^ ((long long)akm << 62) ^ ((long long)bkm << 61) ^ ((long long)p.epi.kind << 56);
-    if (std::count(seen.begin(), seen.end(), key) < 3) {
-      seen.push_back(key);
-      std::vector<unsigned long long> hs((size_t)grid * 4);
-      (void)hipMemcpy(hs.data(), dbg, hs.size() * 8, hipMemcpyDeviceToHost);
-      unsigned long long t_min = ~0ull, t_max = 0;
-      for (int b = 0; b < grid; ++b) { t_min = std::min(t_min, hs[4 * b]); t_max = std::max(t_max, hs[4 * b + 3]); }
-      auto stat = [&](auto f, const char* name) {
-        std::vector<double> v(grid);
-        for (int b = 0; b < grid; ++b) v[b] = f(b) * 0.01;      // 100 MHz ticks -> us
-        std::sort(v.begin(), v.end());
-        fprintf(stderr, "  %-34s min %6.2f  median %6.2f  p90 %6.2f  max %6.2f us\n", name, v[0], v[grid / 2], v[(size_t)(grid * 0.9)], v[grid - 1]);
-      };
-      fprintf(stderr, "[gemm stamps] M=%d N=%d K=%d nsplit %d epi %d akm %d bkm %d: %d workgroups, first entry -> last exit %.2f us\n", p.M, p.N, p.K, p.nsplit,
-              (int)p.epi.kind, (int)akm, (int)bkm, grid, (t_max - t_min) * 0.01);
-      stat([&](int b) { return (double)(hs[4 * b] - t_min); }, "entry after the first entry");
-      stat([&](int b) { return (double)(hs[4 * b + 1] - hs[4 * b]); }, "entry -> first K-tile in LDS");
-      stat([&](int b) { return (double)(hs[4 * b + 2] - hs[4 * b + 1]); }, "K loop");
-      stat([&](int b) { return (double)(hs[4 * b + 3] - hs[4 * b + 2]); }, "epilogue + store drain");
-      stat([&](int b) { return (double)(t_max - hs[4 * b + 3]); }, "exit before the last exit");
-    }
+    gemm_stamps_report(p, grid, st, akm, bkm, "fp32 ring, 16 waves");
     return e;
   }
 #endif
