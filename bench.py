@@ -404,7 +404,7 @@ def extra_workload(w, e, world, rank, local_rank, steps, warmup, sync, torch, di
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=192)
+    ap.add_argument("--steps", type=int, default=200)      # (>= 200 timed steps, median of five repeats)
     ap.add_argument("--warmup", type=int, default=96)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
