@@ -286,12 +286,16 @@ __device__ __forceinline__ void gemm_bf16k_body(const GemmP& p, const int bid, c
 #endif
 }
 
+// (one-piece forms: 64 KiB of LDS, so two workgroups fit a CU -- if the CU admits their 32 waves: floor(800 / (ceil(sgpr / 16) * 16 + 16)) waves per SIMD
+// is 8 only at <= 80 scalar registers (gemm_multi.hpp pair_kernel; the staged pass's batched generator launch has 5 452 workgroups))
 template <bool AKM, bool BKM, int NPIECE = 3, bool F16 = false>
 __global__ __launch_bounds__(1024) void gemm_bf16k_mfma(const GemmP p) {
   __shared__ __attribute__((aligned(16))) float smem[bf16k_smem_dw<NPIECE>()];      // three pieces: 96 KiB, one workgroup per CU; one piece: 64 KiB
   gemm_bf16k_body<AKM, BKM, NPIECE, F16>(p, (int)blockIdx.x, (int)gridDim.x, smem);
 }
 
+// (Round 6: the one-piece forms with their scalar registers capped at 80 -- two 64-KiB workgroups per CU admitted, as for pair_kernel -- measured 0.5-1 % SLOWER
+// on configs[4]: their grids are one round anyway except the per-pass batched generator launch, and the spills cost the loop.  Not kept.)
 template <int NPIECE, bool F16>
 inline hipError_t gemm_bf16k_launch(hipStream_t st, const GemmP& p0, bool akm, bool bkm) {
   GemmP p = p0;
@@ -304,10 +308,12 @@ inline hipError_t gemm_bf16k_launch(hipStream_t st, const GemmP& p0, bool akm, b
   const bool stamping = gemm_stamps_on() && gemm_stamps_begin(p, grid, st);
   struct Report { const GemmP& p; int grid; hipStream_t st; bool akm, bkm, on; ~Report() { if (on) gemm_stamps_report(p, grid, st, akm, bkm, NPIECE == 3 ? "gemm_bf16k_mfma (split-bf16, 16 waves)" : "gemm_bf16k_mfma (one piece)"); } } report{p, grid, st, akm, bkm, stamping};
 #endif
-  if (!akm && !bkm) GANMF_LAUNCH((gemm_bf16k_mfma<false, false, NPIECE, F16>), dim3(grid), dim3(1024), 0, st, p);
-  else if (!akm && bkm) GANMF_LAUNCH((gemm_bf16k_mfma<false, true, NPIECE, F16>), dim3(grid), dim3(1024), 0, st, p);
-  else if (akm && bkm) GANMF_LAUNCH((gemm_bf16k_mfma<true, true, NPIECE, F16>), dim3(grid), dim3(1024), 0, st, p);
-  else return hipErrorInvalidValue;
+  {
+    if (!akm && !bkm) GANMF_LAUNCH((gemm_bf16k_mfma<false, false, NPIECE, F16>), dim3(grid), dim3(1024), 0, st, p);
+    else if (!akm && bkm) GANMF_LAUNCH((gemm_bf16k_mfma<false, true, NPIECE, F16>), dim3(grid), dim3(1024), 0, st, p);
+    else if (akm && bkm) GANMF_LAUNCH((gemm_bf16k_mfma<true, true, NPIECE, F16>), dim3(grid), dim3(1024), 0, st, p);
+    else return hipErrorInvalidValue;
+  }
   return hipGetLastError();
 }
 

@@ -81,8 +81,11 @@ __global__ __launch_bounds__(256 * KG) void de_dcoef_kernel(const GemmP g, const
 // blocks [0, n0): g0, an NN GEMM; blocks [n0, n0 + n1): g1, a TN GEMM
 // NS = 2: 64 KiB of LDS and 52 VGPRs per workgroup, so TWO of the 16-wave workgroups share a CU and the 464 workgroups of
 // the C2 pair are resident in one round (with the 96 KiB ring of the single-GEMM launches they ran as two rounds)
+// SGPRs capped at 80 (round 6): a CU admits floor(800 / (ceil(sgpr / 16) * 16 + 16)) waves per SIMD -- at the 106 scalar registers hipcc took for this
+// kernel that is 6, i.e. ONE 16-wave workgroup per CU whatever its LDS, and in-kernel stamps showed the gV range entering only after the gUb range had
+// left (profiles/r06_pair_kernel.md); at <= 80 it is 8, two workgroups per CU, which is what NS = 2 was built for.
 template <int KG, int NS>
-__global__ __launch_bounds__(256 * KG) void pair_kernel(const GemmP g0, const GemmP g1) {
+__global__ __launch_bounds__(256 * KG) __attribute__((amdgpu_num_sgpr(80))) void pair_kernel(const GemmP g0, const GemmP g1) {
   __shared__ __attribute__((aligned(16))) float smem[NS * (64 + 64) * 64];
   const int n0 = g0.tiles_m * g0.tiles_n * g0.nsplit * g0.nbatch;
   const int n1 = g1.tiles_m * g1.tiles_n * g1.nsplit * g1.nbatch;
@@ -93,7 +96,7 @@ __global__ __launch_bounds__(256 * KG) void pair_kernel(const GemmP g0, const Ge
 // the same pair on a low-precision handle: gUb (NN, split-K slabs) and gV (TN, fused Adam into the second V buffer) on the 16-wave one-piece
 // loop each of them runs stand-alone (gemm_bf16k_mfma<.., 1, F16>: bit-identical); 64 KiB of LDS, two workgroups per CU
 template <bool F16>
-__global__ __launch_bounds__(1024) void pair_lp_kernel(const GemmP g0, const GemmP g1) {
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) void pair_lp_kernel(const GemmP g0, const GemmP g1) {
   __shared__ __attribute__((aligned(16))) float smem[bf16k_smem_dw<1>()];
   const int n0 = g0.tiles_m * g0.tiles_n * g0.nsplit * g0.nbatch;
   const int n1 = g1.tiles_m * g1.tiles_n * g1.nsplit * g1.nbatch;
