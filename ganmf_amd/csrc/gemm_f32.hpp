@@ -1008,6 +1008,7 @@ struct RedP {
   int M, N;
   long long batch_stride;   // of part and out
   EpiD epi;
+  int sc1 = 0;              // 1: the sums are handed to OTHER workgroups of the same launch (wgrad_seam_kernel): write-through (sc1) 16-byte stores
 };
 
 // Slab groups of the reduce: a small output behind a deep split (the reference's defaults on LastFM: 64 x 32 outputs, K = 17 632,
@@ -1038,11 +1039,22 @@ __device__ __forceinline__ void splitk_reduce_body(const RedP& p, const int bx, 
     if (c + 3 < p.N) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) o[j] = epi_apply(e, o[j], m, c + j, p.ld, aux, sq);
+      if (p.sc1) {      // (cdna guide section 6, Guideline 16 R1: payload stored write-through, the storing waves drain before the arrival is counted)
+        typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)out, (short)0, 0x7fffffff, 0x00020000);
+        u32x4s bits;
+        bits[0] = __float_as_uint(o[0]); bits[1] = __float_as_uint(o[1]); bits[2] = __float_as_uint(o[2]); bits[3] = __float_as_uint(o[3]);
+        __builtin_amdgcn_raw_buffer_store_b128(bits, rs, (int)(off * sizeof(float)), 0, 16 /* sc1 */);
+      } else
       *reinterpret_cast<float4*>(out + off) = make_float4(o[0], o[1], o[2], o[3]);
       if (e.planes) planes_store4(PlaneRef{e.planes, e.plane_stride}, off, o[0], o[1], o[2], o[3]);
     } else {
       for (int j = 0; j < 4 && c + j < p.N; ++j) {
         const float r = epi_apply(e, o[j], m, c + j, p.ld, aux, sq);
+        if (p.sc1) {
+          const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)out, (short)0, 0x7fffffff, 0x00020000);
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r), rs, (int)((off + j) * sizeof(float)), 0, 16);
+        } else
         out[off + j] = r;
         if (e.planes) planes_store1(PlaneRef{e.planes, e.plane_stride}, off + j, r);
       }

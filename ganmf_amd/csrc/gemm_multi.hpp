@@ -136,6 +136,40 @@ __global__ __launch_bounds__(256, 2) void wgrad_pair_kernel(const GemmP g0, cons
   else gemm_bf16s_body<64, 64, 32, true, true, 3>(g1, (int)blockIdx.x - n0, n1, smem);
 }
 
+// (round 6, GANMF_TUNE wgrad_seam) the same two products with the slab sum of dE -- which only the gWe range reads -- as the FIRST block range of the launch instead of a
+// launch of its own: blocks [0, nred) sum the slabs and store dE write-through (sc1), drain and count themselves in on an agent-scope counter; blocks [nred, nred + n0) are
+// gWd_ext + Adam(Wd), which never read dE; blocks [nred + n0, ...) are gWe_ext + Adam(We): one lane polls the counter (relaxed), one agent-scope acquire, barrier, then the
+// ordinary body (cdna guide section 6, Guideline 16, counter form).  Workgroups are dispatched in block order, so every reduce block has been DISPATCHED before the first gWe
+// block exists, and by the time the chip has worked through 512 reduce and 928 gWd blocks the sums have long landed: the poll normally passes at once.  Liveness does not rest on
+// that alone: the poll is bounded, and a block that gives up raises cnt[1] (the host turns it into an error) and goes on rather than hang.
+__global__ __launch_bounds__(256, 2) void wgrad_seam_kernel(const GemmP g0, const GemmP g1, const RedP r, const int nred, unsigned long long* cnt,
+                                                            const unsigned long long target) {
+  __shared__ __attribute__((aligned(16))) float smem[Bf16sLds<64, 64, 32, 3>::DW];
+  static_assert(Bf16sLds<64, 64, 32, 3>::DW >= 4 + 4 * 256, "splitk_reduce_body's LDS");
+  const int n0 = g0.tiles_m * g0.tiles_n * g0.nsplit * g0.nbatch;
+  const int n1 = g1.tiles_m * g1.tiles_n * g1.nsplit * g1.nbatch;
+  const int b = (int)blockIdx.x;
+  if (b < nred) {
+    splitk_reduce_body(r, b, nred, 0, smem);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // EVERY storing wave drains its write-through stores ...
+    __syncthreads();                                       // ... before ONE lane counts the block in
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  if (b < nred + n0) { gemm_bf16s_body<64, 64, 32, true, true, 3>(g0, b - nred, n0, smem); return; }
+  if (threadIdx.x == 0) {
+    unsigned spins = 0;
+    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(4);
+      if (++spins > (1u << 22)) { __hip_atomic_store(cnt + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }      // (seconds: something is badly wrong)
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  gemm_bf16s_body<64, 64, 32, true, true, 3>(g1, b - nred - n0, n1, smem);
+}
+
 // ---- host side: can this plan ride in the combined launch?
 inline bool plan_is_f32_64_kg(const GemmPlan& pl, int kg) {
   return pl.mode == MFMA_F32 && pl.tile == 64 && pl.ring == 3 && pl.kg == kg && !pl.persist;

@@ -124,6 +124,28 @@ def test_wd_on_the_side_lane_bit_identical(shape, d_steps, monkeypatch):
             np.testing.assert_array_equal(got[n], ref[n], err_msg="%s, wd_lane=%s" % (n, mode))
 
 
+@pytest.mark.parametrize("shape,d_steps", [
+    ((900, 3706, 32, 992, 128), 2),
+    ((230, 300, 16, 70, 64), 1),
+])
+def test_dE_slab_sum_inside_the_weight_gradient_launch_bit_identical(shape, d_steps, monkeypatch):
+    """GANMF_TUNE wgrad_seam=1: the slab sum of dE as the first block range of the fused weight-gradient launch (wgrad_seam_kernel: write-through stores,
+    an agent-scope arrival counter, one acquire in every gWe workgroup) instead of a launch of its own.  The same sums by the same bodies: every tensor,
+    both Adam moments and every loss bit for bit; two handles in a row (the counter is per handle and monotonic)."""
+    U, N, k, e, B = shape
+    hp = dict(d_lr=1e-4, g_lr=2e-4, d_reg=1e-4, g_reg=0.0, m=10.0, recon_coefficient=0.05)
+    monkeypatch.setenv("GANMF_TUNE", "wgrad_seam=0")
+    ref, ref_l = _run(monkeypatch, 31, 1, U, N, k, e, B, hp, epochs=3, d_steps=d_steps)
+    monkeypatch.setenv("GANMF_TUNE", "wgrad_seam=1")
+    for _ in range(2):
+        got, got_l = _run(monkeypatch, 31, 1, U, N, k, e, B, hp, epochs=3, d_steps=d_steps)
+        for (dl, gl), (dr, gr) in zip(got_l, ref_l):
+            np.testing.assert_array_equal(dl, dr, err_msg="D losses, wgrad_seam=1")
+            np.testing.assert_array_equal(gl, gr, err_msg="G losses, wgrad_seam=1")
+        for n in ref:
+            np.testing.assert_array_equal(got[n], ref[n], err_msg="%s, wgrad_seam=1" % n)
+
+
 def test_second_item_buffer_survives_snapshot_and_restore(monkeypatch):
     """The fused gV update ping-pongs item_embeddings between two buffers: best-weights snapshot / restore and a tensor
     upload in the middle of training must act on the live one (an odd number of generator steps leaves it in the second)."""
