@@ -212,7 +212,7 @@ def cpu_baseline(urm, params, w, seconds):
             n1, el1 = sample(seconds / 3.0, n + 1)
         out1 = {"value_1thread": round(2 * n1 / el1, 3),
                 "sample_1thread": "%d D + %d G updates, BLAS pool limited to one thread (threadpoolctl), %.1f s" % (n1, n1, el1)}
-    except ImportError as ex:      # (no threadpoolctl: the pool's own thread count, no one-thread figure)
+    except Exception as ex:      # (no threadpoolctl, or it cannot steer this BLAS: the pool's own thread count, no one-thread figure -- never lose the line to it)
         n, el = sample(seconds, 1)
         threads = os.cpu_count() or 1
         out1 = {"value_1thread": None, "sample_1thread": "not measured: %s" % ex}
