@@ -117,3 +117,71 @@ def test_engine_create_destroy_does_not_leak():
     cycle(40)
     free1 = free_bytes()
     assert free0 - free1 < 8 << 20, "device memory shrank by %.1f MiB over 40 engine lifetimes" % ((free0 - free1) / 2 ** 20)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_low_precision_launch_forms_random_config(seed, monkeypatch):
+    """Handles created with mfma = "f16" | "bf16" over random shapes wide enough for the combined launches (round 6: front_lp_kernel, pair_lp_kernel, the
+    one-piece 64 x 32 kernel, DisGANMF's dz_0 rows + column sums inside the gradient GEMM's launch):
+    * GANMF, two epochs: gUb + gV in one launch (pair_lp_kernel; the per-pass update of U with it) against the two stand-alone products -- bit for bit
+      (GANMF_MULTI = 127 against 65, i.e. the generator launch combined on both sides: with that bit off the planner may split the generator product along K,
+      another sum; bf16w = 0 on both sides for the same reason);
+    * both models, one D and one G step from the same weights: the default plan against one kernel per piece (+ the round-5 kernels of DisGANMF's backward
+      top) within the single-rounding error of the mode on every first moment, i.e. on every gradient."""
+    from ganmf_amd import _lib as L
+    from ganmf_amd.engine import Engine
+    rng = np.random.RandomState(3000 + seed)
+    mfma = "f16" if seed % 2 == 0 else "bf16"
+    dis = seed % 4 >= 2
+    U, N = int(rng.randint(300, 900)), int(rng.randint(600, 4000))
+    k, e, B = int(rng.choice([16, 64, 100, 250])), int(rng.choice([64, 200, 512, 1024])), int(rng.choice([64, 96, 128]))
+    hp = dict(d_lr=1e-4, g_lr=2e-4, d_reg=float(rng.choice([0.0, 1e-4])), g_reg=0.0, recon_coefficient=float(rng.uniform(0.05, 0.9)))
+    urm = sps.csr_matrix((rng.rand(U, N) < 0.04).astype(np.float32))
+    if dis:
+        w = {"W0": rng.randn(N + 1, e) * 0.03, "b0": rng.randn(e) * 0.01, "Wo": rng.randn(e, 1) * 0.1, "bo": np.zeros(1), "U": rng.randn(U, k) * 0.1, "V": rng.randn(N, k) * 0.1}
+        w["W0"][0, :] *= 1.0 / U      # the float(uid) row
+        ids = {"W0": 0, "b0": 1, "Wo": 2, "bo": 3, "U": 100, "V": 101}
+        kw = dict(model=L.MODEL_DISGANMF, d_layers=1, d_act=str(rng.choice(["linear", "tanh", "relu"])), m=0.0)
+    else:
+        w = {"We": rng.randn(N, e) * 0.03, "be": rng.randn(e) * 0.01, "Wd": rng.randn(e, N) * 0.03, "bd": rng.randn(N) * 0.01, "U": rng.randn(U, k) * 0.1, "V": rng.randn(N, k) * 0.1}
+        ids = {"We": 0, "be": 1, "Wd": 2, "bd": 3, "U": 100, "V": 101}
+        kw = dict(m=10.0)
+    w = {n: v.astype(np.float32) for n, v in w.items()}
+    perms = [rng.permutation(U) for _ in range(2)]
+    uids = perms[0][:B]
+    what = str((mfma, "DisGANMF" if dis else "GANMF", U, N, k, e, B))
+
+    def run(multi, tune, epochs):
+        monkeypatch.setenv("GANMF_MULTI", str(multi))
+        monkeypatch.setenv("GANMF_TUNE", tune)
+        eng = Engine(U, N, k, e, B, mfma=mfma, **kw, **hp)
+        eng.set_urm(urm)
+        for n, tid in ids.items():
+            eng.set_tensor(tid, w[n])
+        if epochs:
+            losses = [eng.train_epoch(p, 1, 1) for p in perms]
+        else:
+            losses = [(np.array([eng.train_step(0, uids)]), np.array([eng.train_step(1, uids)]))]
+        out = {n: eng.get_tensor(tid).copy() for n, tid in ids.items()}
+        out.update({n + ".m": eng.get_tensor(tid, slot=L.SLOT_ADAM_M).copy() for n, tid in ids.items()})
+        eng.close()
+        return out, losses
+    if not dis:
+        ref, ref_l = run(65, "bf16w=0", True)
+        got, got_l = run(127, "bf16w=0", True)
+        for n in ref:
+            np.testing.assert_array_equal(got[n], ref[n], err_msg="%s %s" % (n, what))
+        for (dl, gl), (dr, gr) in zip(got_l, ref_l):
+            np.testing.assert_array_equal(dl, dr, err_msg=what)
+            np.testing.assert_array_equal(gl, gr, err_msg=what)
+    ref, ref_l = run(64, "bf16w=0,dis_top_gw=0,dis_uid_top=0", False)
+    got, got_l = run(127, "", False)
+    # a gradient element moves by its single-rounding error when the order of a low-precision sum changes (or the generator product is split along K)
+    tol = 3e-3 if mfma == "f16" else 2e-2
+    for n in ids:
+        err = _err(got[n + ".m"], ref[n + ".m"].astype(np.float64))
+        assert err <= tol, (n, what, err)
+        lr = hp["g_lr"] if n in ("U", "V") else hp["d_lr"]
+        assert _err(got[n], ref[n].astype(np.float64)) <= 2.2 * lr / np.max(np.abs(ref[n])) + 1e-6, (n, what)      # <= 2 lr per update
+    np.testing.assert_allclose(got_l[0][0], ref_l[0][0], rtol=2e-3, atol=1e-6, err_msg=what)
+    np.testing.assert_allclose(got_l[0][1], ref_l[0][1], rtol=2e-3, atol=1e-6, err_msg=what)
